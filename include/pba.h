@@ -1,0 +1,199 @@
+/*
+ * pba.h -- C-ABI of the MI355X photometric bundle-adjustment engine (libpba_hip.so).
+ *
+ * This is the drop-in boundary for the ONE hot path the engine replaces: the inner seam of
+ * PhotometricBundleAdjustment::optimize(), reference src/photobundle.cc:784-829, i.e.
+ *
+ *     ceres::Problem problem;                                            (:784)
+ *     problem.AddResidualBlock(DescriptorError::Create(...), loss, camera_ptr, xyz);   (:801-802)
+ *     problem.SetParameterBlockConstant(first_camera);                   (:809-813)
+ *     ceres::Solve(GetSolverOptions(...), &problem, &summary);           (:829)
+ *
+ * plus the per-frame plane producer feeding it (DescriptorFrame, :151-257 / imgproc.cc:27-95).
+ * Everything is `extern "C"`, plain pointers and sizes, no C++/torch types.  Functions return 0 on
+ * success or a negative pba_status; they never throw.  All host buffers are caller-owned and are
+ * only read/written during the call; all device memory is engine-owned.  One host thread per handle.
+ *
+ * Data conventions (identical to what the reference hands to Ceres):
+ *   cameras  : 6 doubles per window slot = angle-axis (3) + translation (3) of the WORLD->CAMERA
+ *              transform (photobundle.cc:646-656 PoseToParams of the inverted pose, :774-778)
+ *   points   : 3 doubles, world XYZ (photobundle.cc:795)
+ *   desc     : (2R+1)^2 doubles per point, row-major patch of channel 0 (photobundle.cc:466-479,
+ *              :597-603); values are float casts of pixels, stored as fp32 on the device
+ *   obs      : one residual block per (point, slot) entry, grouped by point (photobundle.cc:791-804)
+ *   weights  : (2R+1)^2 doubles (photobundle.cc:617-644)
+ */
+#ifndef PBA_H
+#define PBA_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PBA_MAX_FRAMES 32
+#define PBA_MAX_RADIUS 5
+
+typedef struct pba_engine pba_engine;
+
+typedef enum pba_status {
+  PBA_OK = 0,
+  PBA_ERR_INVALID = -1,     /* bad argument */
+  PBA_ERR_HIP = -2,         /* HIP runtime error (see pba_last_error) */
+  PBA_ERR_NO_DEVICE = -3,   /* no gfx950 device visible: there is NO CPU fallback */
+  PBA_ERR_STATE = -4,       /* call order violated (e.g. solve before set_problem) */
+  PBA_ERR_COMM = -5,        /* collective transport error */
+  PBA_ERR_NUMERIC = -6      /* non-finite evaluation at the initial point */
+} pba_status;
+
+/* Replaces the constructor arguments of PhotometricBundleAdjustment (photobundle.h:148) that matter on the
+ * hot path: Calibration (calibration.h:19-26), ImageSize (types.h:57-63), Options::patchRadius /
+ * slidingWindowSize / robustThreshold (photobundle.h:26-85). */
+typedef struct pba_config {
+  int32_t rows, cols;        /* image size */
+  int32_t max_frames;        /* window slots (Options::slidingWindowSize), <= PBA_MAX_FRAMES */
+  int32_t radius;            /* Options::patchRadius, 1..PBA_MAX_RADIUS */
+  double fx, fy, cx, cy;     /* pinhole intrinsics */
+  double huber;              /* Options::robustThreshold; <= 0 disables the loss (photobundle.cc:797-798) */
+  int32_t device;            /* HIP device ordinal */
+  int32_t flags;             /* reserved, 0 */
+} pba_config;
+
+/* ceres::Solver::Options as configured by GetSolverOptions (photobundle.cc:738-761) + the Ceres defaults
+ * that shape the path.  pba_default_solver_options fills the reference's values. */
+typedef struct pba_solver_options {
+  int32_t max_num_iterations;            /* 500  (photobundle.cc:751) */
+  int32_t max_num_consecutive_invalid_steps; /* 5 */
+  double function_tolerance;             /* 1e-6 (photobundle.cc:756) */
+  double gradient_tolerance;             /* 1e-6 (:757) */
+  double parameter_tolerance;            /* 1e-6 (:758) */
+  double initial_trust_region_radius;    /* 1e4  */
+  double max_trust_region_radius;        /* 1e16 */
+  double min_trust_region_radius;        /* 1e-32 */
+  double min_relative_decrease;          /* 1e-3 */
+  double min_lm_diagonal;                /* 1e-6 */
+  double max_lm_diagonal;                /* 1e32 */
+  int32_t jacobi_scaling;                /* 1 */
+  int32_t verbose;                       /* minimizer_progress_to_stdout (photobundle.cc:750) */
+} pba_solver_options;
+
+/* ceres::IterationSummary: the 18 fields the reference serialises (ceres_cereal.h:13-30), same names. */
+typedef struct pba_iteration_summary {
+  int32_t iteration;
+  int32_t step_is_valid;
+  int32_t step_is_nonmonotonic;
+  int32_t step_is_successful;
+  double cost;
+  double cost_change;
+  double gradient_max_norm;
+  double gradient_norm;
+  double step_norm;
+  double relative_decrease;
+  double trust_region_radius;
+  double eta;
+  double step_size;
+  int32_t line_search_function_evaluations;
+  int32_t line_search_gradient_evaluations;
+  int32_t line_search_iterations;
+  int32_t linear_solver_iterations;
+  double iteration_time_in_seconds;
+  double step_solver_time_in_seconds;
+  double cumulative_time_in_seconds;
+  double model_cost_change;   /* extra (parity debugging) */
+  double candidate_cost;      /* extra */
+} pba_iteration_summary;
+
+/* ceres::Solver::Summary subset consumed at photobundle.cc:867-874. */
+typedef struct pba_solver_summary {
+  double initial_cost, final_cost, fixed_cost;
+  int32_t num_successful_steps, num_unsuccessful_steps;
+  int32_t num_iterations;            /* entries written to the iterations array */
+  int32_t num_residuals;             /* global (all ranks) */
+  int32_t num_residual_blocks;       /* global (all ranks) */
+  int32_t termination_type;          /* 0 CONVERGENCE, 1 NO_CONVERGENCE, 2 FAILURE */
+  double total_time_in_seconds;
+  int64_t num_jacobian_passes;       /* linearisations (residual + Jacobian) */
+  int64_t num_cost_passes;           /* candidate (residual-only) evaluations */
+  int64_t num_resolve_passes;        /* extra damped Schur solves after rejected / invalid steps */
+  char message[256];
+} pba_solver_summary;
+
+/* Output of one trust-region step attempt (pba_step). */
+typedef struct pba_step_info {
+  double cost;               /* cost at the current linearisation point */
+  double gradient_max_norm;  /* |J^T r|_inf at the current point (unscaled) */
+  double gradient_norm;
+  double model_cost_change;
+  double step_norm;          /* |delta| unscaled */
+  double x_norm;             /* |x| over free parameters at the current point */
+  double candidate_cost;
+  int32_t linear_solver_ok;  /* 0: LINEAR_SOLVER_FAILURE (non-PD block / non-finite step) */
+  int32_t eval_ok;           /* 0: candidate evaluation non-finite */
+} pba_step_info;
+
+/* Device-side accounting for bench.py / rocprof cross-checks. */
+typedef struct pba_counters {
+  double linearize_ms;       /* sum of HIP-event durations of the Jacobian-pass kernel on the engine stream */
+  double cost_ms;            /* ... of the cost-pass kernel */
+  double schur_ms;           /* ... of the Schur elimination kernel */
+  int64_t linearize_launches, cost_launches, schur_launches;
+  int64_t n_obs, n_points;   /* local shard */
+} pba_counters;
+
+const char* pba_status_string(int status);
+const char* pba_last_error(const pba_engine* e);
+void pba_default_solver_options(pba_solver_options* o);
+
+/* ---- lifetime ------------------------------------------------------------------------------------------ */
+int pba_create(const pba_config* cfg, pba_engine** out);
+void pba_destroy(pba_engine* e);
+
+/* ---- frames: replaces DescriptorFrame::Create + ImageGradient::compute (photobundle.cc:225-248, :126-135) --
+ * `image` is the dense row-major rows x cols u8 frame addFrame() receives (photobundle.h:160).  The engine
+ * builds its device plane (I, Gx, Gy bit-exactly as imgproc.cc:27-95) and keeps it in window slot `slot`. */
+int pba_set_frame_u8(pba_engine* e, int slot, const uint8_t* image);
+/* Debug/test readback of the device planes as float I, Gx, Gy (each rows*cols). */
+int pba_get_frame_planes(pba_engine* e, int slot, float* I, float* Gx, float* Gy);
+
+/* ---- problem: replaces the AddResidualBlock loop (photobundle.cc:786-806) ------------------------------- */
+int pba_set_problem(pba_engine* e, int32_t n_points, const double* xyz, const double* desc,
+                    int32_t n_obs, const int32_t* obs_point, const int32_t* obs_slot, const double* weights);
+/* cams6: [n_frames][6]; fixed_slot: SetParameterBlockConstant (photobundle.cc:809-813), -1 for none. */
+int pba_set_cameras(pba_engine* e, const double* cams6, int32_t n_frames, int32_t fixed_slot);
+/* Current (best) state; either pointer may be NULL. */
+int pba_get_state(pba_engine* e, double* cams6, double* xyz);
+
+/* ---- primitive passes used by the host LM driver (exposed for tests and alternative drivers) ------------- */
+/* Jacobian pass at the current point: residuals, analytic per-patch structure tensors, loss correction. */
+int pba_linearize(pba_engine* e, double* cost);
+/* Damped Schur solve with trust-region `radius` from the stored linearisation, back-substitution, candidate
+ * point and its cost (cost pass).  init_scale != 0 (iteration 0) also fixes the Jacobi scaling vector. */
+int pba_step(pba_engine* e, double radius, int32_t init_scale, const pba_solver_options* o, pba_step_info* out);
+/* Make the candidate the current point (the caller then calls pba_linearize). */
+int pba_accept(pba_engine* e);
+/* Test hooks: copies of the reduced (global) system of the LAST pba_step: n = 6 * free cameras.
+ * S[n*n] row-major = s_c (U - sum W P W^T) s_c + D_c^2, rhs[n], both in Jacobi-scaled space. */
+int pba_get_reduced_system(pba_engine* e, double* S, double* rhs, int32_t* n);
+/* Test hook: per-observation record of the last linearisation: [n_obs][6] = rho'*M11, M12, M22, rho'*b1, b2, rho/2. */
+int pba_get_obs_records(pba_engine* e, double* rec6);
+
+/* ---- the LM loop: replaces ceres::Solve (photobundle.cc:829) --------------------------------------------- */
+int pba_solve(pba_engine* e, const pba_solver_options* o, pba_solver_summary* summary,
+              pba_iteration_summary* iterations, int32_t max_iterations_out);
+
+/* ---- multi-GPU: points are sharded across ranks, one all-reduce of the reduced camera system per solve --- */
+/* RCCL transport (one process per GPU): rank 0 calls pba_comm_unique_id, broadcasts the 128 bytes out of band. */
+int pba_comm_unique_id(void* id128);
+int pba_comm_init_rccl(pba_engine* e, const void* id128, int32_t rank, int32_t world);
+/* Host-staged transport: fn must sum `n` doubles in place across all ranks (op 0) or take the max (op 1). */
+typedef int (*pba_allreduce_fn)(double* buf, int64_t n, int32_t op, void* ctx);
+int pba_comm_init_callback(pba_engine* e, pba_allreduce_fn fn, void* ctx, int32_t rank, int32_t world);
+
+int pba_get_counters(pba_engine* e, pba_counters* c);
+int pba_reset_counters(pba_engine* e);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PBA_H */

@@ -1,0 +1,115 @@
+// pba_comm.cpp -- see pba_comm.h
+#include "pba_comm.h"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <cstring>
+
+namespace pba {
+
+namespace {
+struct Rccl {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  std::string err;
+  bool load() {
+    if (lib) return true;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) { lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (lib) break; }
+    if (!lib) { err = std::string("dlopen(librccl) failed: ") + dlerror(); return false; }
+    GetUniqueId = reinterpret_cast<decltype(GetUniqueId)>(dlsym(lib, "ncclGetUniqueId"));
+    CommInitRank = reinterpret_cast<decltype(CommInitRank)>(dlsym(lib, "ncclCommInitRank"));
+    CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+    AllReduce = reinterpret_cast<decltype(AllReduce)>(dlsym(lib, "ncclAllReduce"));
+    GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+    if (!GetUniqueId || !CommInitRank || !CommDestroy || !AllReduce || !GetErrorString) { err = "librccl misses a required symbol"; return false; }
+    return true;
+  }
+};
+Rccl& rccl() { static Rccl r; return r; }
+}  // namespace
+
+int Comm::unique_id(void* id128) {
+  Rccl& r = rccl();
+  if (!r.load()) return 1;
+  ncclUniqueId id;
+  if (r.GetUniqueId(&id) != ncclSuccess) return 1;
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  std::memcpy(id128, &id, 128);
+  return 0;
+}
+
+int Comm::init_rccl(const void* id128, int rank_, int world_) {
+  shutdown();
+  Rccl& r = rccl();
+  if (!r.load()) { err = r.err; return 1; }
+  ncclUniqueId id;
+  std::memcpy(&id, id128, 128);
+  ncclComm_t c = nullptr;
+  const ncclResult_t rc = r.CommInitRank(&c, world_, id, rank_);
+  if (rc != ncclSuccess) { err = std::string("ncclCommInitRank: ") + r.GetErrorString(rc); return 1; }
+  if (hipMalloc(reinterpret_cast<void**>(&d_small), 64 * sizeof(double)) != hipSuccess) { err = "hipMalloc(d_small)"; return 1; }
+  nccl_comm = c; world = world_; rank = rank_; kind = 1;
+  return 0;
+}
+
+int Comm::init_callback(pba_allreduce_fn f, void* c, int rank_, int world_) {
+  shutdown();
+  fn = f; ctx = c; world = world_; rank = rank_; kind = 2;
+  return 0;
+}
+
+int Comm::allreduce_device(double* d, size_t n, int op, hipStream_t s) {
+  if (world <= 1 || n == 0) return 0;
+  if (kind == 1) {
+    Rccl& r = rccl();
+    const ncclResult_t rc = r.AllReduce(d, d, n, ncclDouble, op == 0 ? ncclSum : ncclMax, static_cast<ncclComm_t>(nccl_comm), s);
+    if (rc != ncclSuccess) { err = std::string("ncclAllReduce: ") + r.GetErrorString(rc); return 1; }
+    return 0;
+  }
+  if (kind == 2) {
+    if (n > stage_cap) {
+      if (h_stage) (void)hipHostFree(h_stage);
+      h_stage = nullptr;
+      if (hipHostMalloc(reinterpret_cast<void**>(&h_stage), n * sizeof(double)) != hipSuccess) { err = "hipHostMalloc(stage)"; return 1; }
+      stage_cap = n;
+    }
+    if (hipMemcpyAsync(h_stage, d, n * sizeof(double), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { err = "stage D2H"; return 1; }
+    if (fn(h_stage, (int64_t)n, op, ctx) != 0) { err = "all-reduce callback failed"; return 1; }
+    if (hipMemcpyAsync(d, h_stage, n * sizeof(double), hipMemcpyHostToDevice, s) != hipSuccess) { err = "stage H2D"; return 1; }
+    return 0;
+  }
+  err = "no transport initialised";
+  return 1;
+}
+
+int Comm::allreduce_host(double* h, int n, int op) {
+  if (world <= 1 || n <= 0) return 0;
+  if (n > 64) { err = "allreduce_host: n > 64"; return 1; }
+  if (kind == 2) {
+    if (fn(h, n, op, ctx) != 0) { err = "all-reduce callback failed"; return 1; }
+    return 0;
+  }
+  if (kind == 1) {
+    if (hipMemcpyAsync(d_small, h, n * sizeof(double), hipMemcpyHostToDevice, stream) != hipSuccess) { err = "H2D"; return 1; }
+    if (allreduce_device(d_small, (size_t)n, op, stream)) return 1;
+    if (hipMemcpyAsync(h, d_small, n * sizeof(double), hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) { err = "D2H"; return 1; }
+    return 0;
+  }
+  err = "no transport initialised";
+  return 1;
+}
+
+void Comm::shutdown() {
+  if (kind == 1 && nccl_comm) { rccl().CommDestroy(static_cast<ncclComm_t>(nccl_comm)); nccl_comm = nullptr; }
+  if (h_stage) { (void)hipHostFree(h_stage); h_stage = nullptr; stage_cap = 0; }
+  if (d_small) { (void)hipFree(d_small); d_small = nullptr; }
+  kind = 0; world = 1; rank = 0; fn = nullptr; ctx = nullptr;
+}
+
+}  // namespace pba

@@ -1,0 +1,585 @@
+// pba_engine.hip -- C-ABI (include/pba.h) of the MI355X photometric bundle-adjustment engine.
+//
+// Owns all device memory, one HIP stream per engine; every pass is stream-ordered and the host synchronises
+// once per step attempt (pba_step) to read a 32-double scalar block.  There is no CPU fallback: pba_create
+// fails with PBA_ERR_NO_DEVICE when no GPU is visible.
+#include "../../include/pba.h"
+#include "pba_comm.h"
+#include "pba_internal.h"
+#include "pba_kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace pba;
+
+struct pba_engine {
+  pba_config cfg{};
+  hipStream_t stream = nullptr;
+  std::string err;
+
+  // frames
+  uint32_t* d_frames = nullptr;     // [max_frames][rows*cols] packed texels
+  uint8_t* d_img_stage = nullptr;   // [rows*cols]
+  std::vector<uint8_t> frame_set;
+
+  // problem
+  int n_points = 0, n_obs = 0, n_frames = 0, fixed_slot = -1, n_free = 0;
+  bool have_problem = false, have_cams = false, have_lin = false;
+  int cur = 0;                      // ping-pong index of the current point
+  double* d_xyz[2] = {nullptr, nullptr};
+  double* d_cams[2] = {nullptr, nullptr};
+  CamGeom* d_geom[2] = {nullptr, nullptr};
+  float* d_desc = nullptr;
+  double* d_w2 = nullptr;
+  int32_t* d_obs_point = nullptr;
+  uint8_t* d_obs_slot = nullptr;
+  int32_t* d_pt_begin = nullptr;
+  int32_t* d_tile_obs = nullptr;
+  int n_tiles = 0;
+  // linearisation + solve scratch
+  int64_t rec_stride = 0;
+  double* d_rec = nullptr;          // [6][rec_stride]
+  double* d_sp = nullptr;           // [n_points][3]
+  double* d_ptrec = nullptr;        // [n_points][12]
+  double* d_sc = nullptr;           // [6 * kMaxFrames]
+  double* d_delta_c = nullptr;      // [kMaxFrames][6]
+  double* d_partial = nullptr;      // [schur_grid][part_stride]
+  double* d_red = nullptr;          // [kChunks][part_stride]
+  double* d_packed = nullptr;       // [part_stride]
+  double* d_S = nullptr;            // [n*n] debug copy
+  double* d_rhs = nullptr;          // [n]
+  double* d_block_cost[2] = {nullptr, nullptr};   // [sample_grid] (0: Jacobian pass, 1: cost pass)
+  int32_t* d_block_fail[2] = {nullptr, nullptr};
+  double* d_bs_out = nullptr;       // [backsub_grid][3]
+  double* d_scal = nullptr;         // [kNumScal]
+  double* h_scal = nullptr;         // pinned
+  int schur_grid = 0, sample_grid = 0, backsub_grid = 0, sample_waves = 4;
+  int n_tasks = 0, part_stride = 0;
+  static constexpr int kChunks = 8;
+
+  Comm comm;
+
+  // counters
+  bool profile = false;
+  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  bool ev_used[3] = {false, false, false};
+  pba_counters ctr{};
+};
+
+namespace {
+
+int fail(pba_engine* e, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (e) e->err = buf;
+  return code;
+}
+
+#define HIP_TRY(e, call)                                                                         \
+  do {                                                                                           \
+    hipError_t _r = (call);                                                                      \
+    if (_r != hipSuccess) return fail((e), PBA_ERR_HIP, "%s: %s", #call, hipGetErrorString(_r)); \
+  } while (0)
+
+template <class T>
+int dev_alloc(pba_engine* e, T** p, size_t n) {
+  if (*p) { (void)hipFree(*p); *p = nullptr; }
+  if (n == 0) n = 1;
+  HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(p), n * sizeof(T)));
+  return PBA_OK;
+}
+template <class T>
+void dev_free(T** p) { if (*p) { (void)hipFree(*p); *p = nullptr; } }
+
+template <int R, bool JAC>
+void launch_sample_r(pba_engine* e, const SampleParams& sp) {
+  constexpr int WAVES = (R <= 2) ? 4 : (R == 3 ? 2 : 1);
+  hipLaunchKernelGGL((k_sample<R, JAC, WAVES>), dim3(e->sample_grid), dim3(WAVES * 64), 0, e->stream, sp);
+}
+template <bool JAC>
+void launch_sample(pba_engine* e, const SampleParams& sp) {
+  switch (e->cfg.radius) {
+    case 1: launch_sample_r<1, JAC>(e, sp); break;
+    case 2: launch_sample_r<2, JAC>(e, sp); break;
+    case 3: launch_sample_r<3, JAC>(e, sp); break;
+    case 4: launch_sample_r<4, JAC>(e, sp); break;
+    default: launch_sample_r<5, JAC>(e, sp); break;
+  }
+}
+int sample_waves_for_radius(int R) { return (R <= 2) ? 4 : (R == 3 ? 2 : 1); }
+
+size_t schur_smem_bytes() {
+  return sizeof(double) * (kTile * kObsStride + kTile * 9 + kTile) + kTile * kMaxFrames;
+}
+
+template <int NT>
+void launch_schur_nt(pba_engine* e, const SchurParams& sp) {
+  hipLaunchKernelGGL((k_schur<NT>), dim3(e->schur_grid), dim3(kTile), schur_smem_bytes(), e->stream, sp);
+}
+void launch_schur(pba_engine* e, const SchurParams& sp) {
+  const int nt = (e->n_tasks + kTile - 1) / kTile;
+  switch (nt) {
+    case 1: launch_schur_nt<1>(e, sp); break;
+    case 2: launch_schur_nt<2>(e, sp); break;
+    case 3: launch_schur_nt<3>(e, sp); break;
+    case 4: launch_schur_nt<4>(e, sp); break;
+    case 5: launch_schur_nt<5>(e, sp); break;
+    case 6: launch_schur_nt<6>(e, sp); break;
+    default: launch_schur_nt<7>(e, sp); break;
+  }
+}
+
+SampleParams make_sample_params(pba_engine* e, int which_point, int which_out) {
+  SampleParams sp{};
+  sp.frames = e->d_frames;
+  sp.geom = e->d_geom[which_point];
+  sp.xyz = e->d_xyz[which_point];
+  sp.desc = e->d_desc;
+  sp.w2 = e->d_w2;
+  sp.obs_point = e->d_obs_point;
+  sp.obs_slot = e->d_obs_slot;
+  sp.rec = e->d_rec;
+  sp.block_cost = e->d_block_cost[which_out];
+  sp.block_fail = e->d_block_fail[which_out];
+  sp.rec_stride = e->rec_stride;
+  sp.n_obs = e->n_obs;
+  sp.rows = e->cfg.rows;
+  sp.cols = e->cfg.cols;
+  sp.fx = e->cfg.fx; sp.fy = e->cfg.fy; sp.cx = e->cfg.cx; sp.cy = e->cfg.cy;
+  sp.huber = e->cfg.huber;
+  return sp;
+}
+
+void ev_begin(pba_engine* e, int k) { if (e->profile) { (void)hipEventRecord(e->ev[2 * k], e->stream); } }
+void ev_end(pba_engine* e, int k) { if (e->profile) { (void)hipEventRecord(e->ev[2 * k + 1], e->stream); e->ev_used[k] = true; } }
+void ev_collect(pba_engine* e) {
+  if (!e->profile) return;
+  double* acc[3] = {&e->ctr.linearize_ms, &e->ctr.cost_ms, &e->ctr.schur_ms};
+  int64_t* cnt[3] = {&e->ctr.linearize_launches, &e->ctr.cost_launches, &e->ctr.schur_launches};
+  for (int k = 0; k < 3; ++k) {
+    if (!e->ev_used[k]) continue;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, e->ev[2 * k], e->ev[2 * k + 1]) == hipSuccess) { *acc[k] += ms; *cnt[k] += 1; }
+    e->ev_used[k] = false;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* pba_status_string(int s) {
+  switch (s) {
+    case PBA_OK: return "ok";
+    case PBA_ERR_INVALID: return "invalid argument";
+    case PBA_ERR_HIP: return "HIP runtime error";
+    case PBA_ERR_NO_DEVICE: return "no HIP device (the engine has no CPU fallback)";
+    case PBA_ERR_STATE: return "call order violated";
+    case PBA_ERR_COMM: return "collective transport error";
+    case PBA_ERR_NUMERIC: return "non-finite evaluation";
+    default: return "unknown";
+  }
+}
+
+const char* pba_last_error(const pba_engine* e) { return e ? e->err.c_str() : ""; }
+
+void pba_default_solver_options(pba_solver_options* o) {
+  o->max_num_iterations = 500;              // reference photobundle.cc:751
+  o->max_num_consecutive_invalid_steps = 5;
+  o->function_tolerance = 1e-6;             // :756
+  o->gradient_tolerance = 1e-6;             // :757
+  o->parameter_tolerance = 1e-6;            // :758
+  o->initial_trust_region_radius = 1e4;     // Ceres defaults
+  o->max_trust_region_radius = 1e16;
+  o->min_trust_region_radius = 1e-32;
+  o->min_relative_decrease = 1e-3;
+  o->min_lm_diagonal = 1e-6;
+  o->max_lm_diagonal = 1e32;
+  o->jacobi_scaling = 1;
+  o->verbose = 0;
+}
+
+int pba_create(const pba_config* cfg, pba_engine** out) {
+  if (!cfg || !out) return PBA_ERR_INVALID;
+  *out = nullptr;
+  if (cfg->rows < 8 || cfg->cols < 8 || cfg->max_frames < 2 || cfg->max_frames > kMaxFrames || cfg->radius < 1 ||
+      cfg->radius > kMaxRadius || (int64_t)cfg->rows * cfg->cols * cfg->max_frames >= (1ll << 31))
+    return PBA_ERR_INVALID;
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0 || cfg->device < 0 || cfg->device >= n_dev) {
+    (void)hipGetLastError();
+    return PBA_ERR_NO_DEVICE;
+  }
+  pba_engine* e = new pba_engine();
+  e->cfg = *cfg;
+  int rc = PBA_OK;
+  auto bail = [&](int code) { pba_destroy(e); return code; };
+  if (hipSetDevice(cfg->device) != hipSuccess) return bail(PBA_ERR_HIP);
+  if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) return bail(PBA_ERR_HIP);
+  e->comm.stream = e->stream;
+  const size_t npix = (size_t)cfg->rows * cfg->cols;
+  if ((rc = dev_alloc(e, &e->d_frames, npix * cfg->max_frames))) return bail(rc);
+  if ((rc = dev_alloc(e, &e->d_img_stage, npix))) return bail(rc);
+  if (hipMemsetAsync(e->d_frames, 0, npix * cfg->max_frames * sizeof(uint32_t), e->stream) != hipSuccess) return bail(PBA_ERR_HIP);
+  e->frame_set.assign(cfg->max_frames, 0);
+  for (int k = 0; k < 2; ++k) {
+    if ((rc = dev_alloc(e, &e->d_cams[k], 6 * kMaxFrames))) return bail(rc);
+    if ((rc = dev_alloc(e, &e->d_geom[k], kMaxFrames))) return bail(rc);
+  }
+  if ((rc = dev_alloc(e, &e->d_sc, 6 * kMaxFrames))) return bail(rc);
+  if ((rc = dev_alloc(e, &e->d_delta_c, 6 * kMaxFrames))) return bail(rc);
+  if ((rc = dev_alloc(e, &e->d_scal, (size_t)kNumScal))) return bail(rc);
+  if ((rc = dev_alloc(e, &e->d_S, (size_t)36 * kMaxFrames * kMaxFrames))) return bail(rc);
+  if ((rc = dev_alloc(e, &e->d_rhs, (size_t)6 * kMaxFrames))) return bail(rc);
+  if (hipMemsetAsync(e->d_scal, 0, kNumScal * sizeof(double), e->stream) != hipSuccess) return bail(PBA_ERR_HIP);
+  if (hipHostMalloc(reinterpret_cast<void**>(&e->h_scal), kNumScal * sizeof(double)) != hipSuccess) return bail(PBA_ERR_HIP);
+  for (int k = 0; k < 6; ++k)
+    if (hipEventCreate(&e->ev[k]) != hipSuccess) return bail(PBA_ERR_HIP);
+  e->sample_waves = sample_waves_for_radius(cfg->radius);
+  if (hipStreamSynchronize(e->stream) != hipSuccess) return bail(PBA_ERR_HIP);
+  *out = e;
+  return PBA_OK;
+}
+
+void pba_destroy(pba_engine* e) {
+  if (!e) return;
+  (void)hipSetDevice(e->cfg.device);
+  if (e->stream) (void)hipStreamSynchronize(e->stream);
+  e->comm.shutdown();
+  dev_free(&e->d_frames); dev_free(&e->d_img_stage);
+  for (int k = 0; k < 2; ++k) { dev_free(&e->d_xyz[k]); dev_free(&e->d_cams[k]); dev_free(&e->d_geom[k]); dev_free(&e->d_block_cost[k]); dev_free(&e->d_block_fail[k]); }
+  dev_free(&e->d_desc); dev_free(&e->d_w2); dev_free(&e->d_obs_point); dev_free(&e->d_obs_slot); dev_free(&e->d_pt_begin);
+  dev_free(&e->d_tile_obs); dev_free(&e->d_rec); dev_free(&e->d_sp); dev_free(&e->d_ptrec); dev_free(&e->d_sc);
+  dev_free(&e->d_delta_c); dev_free(&e->d_partial); dev_free(&e->d_red); dev_free(&e->d_packed); dev_free(&e->d_S);
+  dev_free(&e->d_rhs); dev_free(&e->d_bs_out); dev_free(&e->d_scal);
+  if (e->h_scal) (void)hipHostFree(e->h_scal);
+  for (int k = 0; k < 6; ++k) if (e->ev[k]) (void)hipEventDestroy(e->ev[k]);
+  if (e->stream) (void)hipStreamDestroy(e->stream);
+  delete e;
+}
+
+int pba_set_frame_u8(pba_engine* e, int slot, const uint8_t* image) {
+  if (!e || !image || slot < 0 || slot >= e->cfg.max_frames) return PBA_ERR_INVALID;
+  HIP_TRY(e, hipSetDevice(e->cfg.device));
+  const size_t npix = (size_t)e->cfg.rows * e->cfg.cols;
+  HIP_TRY(e, hipMemcpyAsync(e->d_img_stage, image, npix, hipMemcpyHostToDevice, e->stream));
+  dim3 grid((e->cfg.cols + 255) / 256, e->cfg.rows);
+  hipLaunchKernelGGL(k_pack_frame, grid, dim3(256), 0, e->stream, e->d_img_stage, e->d_frames + npix * slot,
+                     e->cfg.rows, e->cfg.cols);
+  HIP_TRY(e, hipGetLastError());
+  HIP_TRY(e, hipStreamSynchronize(e->stream));   // the caller's buffer is only borrowed for the call
+  e->frame_set[slot] = 1;
+  return PBA_OK;
+}
+
+int pba_get_frame_planes(pba_engine* e, int slot, float* I, float* Gx, float* Gy) {
+  if (!e || slot < 0 || slot >= e->cfg.max_frames || !I || !Gx || !Gy) return PBA_ERR_INVALID;
+  HIP_TRY(e, hipSetDevice(e->cfg.device));
+  const size_t npix = (size_t)e->cfg.rows * e->cfg.cols;
+  float* d = nullptr;
+  HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(&d), 3 * npix * sizeof(float)));
+  hipLaunchKernelGGL(k_unpack_frame, dim3((npix + 255) / 256), dim3(256), 0, e->stream, e->d_frames + npix * slot, d,
+                     d + npix, d + 2 * npix, (int)npix);
+  hipError_t r = hipMemcpyAsync(I, d, npix * sizeof(float), hipMemcpyDeviceToHost, e->stream);
+  if (r == hipSuccess) r = hipMemcpyAsync(Gx, d + npix, npix * sizeof(float), hipMemcpyDeviceToHost, e->stream);
+  if (r == hipSuccess) r = hipMemcpyAsync(Gy, d + 2 * npix, npix * sizeof(float), hipMemcpyDeviceToHost, e->stream);
+  if (r == hipSuccess) r = hipStreamSynchronize(e->stream);
+  (void)hipFree(d);
+  if (r != hipSuccess) return fail(e, PBA_ERR_HIP, "pba_get_frame_planes: %s", hipGetErrorString(r));
+  return PBA_OK;
+}
+
+int pba_set_problem(pba_engine* e, int32_t n_points, const double* xyz, const double* desc, int32_t n_obs,
+                    const int32_t* obs_point, const int32_t* obs_slot, const double* weights) {
+  if (!e || n_points <= 0 || n_obs <= 0 || !xyz || !desc || !obs_point || !obs_slot || !weights) return PBA_ERR_INVALID;
+  HIP_TRY(e, hipSetDevice(e->cfg.device));
+  const int P = (2 * e->cfg.radius + 1) * (2 * e->cfg.radius + 1);
+  // validate + CSR + tiles (whole points per tile of <= kTile observations)
+  std::vector<int32_t> pt_begin(n_points + 1, 0);
+  std::vector<uint8_t> slot8(n_obs);
+  for (int o = 0; o < n_obs; ++o) {
+    const int p = obs_point[o], s = obs_slot[o];
+    if (p < 0 || p >= n_points || s < 0 || s >= e->cfg.max_frames) return fail(e, PBA_ERR_INVALID, "observation %d out of range", o);
+    if (o > 0 && p < obs_point[o - 1]) return fail(e, PBA_ERR_INVALID, "observations must be grouped by point");
+    if (o > 0 && p == obs_point[o - 1] && s <= obs_slot[o - 1]) return fail(e, PBA_ERR_INVALID, "duplicate / unsorted slot for point %d", p);
+    pt_begin[p + 1]++;
+    slot8[o] = (uint8_t)s;
+  }
+  for (int p = 0; p < n_points; ++p) {
+    if (pt_begin[p + 1] == 0) return fail(e, PBA_ERR_INVALID, "point %d has no observation", p);
+    pt_begin[p + 1] += pt_begin[p];
+  }
+  std::vector<int32_t> tiles(1, 0);
+  {
+    int begin = 0;
+    for (int p = 0; p < n_points; ++p) {
+      if (pt_begin[p + 1] - begin > kTile) { tiles.push_back(pt_begin[p]); begin = pt_begin[p]; }
+    }
+    tiles.push_back(n_obs);
+  }
+  e->n_tiles = (int)tiles.size() - 1;
+  e->n_points = n_points;
+  e->n_obs = n_obs;
+  e->ctr.n_obs = n_obs; e->ctr.n_points = n_points;
+
+  std::vector<float> descf((size_t)n_points * P);
+  for (size_t i = 0; i < descf.size(); ++i) descf[i] = (float)desc[i];
+  std::vector<double> w2(P);
+  for (int i = 0; i < P; ++i) w2[i] = weights[i] * weights[i];
+
+  int rc;
+  for (int k = 0; k < 2; ++k) if ((rc = dev_alloc(e, &e->d_xyz[k], (size_t)3 * n_points))) return rc;
+  if ((rc = dev_alloc(e, &e->d_desc, descf.size()))) return rc;
+  if ((rc = dev_alloc(e, &e->d_w2, (size_t)P))) return rc;
+  if ((rc = dev_alloc(e, &e->d_obs_point, (size_t)n_obs))) return rc;
+  if ((rc = dev_alloc(e, &e->d_obs_slot, (size_t)n_obs))) return rc;
+  if ((rc = dev_alloc(e, &e->d_pt_begin, (size_t)n_points + 1))) return rc;
+  if ((rc = dev_alloc(e, &e->d_tile_obs, tiles.size()))) return rc;
+  e->rec_stride = ((int64_t)n_obs + 255) / 256 * 256;
+  if ((rc = dev_alloc(e, &e->d_rec, (size_t)6 * e->rec_stride))) return rc;
+  if ((rc = dev_alloc(e, &e->d_sp, (size_t)3 * n_points))) return rc;
+  if ((rc = dev_alloc(e, &e->d_ptrec, (size_t)12 * n_points))) return rc;
+  e->sample_grid = (n_obs + e->sample_waves * 64 - 1) / (e->sample_waves * 64);
+  for (int k = 0; k < 2; ++k) {
+    if ((rc = dev_alloc(e, &e->d_block_cost[k], (size_t)e->sample_grid))) return rc;
+    if ((rc = dev_alloc(e, &e->d_block_fail[k], (size_t)e->sample_grid))) return rc;
+  }
+  e->backsub_grid = (n_points + 255) / 256;
+  if ((rc = dev_alloc(e, &e->d_bs_out, (size_t)3 * e->backsub_grid))) return rc;
+  e->schur_grid = std::min(e->n_tiles, 256 * 3);
+
+  HIP_TRY(e, hipMemcpyAsync(e->d_xyz[0], xyz, sizeof(double) * 3 * n_points, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(e, hipMemcpyAsync(e->d_desc, descf.data(), sizeof(float) * descf.size(), hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(e, hipMemcpyAsync(e->d_w2, w2.data(), sizeof(double) * P, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(e, hipMemcpyAsync(e->d_obs_point, obs_point, sizeof(int32_t) * n_obs, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(e, hipMemcpyAsync(e->d_obs_slot, slot8.data(), n_obs, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(e, hipMemcpyAsync(e->d_pt_begin, pt_begin.data(), sizeof(int32_t) * (n_points + 1), hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(e, hipMemcpyAsync(e->d_tile_obs, tiles.data(), sizeof(int32_t) * tiles.size(), hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  e->cur = 0;
+  e->have_problem = true;
+  e->have_lin = false;
+  return PBA_OK;
+}
+
+int pba_set_cameras(pba_engine* e, const double* cams6, int32_t n_frames, int32_t fixed_slot) {
+  if (!e || !cams6 || n_frames < 2 || n_frames > e->cfg.max_frames || fixed_slot >= n_frames) return PBA_ERR_INVALID;
+  HIP_TRY(e, hipSetDevice(e->cfg.device));
+  e->n_frames = n_frames;
+  e->fixed_slot = fixed_slot < 0 ? -1 : fixed_slot;
+  e->n_free = n_frames - (e->fixed_slot >= 0 ? 1 : 0);
+  e->n_tasks = 6 * (e->n_free * (e->n_free + 1) / 2);
+  e->part_stride = 6 * e->n_tasks + 3 * 6 * e->n_free + 3;
+  int rc;
+  if ((rc = dev_alloc(e, &e->d_partial, (size_t)std::max(1, 256 * 3) * e->part_stride))) return rc;
+  if ((rc = dev_alloc(e, &e->d_red, (size_t)pba_engine::kChunks * e->part_stride))) return rc;
+  if ((rc = dev_alloc(e, &e->d_packed, (size_t)e->part_stride))) return rc;
+  HIP_TRY(e, hipMemcpyAsync(e->d_cams[e->cur], cams6, sizeof(double) * 6 * n_frames, hipMemcpyHostToDevice, e->stream));
+  hipLaunchKernelGGL(k_cam_geom, dim3(1), dim3(64), 0, e->stream, e->d_cams[e->cur], e->d_geom[e->cur], n_frames, e->fixed_slot);
+  HIP_TRY(e, hipGetLastError());
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  e->have_cams = true;
+  e->have_lin = false;
+  return PBA_OK;
+}
+
+int pba_get_state(pba_engine* e, double* cams6, double* xyz) {
+  if (!e) return PBA_ERR_INVALID;
+  if (!e->have_problem || !e->have_cams) return fail(e, PBA_ERR_STATE, "pba_get_state before set_problem/set_cameras");
+  HIP_TRY(e, hipSetDevice(e->cfg.device));
+  if (cams6) HIP_TRY(e, hipMemcpyAsync(cams6, e->d_cams[e->cur], sizeof(double) * 6 * e->n_frames, hipMemcpyDeviceToHost, e->stream));
+  if (xyz) HIP_TRY(e, hipMemcpyAsync(xyz, e->d_xyz[e->cur], sizeof(double) * 3 * e->n_points, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  return PBA_OK;
+}
+
+int pba_linearize(pba_engine* e, double* cost) {
+  if (!e) return PBA_ERR_INVALID;
+  if (!e->have_problem || !e->have_cams) return fail(e, PBA_ERR_STATE, "pba_linearize before set_problem/set_cameras");
+  HIP_TRY(e, hipSetDevice(e->cfg.device));
+  SampleParams sp = make_sample_params(e, e->cur, 0);
+  ev_begin(e, 0);
+  launch_sample<true>(e, sp);
+  ev_end(e, 0);
+  HIP_TRY(e, hipGetLastError());
+  e->have_lin = true;
+  if (cost) {
+    std::vector<double> bc(e->sample_grid);
+    HIP_TRY(e, hipMemcpyAsync(bc.data(), e->d_block_cost[0], sizeof(double) * e->sample_grid, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    ev_collect(e);
+    double c = 0.0;
+    for (double v : bc) c += v;
+    if (e->comm.world > 1) {
+      if (e->comm.allreduce_host(&c, 1, 0)) return fail(e, PBA_ERR_COMM, "allreduce(cost) failed: %s", e->comm.err.c_str());
+    }
+    *cost = c;
+  }
+  return PBA_OK;
+}
+
+int pba_step(pba_engine* e, double radius, int32_t init_scale, const pba_solver_options* o, pba_step_info* out) {
+  return pba_internal_step(e, radius, init_scale, o, out, 0);
+}
+
+// grad_only != 0: stop after the reduced solve (cost / gradient norms of the linearisation point only).
+int pba_internal_step(pba_engine* e, double radius, int32_t init_scale, const pba_solver_options* o, pba_step_info* out,
+                      int grad_only) {
+  if (!e || !o || !out || !(radius > 0.0)) return PBA_ERR_INVALID;
+  if (!e->have_lin) return fail(e, PBA_ERR_STATE, "pba_step before pba_linearize");
+  HIP_TRY(e, hipSetDevice(e->cfg.device));
+  const int cur = e->cur, cand = 1 - e->cur;
+  const int n = 6 * e->n_free;
+
+  SchurParams sc{};
+  sc.xyz = e->d_xyz[cur]; sc.geom = e->d_geom[cur]; sc.rec = e->d_rec; sc.obs_point = e->d_obs_point;
+  sc.obs_slot = e->d_obs_slot; sc.tile_obs = e->d_tile_obs; sc.pt_begin = e->d_pt_begin; sc.sp = e->d_sp;
+  sc.ptrec = e->d_ptrec; sc.partial = e->d_partial; sc.rec_stride = e->rec_stride; sc.n_tiles = e->n_tiles;
+  sc.n_free = e->n_free; sc.n_tasks = e->n_tasks; sc.part_stride = e->part_stride; sc.init_scale = init_scale;
+  sc.jacobi = o->jacobi_scaling; sc.fx = e->cfg.fx; sc.fy = e->cfg.fy; sc.radius = radius;
+  sc.min_diag = o->min_lm_diagonal; sc.max_diag = o->max_lm_diagonal;
+  ev_begin(e, 2);
+  launch_schur(e, sc);
+  ev_end(e, 2);
+  const int chunks = pba_engine::kChunks;
+  hipLaunchKernelGGL(k_reduce_partials, dim3((e->part_stride + 63) / 64, chunks), dim3(64), 0, e->stream, e->d_partial,
+                     e->schur_grid, e->part_stride, chunks, e->d_red);
+  hipLaunchKernelGGL(k_pack_reduced, dim3(std::min(64, (e->part_stride + 255) / 256)), dim3(256), 0, e->stream, e->d_red,
+                     e->part_stride, chunks, e->d_block_cost[0], e->d_block_fail[0], e->sample_grid, e->d_packed, e->d_scal);
+  HIP_TRY(e, hipGetLastError());
+  if (e->comm.world > 1) {
+    if (e->comm.allreduce_device(e->d_packed, (size_t)e->part_stride - 1, 0, e->stream))
+      return fail(e, PBA_ERR_COMM, "allreduce(reduced system) failed: %s", e->comm.err.c_str());
+  }
+  SolveParams so{};
+  so.packed = e->d_packed; so.cams = e->d_cams[cur]; so.cams_cand = e->d_cams[cand]; so.delta_c = e->d_delta_c;
+  so.sc = e->d_sc; so.S_dbg = e->d_S; so.rhs_dbg = e->d_rhs; so.scal = e->d_scal; so.geom = e->d_geom[cur];
+  so.n_frames = e->n_frames; so.n_free = e->n_free; so.n_tasks = e->n_tasks; so.stride = e->part_stride;
+  so.init_scale = init_scale; so.jacobi = o->jacobi_scaling; so.radius = radius; so.min_diag = o->min_lm_diagonal;
+  so.max_diag = o->max_lm_diagonal;
+  const size_t solve_smem = sizeof(double) * ((size_t)n * n + 4 * n);
+  hipLaunchKernelGGL(k_solve, dim3(1), dim3(256), solve_smem, e->stream, so);
+  if (!grad_only) {
+  BacksubParams bs{};
+  bs.xyz = e->d_xyz[cur]; bs.xyz_cand = e->d_xyz[cand]; bs.geom = e->d_geom[cur]; bs.rec = e->d_rec;
+  bs.pt_begin = e->d_pt_begin; bs.obs_slot = e->d_obs_slot; bs.sp = e->d_sp; bs.ptrec = e->d_ptrec;
+  bs.delta_c = e->d_delta_c; bs.block_out = e->d_bs_out; bs.rec_stride = e->rec_stride; bs.n_points = e->n_points;
+  bs.fx = e->cfg.fx; bs.fy = e->cfg.fy;
+  hipLaunchKernelGGL(k_backsub, dim3(e->backsub_grid), dim3(256), 0, e->stream, bs);
+
+  // candidate point: geometry + cost pass
+  hipLaunchKernelGGL(k_cam_geom, dim3(1), dim3(64), 0, e->stream, e->d_cams[cand], e->d_geom[cand], e->n_frames, e->fixed_slot);
+  SampleParams sp = make_sample_params(e, cand, 1);
+  ev_begin(e, 1);
+  launch_sample<false>(e, sp);
+  ev_end(e, 1);
+  hipLaunchKernelGGL(k_finalize_step, dim3(1), dim3(256), 0, e->stream, e->d_bs_out, e->backsub_grid, e->d_block_cost[1],
+                     e->d_block_fail[1], e->sample_grid, e->d_scal);
+  }
+  HIP_TRY(e, hipGetLastError());
+  if (e->comm.world > 1) {
+    if ((!grad_only && e->comm.allreduce_device(e->d_scal + kCandCost, kSumBCount, 0, e->stream)) ||
+        e->comm.allreduce_device(e->d_scal + kGmaxPts, kMaxCount, 1, e->stream))
+      return fail(e, PBA_ERR_COMM, "allreduce(step scalars) failed: %s", e->comm.err.c_str());
+  }
+  HIP_TRY(e, hipMemcpyAsync(e->h_scal, e->d_scal, sizeof(double) * kNumScal, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  ev_collect(e);
+  const double* s = e->h_scal;
+  out->cost = s[kCostLin];
+  out->gradient_max_norm = std::max(s[kGmaxPts], s[kGmaxCams]);
+  out->gradient_norm = std::sqrt(s[kGnorm2Pts] + s[kGnorm2Cams]);
+  out->model_cost_change = s[kMccPts] + s[kMccCams];
+  out->step_norm = std::sqrt(s[kStep2Pts] + s[kStep2Cams]);
+  out->x_norm = std::sqrt(s[kX2Pts] + s[kX2Cams]);
+  out->candidate_cost = s[kCandCost];
+  out->linear_solver_ok = (s[kSolveOk] > 0.5 && s[kSchurFail] < 0.5) ? 1 : 0;
+  out->eval_ok = (s[kEvalFailCand] < 0.5 && std::isfinite(s[kCandCost])) ? 1 : 0;
+  if (s[kEvalFailLin] > 0.5) return fail(e, PBA_ERR_NUMERIC, "non-finite residual block at the linearisation point");
+  return PBA_OK;
+}
+
+int pba_accept(pba_engine* e) {
+  if (!e) return PBA_ERR_INVALID;
+  if (!e->have_lin) return fail(e, PBA_ERR_STATE, "pba_accept before pba_step");
+  e->cur = 1 - e->cur;
+  e->have_lin = false;
+  return PBA_OK;
+}
+
+int pba_get_reduced_system(pba_engine* e, double* S, double* rhs, int32_t* n_out) {
+  if (!e || !n_out) return PBA_ERR_INVALID;
+  HIP_TRY(e, hipSetDevice(e->cfg.device));
+  const int n = 6 * e->n_free;
+  *n_out = n;
+  if (S) HIP_TRY(e, hipMemcpyAsync(S, e->d_S, sizeof(double) * n * n, hipMemcpyDeviceToHost, e->stream));
+  if (rhs) HIP_TRY(e, hipMemcpyAsync(rhs, e->d_rhs, sizeof(double) * n, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  return PBA_OK;
+}
+
+int pba_get_obs_records(pba_engine* e, double* rec6) {
+  if (!e || !rec6) return PBA_ERR_INVALID;
+  if (!e->have_problem) return fail(e, PBA_ERR_STATE, "no problem");
+  HIP_TRY(e, hipSetDevice(e->cfg.device));
+  std::vector<double> tmp((size_t)6 * e->rec_stride);
+  HIP_TRY(e, hipMemcpyAsync(tmp.data(), e->d_rec, sizeof(double) * tmp.size(), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  for (int o = 0; o < e->n_obs; ++o)
+    for (int k = 0; k < 6; ++k) rec6[(size_t)o * 6 + k] = tmp[(size_t)k * e->rec_stride + o];
+  return PBA_OK;
+}
+
+int pba_comm_unique_id(void* id128) { return Comm::unique_id(id128) ? PBA_ERR_COMM : PBA_OK; }
+
+int pba_comm_init_rccl(pba_engine* e, const void* id128, int32_t rank, int32_t world) {
+  if (!e || !id128 || world < 1 || rank < 0 || rank >= world) return PBA_ERR_INVALID;
+  HIP_TRY(e, hipSetDevice(e->cfg.device));
+  if (e->comm.init_rccl(id128, rank, world)) return fail(e, PBA_ERR_COMM, "%s", e->comm.err.c_str());
+  return PBA_OK;
+}
+
+int pba_comm_init_callback(pba_engine* e, pba_allreduce_fn fn, void* ctx, int32_t rank, int32_t world) {
+  if (!e || !fn || world < 1 || rank < 0 || rank >= world) return PBA_ERR_INVALID;
+  HIP_TRY(e, hipSetDevice(e->cfg.device));
+  if (e->comm.init_callback(fn, ctx, rank, world)) return fail(e, PBA_ERR_COMM, "%s", e->comm.err.c_str());
+  return PBA_OK;
+}
+
+int pba_get_counters(pba_engine* e, pba_counters* c) {
+  if (!e || !c) return PBA_ERR_INVALID;
+  *c = e->ctr;
+  return PBA_OK;
+}
+
+int pba_reset_counters(pba_engine* e) {
+  if (!e) return PBA_ERR_INVALID;
+  const int64_t no = e->ctr.n_obs, np = e->ctr.n_points;
+  e->ctr = pba_counters{};
+  e->ctr.n_obs = no; e->ctr.n_points = np;
+  e->profile = true;   // counters are only collected once asked for
+  return PBA_OK;
+}
+
+}  // extern "C"
+
+// engine internals needed by the LM driver (pba_lm.cpp)
+extern "C" {
+int pba_internal_world(const pba_engine* e) { return e->comm.world; }
+int pba_internal_rank(const pba_engine* e) { return e->comm.rank; }
+int64_t pba_internal_local_blocks(const pba_engine* e) { return e->n_obs; }
+int pba_internal_patch_len(const pba_engine* e) { return (2 * e->cfg.radius + 1) * (2 * e->cfg.radius + 1); }
+int pba_internal_allreduce_host(pba_engine* e, double* v, int n, int op) {
+  if (e->comm.world <= 1) return 0;
+  return e->comm.allreduce_host(v, n, op);
+}
+}  // extern "C"

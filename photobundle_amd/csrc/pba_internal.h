@@ -1,0 +1,14 @@
+// pba_internal.h -- engine entry points shared by the engine and the host LM driver (not part of the public ABI).
+#pragma once
+#include "../../include/pba.h"
+
+extern "C" {
+// grad_only != 0: stop after the reduced solve (cost / gradient norms of the linearisation point only).
+int pba_internal_step(pba_engine* e, double radius, int32_t init_scale, const pba_solver_options* o, pba_step_info* out,
+                      int grad_only);
+int pba_internal_world(const pba_engine* e);
+int pba_internal_rank(const pba_engine* e);
+int64_t pba_internal_local_blocks(const pba_engine* e);
+int pba_internal_patch_len(const pba_engine* e);
+int pba_internal_allreduce_host(pba_engine* e, double* v, int n, int op);
+}

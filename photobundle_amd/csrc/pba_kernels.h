@@ -1,0 +1,956 @@
+// pba_kernels.h -- hand-written HIP kernels of the photometric BA hot path for gfx950 (CDNA4, wave64).
+//
+// Replaces, on the device, what the reference evaluates through Ceres autodiff:
+//   DescriptorError::operator()  reference src/photobundle.cc:696-727
+//   SampleWithDerivative / SampleLinear / LinearInitAxis  reference src/sample_eigen.h:33-126
+//   Chain::Rule (derivative injection)  reference src/jet_extras.h:87-111 -> analytic: J_i = -w [gx gy] A
+//   Calibration::project  reference src/calibration.h:34-38
+//   HuberLoss + Corrector, SchurEliminator, LevenbergMarquardtStrategy (Ceres, absent dependency)
+#pragma once
+#include "pba_device.h"
+
+#include <cfloat>
+#include <climits>
+
+namespace pba {
+
+// =====================================================================================================
+// frames
+// =====================================================================================================
+// One thread per pixel; 4 pixels per thread along the row would be the next step if this ever mattered
+// (once per frame, 466k pixels).  imgproc.cc:27-95 semantics, packed as described in pba_device.h.
+__global__ void k_pack_frame(const uint8_t* __restrict__ img, uint32_t* __restrict__ tex, int rows, int cols) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y;
+  if (x >= cols) return;
+  const size_t i = (size_t)y * cols + x;
+  const int I = img[i];
+  int gx2 = 0, gy2 = 0;
+  if (y >= 1 && y < rows - 1 && x >= 1 && x < cols - 1) {
+    gx2 = (int)img[i + 1] - (int)img[i - 1];
+    gy2 = (int)img[i + cols] - (int)img[i - cols];
+  }
+  tex[i] = pack_texel(I, gx2, gy2);
+}
+
+__device__ __forceinline__ float tex_I(uint32_t t) { return (float)(t & 0xffu); }
+__device__ __forceinline__ float tex_gx2(uint32_t t) { return (float)(((int32_t)(t << 14)) >> 22); }
+__device__ __forceinline__ float tex_gy2(uint32_t t) { return (float)(((int32_t)(t << 4)) >> 22); }
+
+__global__ void k_unpack_frame(const uint32_t* __restrict__ tex, float* I, float* Gx, float* Gy, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t t = tex[i];
+  I[i] = tex_I(t);
+  Gx[i] = 0.5f * tex_gx2(t);
+  Gy[i] = 0.5f * tex_gy2(t);
+}
+
+// =====================================================================================================
+// camera geometry
+// =====================================================================================================
+__global__ void k_cam_geom(const double* __restrict__ cams, CamGeom* __restrict__ geom, int n_frames, int fixed_slot) {
+  const int c = threadIdx.x;
+  if (c >= n_frames) return;
+  CamGeom g;
+  const double* p = cams + 6 * c;
+  for (int k = 0; k < 3; ++k) { g.aa[k] = p[k]; g.t[k] = p[3 + k]; }
+  const double wx = p[0], wy = p[1], wz = p[2];
+  const double theta2 = wx * wx + wy * wy + wz * wz;
+  g.rodrigues = theta2 > DBL_EPSILON;
+  g.is_free = (c != fixed_slot);
+  g.free_index = (c == fixed_slot) ? -1 : (fixed_slot >= 0 && c > fixed_slot ? c - 1 : c);
+  g.pad = 0;
+  if (g.rodrigues) {
+    const double theta = sqrt(theta2);
+    const double ct = cos(theta), st = sin(theta);
+    const double ti = 1.0 / theta;
+    const double ax = wx * ti, ay = wy * ti, az = wz * ti;
+    g.w[0] = ax; g.w[1] = ay; g.w[2] = az; g.ct = ct; g.st = st;
+    const double oc = 1.0 - ct;
+    double R[9] = {ct + ax * ax * oc,      ax * ay * oc - az * st, ay * st + ax * az * oc,
+                   az * st + ax * ay * oc, ct + ay * ay * oc,      -ax * st + ay * az * oc,
+                   -ay * st + ax * az * oc, ax * st + ay * az * oc, ct + az * az * oc};
+    for (int k = 0; k < 9; ++k) g.R[k] = R[k];
+    // B = (w w^T + (R^T - I) [w]x) / theta^2   (Gallego & Yezzi 2015);  dR_k = R [B_k]x
+    const double W[3] = {wx, wy, wz};
+    const double Wx[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
+    double B[9];
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) {
+        double acc = W[i] * W[j];
+        for (int k = 0; k < 3; ++k) acc += (R[3 * k + i] - (i == k ? 1.0 : 0.0)) * Wx[3 * k + j];
+        B[3 * i + j] = acc / theta2;
+      }
+    for (int k = 0; k < 3; ++k) {
+      const double b0 = B[k], b1 = B[3 + k], b2 = B[6 + k];   // column k of B
+      const double Bx[9] = {0, -b2, b1, b2, 0, -b0, -b1, b0, 0};
+      for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+          double acc = 0;
+          for (int m = 0; m < 3; ++m) acc += R[3 * i + m] * Bx[3 * m + j];
+          g.dR[9 * k + 3 * i + j] = acc;
+        }
+    }
+  } else {
+    g.w[0] = g.w[1] = g.w[2] = 0.0; g.ct = 1.0; g.st = 0.0;
+    const double R[9] = {1, -wz, wy, wz, 1, -wx, -wy, wx, 1};
+    for (int k = 0; k < 9; ++k) g.R[k] = R[k];
+    for (int k = 0; k < 3; ++k) {
+      const double e0 = (k == 0), e1 = (k == 1), e2 = (k == 2);
+      const double Ex[9] = {0, -e2, e1, e2, 0, -e0, -e1, e0, 0};
+      for (int m = 0; m < 9; ++m) g.dR[9 * k + m] = Ex[m];
+    }
+  }
+  geom[c] = g;
+}
+
+// xw = R(aa) X + t in the operation order of ceres::AngleAxisRotatePoint, then Calibration::project.
+// Contraction is off so that (u, v) round exactly like the (FMA-free) reference build.
+__device__ __forceinline__ void transform_point(const CamGeom& g, const double X[3], double xw[3]) {
+#pragma clang fp contract(off)
+  if (g.rodrigues) {
+    const double w0 = g.w[0], w1 = g.w[1], w2 = g.w[2];
+    const double c0 = w1 * X[2] - w2 * X[1];
+    const double c1 = w2 * X[0] - w0 * X[2];
+    const double c2 = w0 * X[1] - w1 * X[0];
+    const double tmp = (w0 * X[0] + w1 * X[1] + w2 * X[2]) * (1.0 - g.ct);
+    xw[0] = X[0] * g.ct + c0 * g.st + w0 * tmp;
+    xw[1] = X[1] * g.ct + c1 * g.st + w1 * tmp;
+    xw[2] = X[2] * g.ct + c2 * g.st + w2 * tmp;
+  } else {
+    xw[0] = X[0] + (g.aa[1] * X[2] - g.aa[2] * X[1]);
+    xw[1] = X[1] + (g.aa[2] * X[0] - g.aa[0] * X[2]);
+    xw[2] = X[2] + (g.aa[0] * X[1] - g.aa[1] * X[0]);
+  }
+  xw[0] += g.t[0];
+  xw[1] += g.t[1];
+  xw[2] += g.t[2];
+}
+
+__device__ __forceinline__ void project_point(const double xw[3], double fx, double fy, double cx, double cy,
+                                              double& u, double& v) {
+#pragma clang fp contract(off)
+  u = ((xw[0] * fx) / xw[2]) + cx;
+  v = ((xw[1] * fy) / xw[2]) + cy;
+}
+
+// Analytic 2x6 / 2x3 Jacobians of (u, v) w.r.t. camera [w, t] and point.
+__device__ __forceinline__ void projection_jacobians(const CamGeom& g, const double X[3], const double xw[3],
+                                                     double fx, double fy, double Ac[2][6], double Ap[2][3]) {
+  const double iz = 1.0 / xw[2];
+  const double ju0 = fx * iz, ju2 = -fx * xw[0] * iz * iz;
+  const double jv1 = fy * iz, jv2 = -fy * xw[1] * iz * iz;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double* D = g.dR + 9 * k;
+    const double d0 = D[0] * X[0] + D[1] * X[1] + D[2] * X[2];
+    const double d1 = D[3] * X[0] + D[4] * X[1] + D[5] * X[2];
+    const double d2 = D[6] * X[0] + D[7] * X[1] + D[8] * X[2];
+    Ac[0][k] = ju0 * d0 + ju2 * d2;
+    Ac[1][k] = jv1 * d1 + jv2 * d2;
+    Ap[0][k] = ju0 * g.R[k] + ju2 * g.R[6 + k];
+    Ap[1][k] = jv1 * g.R[3 + k] + jv2 * g.R[6 + k];
+  }
+  Ac[0][3] = ju0; Ac[0][4] = 0.0; Ac[0][5] = ju2;
+  Ac[1][3] = 0.0; Ac[1][4] = jv1; Ac[1][5] = jv2;
+}
+
+// =====================================================================================================
+// sampling (sample_eigen.h) -- exact mixed fp32/fp64 arithmetic of the reference
+// =====================================================================================================
+__device__ __forceinline__ int trunc_x86(float x) {
+  // static_cast<int>(float) with the x86 cvttss2si convention for NaN / out-of-range (INT_MIN)
+  return (x >= -2147483648.0f && x < 2147483648.0f) ? (int)x : INT_MIN;
+}
+
+// sample_eigen.h:34-52
+__device__ __forceinline__ void linear_init_axis(float x, int size, int& x1, int& x2, float& dx) {
+  const int ix = trunc_x86(x);
+  if (ix < 0) { x1 = 0; x2 = 0; dx = 1.0f; }
+  else if (ix > size - 2) { x1 = size - 1; x2 = size - 1; dx = 1.0f; }
+  else { x1 = ix; x2 = ix + 1; dx = __fsub_rn((float)x2, x); }
+}
+
+// sample_eigen.h:82-83: dx*a11 is a float product; (1.0 - dx) and everything downstream is double.
+__device__ __forceinline__ double hlerp_exact(float dx, double omdx, float a1, float a2) {
+  return __dadd_rn((double)__fmul_rn(dx, a1), __dmul_rn(omdx, (double)a2));
+}
+__device__ __forceinline__ float vlerp_exact(float dy, float omdy, double top, double bot) {
+  return __double2float_rn(__dadd_rn(__dmul_rn((double)dy, top), __dmul_rn((double)omdy, bot)));
+}
+
+// Generic (irregular) tap: any position, straight from the packed frame in global memory.
+template <bool JAC>
+__device__ __forceinline__ void sample_generic(const uint32_t* __restrict__ frame, int rows, int cols, float yf,
+                                               float xf, float& sI, float& sgx, float& sgy) {
+  int x1, x2, y1, y2; float dx, dy;
+  linear_init_axis(yf, rows, y1, y2, dy);
+  linear_init_axis(xf, cols, x1, x2, dx);
+  const uint32_t t11 = frame[(size_t)y1 * cols + x1], t12 = frame[(size_t)y1 * cols + x2];
+  const uint32_t t21 = frame[(size_t)y2 * cols + x1], t22 = frame[(size_t)y2 * cols + x2];
+  const double omdx = __dsub_rn(1.0, (double)dx);
+  const float omdy = __fsub_rn(1.0f, dy);
+  sI = vlerp_exact(dy, omdy, hlerp_exact(dx, omdx, tex_I(t11), tex_I(t12)), hlerp_exact(dx, omdx, tex_I(t21), tex_I(t22)));
+  if (JAC) {
+    // 2*G is blended and the exact power-of-two scale is applied at the end
+    sgx = 0.5f * vlerp_exact(dy, omdy, hlerp_exact(dx, omdx, tex_gx2(t11), tex_gx2(t12)), hlerp_exact(dx, omdx, tex_gx2(t21), tex_gx2(t22)));
+    sgy = 0.5f * vlerp_exact(dy, omdy, hlerp_exact(dx, omdx, tex_gy2(t11), tex_gy2(t12)), hlerp_exact(dx, omdx, tex_gy2(t21), tex_gy2(t22)));
+  }
+}
+
+struct SampleParams {
+  const uint32_t* frames;     // [n_frames][rows*cols] packed texels
+  const CamGeom* geom;        // [n_frames]
+  const double* xyz;          // [n_points][3]
+  const float* desc;          // [n_points][P]
+  const double* w2;           // [P] squared patch weights
+  const int32_t* obs_point;   // [n_obs]
+  const uint8_t* obs_slot;    // [n_obs]
+  double* rec;                // SoA [6][rec_stride]: rho'*M11, M12, M22, rho'*b1, b2, rho/2   (JAC only)
+  double* block_cost;         // [gridDim.x] per-block cost partial
+  int32_t* block_fail;        // [gridDim.x] non-finite flag
+  int64_t rec_stride;
+  int32_t n_obs;
+  int32_t rows, cols;
+  double fx, fy, cx, cy;
+  double huber;
+};
+
+// One LANE per observation (residual block); each wave stages the (2R+2)^2 texel footprints of its 64
+// observations through LDS with cooperative row-segment loads (consecutive lanes read consecutive texels of a
+// footprint row), then every lane walks its own patch with the separable form of the reference's bilinear rule:
+// horizontal lerps H[r][j] are shared by the two pixel rows that touch footprint row r, which is exact because
+// bot(i, j) and top(i+1, j) are the same expression (sample_eigen.h:82-83).
+//   JAC = true : Jacobian pass. Emits per observation M = sum w^2 g g^T, b = sum w^2 g e (rho'-scaled) and rho/2.
+//   JAC = false: cost pass (intensity only).
+template <int R, bool JAC, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void k_sample(SampleParams p) {
+  constexpr int W = 2 * R + 1;      // patch side
+  constexpr int F = 2 * R + 2;      // footprint side
+  constexpr int FF = F * F;
+  constexpr int LSTRIDE = 65;       // texel-major LDS layout [t][lane], odd stride: conflict-free both ways
+  __shared__ uint32_t s_tex[WAVES][FF * LSTRIDE];
+  __shared__ int32_t s_base[WAVES][64];
+  __shared__ double s_red[WAVES * 64];
+  __shared__ int32_t s_fail;
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int obs = blockIdx.x * (WAVES * 64) + threadIdx.x;
+  const bool active = obs < p.n_obs;
+  if (threadIdx.x == 0) s_fail = 0;
+
+  // ---- phase 1: geometry, one lane per observation (fp64) ------------------------------------------------
+  int pt = 0, slot = 0;
+  double u = 0.0, v = 0.0;
+  float xf[W], yf[W];
+  int bx = 0, by = 0;
+  bool regular = false;
+  if (active) {
+    pt = p.obs_point[obs];
+    slot = p.obs_slot[obs];
+    const double X[3] = {p.xyz[3 * (size_t)pt], p.xyz[3 * (size_t)pt + 1], p.xyz[3 * (size_t)pt + 2]};
+    double xw[3];
+    transform_point(p.geom[slot], X, xw);
+    project_point(xw, p.fx, p.fy, p.cx, p.cy, u, v);
+    // photobundle.cc:715-717: v + T(y), u + T(x) in double, rounded to float in SampleWithDerivative (:117-118)
+    bool reg = true;
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+      xf[j] = (float)(u + (double)(j - R));
+      yf[j] = (float)(v + (double)(j - R));
+    }
+    bx = trunc_x86(xf[0]);
+    by = trunc_x86(yf[0]);
+    reg = (bx >= 0) && (bx + W - 1 <= p.cols - 2) && (by >= 0) && (by + W - 1 <= p.rows - 2);
+#pragma unroll
+    for (int j = 1; j < W; ++j) reg = reg && (trunc_x86(xf[j]) == bx + j) && (trunc_x86(yf[j]) == by + j);
+    regular = reg;
+  }
+  s_base[wave][lane] = (active && regular) ? (int32_t)(slot * (p.rows * p.cols) + by * p.cols + bx) : -1;
+  __syncthreads();
+
+  // ---- phase 2: cooperative footprint staging global -> LDS ----------------------------------------------
+#pragma unroll 4
+  for (int n = 0; n < FF; ++n) {
+    const int g = n * 64 + lane;
+    const int o = g / FF;
+    const int t = g - o * FF;
+    const int base = s_base[wave][o];
+    uint32_t tx = 0;
+    if (base >= 0) tx = p.frames[(size_t)base + (t / F) * p.cols + (t % F)];
+    s_tex[wave][t * LSTRIDE + o] = tx;
+  }
+  __syncthreads();
+
+  // ---- phase 3: per-lane patch walk ------------------------------------------------------------------------
+  double m11 = 0, m12 = 0, m22 = 0, b1 = 0, b2 = 0, cc = 0;
+  if (active) {
+    const float* p0 = p.desc + (size_t)pt * (W * W);
+    if (regular) {
+      float dxs[W], dys[W];
+      double omdx[W];
+#pragma unroll
+      for (int j = 0; j < W; ++j) {
+        dxs[j] = __fsub_rn((float)(bx + j + 1), xf[j]);
+        dys[j] = __fsub_rn((float)(by + j + 1), yf[j]);
+        omdx[j] = __dsub_rn(1.0, (double)dxs[j]);
+      }
+      constexpr int NPL = JAC ? 3 : 1;
+      double Hp[NPL][W], Hc[NPL][W];
+#pragma unroll
+      for (int r = 0; r < F; ++r) {
+        uint32_t t[F];
+#pragma unroll
+        for (int c = 0; c < F; ++c) t[c] = s_tex[wave][(r * F + c) * LSTRIDE + lane];
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+          Hc[0][j] = hlerp_exact(dxs[j], omdx[j], tex_I(t[j]), tex_I(t[j + 1]));
+          if (JAC) {
+            Hc[1][j] = hlerp_exact(dxs[j], omdx[j], tex_gx2(t[j]), tex_gx2(t[j + 1]));
+            Hc[2][j] = hlerp_exact(dxs[j], omdx[j], tex_gy2(t[j]), tex_gy2(t[j + 1]));
+          }
+        }
+        if (r >= 1) {
+          const int i = r - 1;
+          const float dy = dys[i];
+          const float omdy = __fsub_rn(1.0f, dy);
+#pragma unroll
+          for (int j = 0; j < W; ++j) {
+            const float sI = vlerp_exact(dy, omdy, Hp[0][j], Hc[0][j]);
+            const double e = (double)p0[i * W + j] - (double)sI;   // photobundle.cc:720 (i0 - i1)
+            const double w2 = p.w2[i * W + j];
+            cc += w2 * e * e;
+            if (JAC) {
+              const double gx = (double)(0.5f * vlerp_exact(dy, omdy, Hp[1][j], Hc[1][j]));
+              const double gy = (double)(0.5f * vlerp_exact(dy, omdy, Hp[2][j], Hc[2][j]));
+              const double wgx = w2 * gx, wgy = w2 * gy;
+              m11 += wgx * gx; m12 += wgx * gy; m22 += wgy * gy;
+              b1 += wgx * e; b2 += wgy * e;
+            }
+          }
+        }
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+          for (int j = 0; j < W; ++j) Hp[pl][j] = Hc[pl][j];
+      }
+    } else {
+      // border / clamped / rounding-irregular observation: per-pixel generic rule from global memory
+      const uint32_t* frame = p.frames + (size_t)slot * p.rows * p.cols;
+      for (int i = 0; i < W; ++i) {
+        for (int j = 0; j < W; ++j) {
+          float sI, sgx = 0.f, sgy = 0.f;
+          sample_generic<JAC>(frame, p.rows, p.cols, yf[i], xf[j], sI, sgx, sgy);
+          const double e = (double)p0[i * W + j] - (double)sI;
+          const double w2 = p.w2[i * W + j];
+          cc += w2 * e * e;
+          if (JAC) {
+            const double gx = (double)sgx, gy = (double)sgy;
+            const double wgx = w2 * gx, wgy = w2 * gy;
+            m11 += wgx * gx; m12 += wgx * gy; m22 += wgy * gy;
+            b1 += wgx * e; b2 += wgy * e;
+          }
+        }
+      }
+    }
+  }
+
+  // ---- phase 4: loss (HuberLoss::Evaluate + Corrector with rho'' <= 0), record, block cost ---------------
+  double cost_obs = 0.0;
+  if (active) {
+    double rho0 = cc, rho1 = 1.0;
+    if (p.huber > 0.0 && cc > p.huber * p.huber) {
+      const double r = sqrt(cc);
+      rho0 = 2.0 * p.huber * r - p.huber * p.huber;
+      rho1 = fmax(DBL_MIN, p.huber / r);
+    }
+    cost_obs = 0.5 * rho0;
+    if (!isfinite(cc)) atomicOr(&s_fail, 1);
+    if (JAC) {
+      p.rec[0 * p.rec_stride + obs] = rho1 * m11;
+      p.rec[1 * p.rec_stride + obs] = rho1 * m12;
+      p.rec[2 * p.rec_stride + obs] = rho1 * m22;
+      p.rec[3 * p.rec_stride + obs] = rho1 * b1;
+      p.rec[4 * p.rec_stride + obs] = rho1 * b2;
+      p.rec[5 * p.rec_stride + obs] = cost_obs;
+    }
+  }
+  // deterministic block reduction (fixed tree)
+  s_red[threadIdx.x] = cost_obs;
+  __syncthreads();
+  for (int s = WAVES * 32; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) s_red[threadIdx.x] += s_red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    p.block_cost[blockIdx.x] = s_red[0];
+    p.block_fail[blockIdx.x] = s_fail;
+  }
+}
+
+
+// =====================================================================================================
+// Schur elimination of the points (SchurEliminator::Eliminate restated for the device)
+//   one lane per observation, whole points per tile, owner-computes accumulation (no atomics: the order of
+//   every floating-point sum is fixed by the tile/grid decomposition, so runs are reproducible)
+// =====================================================================================================
+constexpr int kTile = 128;              // observations (= threads) per tile
+constexpr int kObsStride = 37;          // doubles per observation in LDS (36 + 1 pad)
+
+struct SchurParams {
+  const double* xyz;
+  const CamGeom* geom;
+  const double* rec;            // SoA [6][rec_stride]
+  const int32_t* obs_point;
+  const uint8_t* obs_slot;
+  const int32_t* tile_obs;      // [n_tiles + 1] observation range of each tile (whole points)
+  const int32_t* pt_begin;      // [n_points + 1] CSR
+  double* sp;                   // [n_points][3] Jacobi scale of the point columns (written when init_scale)
+  double* ptrec;                // [n_points][12]: P (6, sym packed 00 01 02 11 12 22), g_p (3), D_p^2 (3)
+  double* partial;              // [gridDim.x][part_stride]
+  int64_t rec_stride;
+  int32_t n_tiles;
+  int32_t n_free;               // free cameras
+  int32_t n_tasks;              // 6 * n_free (n_free + 1) / 2
+  int32_t part_stride;          // n_tasks * 6 + 3 * 6 * n_free + 3
+  int32_t init_scale;
+  int32_t jacobi;
+  double fx, fy;
+  double radius, min_diag, max_diag;
+};
+
+__device__ __forceinline__ int sym6(int i, int j) {  // packed upper triangle of a symmetric 6x6 (21 entries)
+  const int a = i < j ? i : j, b = i < j ? j : i;
+  return a * 6 - (a * (a - 1)) / 2 + (b - a);
+}
+
+// Packed / partial layout (doubles), n = 6 * n_free:
+//   [0, 6 n_tasks)            T: task q = (pair(a<=b), row i) -> 6 entries of block (a, b), row i
+//   [.., +n) rhs   [.., +n) g_c   [.., +n) diag(U)
+//   partial only: +0 gmax_pts, +1 gnorm2_pts, +2 schur_fail
+// NT = owner tasks per thread.
+template <int NT>
+__global__ __launch_bounds__(kTile) void k_schur(SchurParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* s_obs = reinterpret_cast<double*>(smem);                       // [kTile][kObsStride]
+  double* s_vg = s_obs + kTile * kObsStride;                             // [kTile][9]  V_l (6) g_l (3)
+  double* s_red = s_vg + kTile * 9;                                      // [kTile]
+  int8_t* s_lane_of = reinterpret_cast<int8_t*>(s_red + kTile);          // [points in tile][kMaxFrames] by FREE index
+
+  const int tid = threadIdx.x;
+  const int nf = p.n_free;
+
+  int ta[NT], tb[NT], ti[NT];
+#pragma unroll
+  for (int k = 0; k < NT; ++k) {
+    const int q = tid + k * kTile;
+    ta[k] = -1; tb[k] = 0; ti[k] = 0;
+    if (q < p.n_tasks) {
+      const int pair = q / 6;
+      ti[k] = q - pair * 6;
+      int a = 0, rem = pair;
+      while (rem >= nf - a) { rem -= nf - a; ++a; }   // pairs enumerated row by row: (a, a..nf-1)
+      ta[k] = a; tb[k] = a + rem;
+    }
+  }
+  double acc[NT][6];
+#pragma unroll
+  for (int k = 0; k < NT; ++k)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) acc[k][j] = 0.0;
+  // vector owners: thread tid < 6 nf owns entry (camera tid / 6, row tid % 6) of rhs, g_c and diag(U)
+  const int va = (tid < 6 * nf) ? tid / 6 : -1;
+  const int vi = tid % 6;
+  double acc_rhs = 0.0, acc_gc = 0.0, acc_du = 0.0;
+  double gmax = 0.0, gn2 = 0.0;
+  int fail = 0;
+
+  for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
+    const int o0 = p.tile_obs[tile], o1 = p.tile_obs[tile + 1];
+    const int n_here = o1 - o0;
+    const int pt0 = p.obs_point[o0];
+    const int n_pts = p.obs_point[o1 - 1] - pt0 + 1;
+    const bool active = tid < n_here;
+    const int obs = o0 + tid;
+
+    for (int k = tid; k < n_pts * kMaxFrames; k += kTile) s_lane_of[k] = -1;
+    __syncthreads();
+
+    // ---- P1: per observation geometry and point-side contributions -----------------------------------
+    int pt = 0, fa = -1;
+    double Ac[2][6], Ap[2][3], M[3] = {0, 0, 0}, b[2] = {0, 0};
+    double MAp[2][3];
+    if (active) {
+      pt = p.obs_point[obs];
+      const int slot = p.obs_slot[obs];
+      const CamGeom& g = p.geom[slot];
+      fa = g.free_index;
+      const double X[3] = {p.xyz[3 * (size_t)pt], p.xyz[3 * (size_t)pt + 1], p.xyz[3 * (size_t)pt + 2]};
+      double xw[3];
+      transform_point(g, X, xw);
+      projection_jacobians(g, X, xw, p.fx, p.fy, Ac, Ap);
+      M[0] = p.rec[0 * p.rec_stride + obs]; M[1] = p.rec[1 * p.rec_stride + obs]; M[2] = p.rec[2 * p.rec_stride + obs];
+      b[0] = p.rec[3 * p.rec_stride + obs]; b[1] = p.rec[4 * p.rec_stride + obs];
+      // MAp = M Ap (2x3);  V_l = Ap^T M Ap;  g_l = -Ap^T b   (J = -w g A  =>  J^T r = -A^T b)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { MAp[0][k] = M[0] * Ap[0][k] + M[1] * Ap[1][k]; MAp[1][k] = M[1] * Ap[0][k] + M[2] * Ap[1][k]; }
+      double* vg = s_vg + tid * 9;
+      vg[0] = Ap[0][0] * MAp[0][0] + Ap[1][0] * MAp[1][0];
+      vg[1] = Ap[0][0] * MAp[0][1] + Ap[1][0] * MAp[1][1];
+      vg[2] = Ap[0][0] * MAp[0][2] + Ap[1][0] * MAp[1][2];
+      vg[3] = Ap[0][1] * MAp[0][1] + Ap[1][1] * MAp[1][1];
+      vg[4] = Ap[0][1] * MAp[0][2] + Ap[1][1] * MAp[1][2];
+      vg[5] = Ap[0][2] * MAp[0][2] + Ap[1][2] * MAp[1][2];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) vg[6 + k] = -(Ap[0][k] * b[0] + Ap[1][k] * b[1]);
+      if (fa >= 0) s_lane_of[(pt - pt0) * kMaxFrames + fa] = (int8_t)tid;
+    }
+    __syncthreads();
+
+    // ---- P2: point totals, damping, effective inverse, per-observation Schur factors -------------------
+    double rl[6] = {0, 0, 0, 0, 0, 0}, gcl[6] = {0, 0, 0, 0, 0, 0};
+    if (active) {
+      const int l0 = p.pt_begin[pt] - o0, l1 = p.pt_begin[pt + 1] - o0;
+      double V[6] = {0, 0, 0, 0, 0, 0}, gp[3] = {0, 0, 0};
+      for (int l = l0; l < l1; ++l) {
+        const double* vg = s_vg + l * 9;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) V[k] += vg[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) gp[k] += vg[6 + k];
+      }
+      const bool head = (tid == l0);
+      double s[3];
+      const double vd[3] = {V[0], V[3], V[5]};
+      if (p.init_scale) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) s[k] = p.jacobi ? 1.0 / (1.0 + sqrt(vd[k])) : 1.0;
+        if (head) { p.sp[3 * (size_t)pt] = s[0]; p.sp[3 * (size_t)pt + 1] = s[1]; p.sp[3 * (size_t)pt + 2] = s[2]; }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) s[k] = p.sp[3 * (size_t)pt + k];
+      }
+      double D2[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) D2[k] = fmin(fmax(s[k] * s[k] * vd[k], p.min_diag), p.max_diag) / p.radius;
+      // Vs = s V s + D^2 (LevenbergMarquardtStrategy diagonal on the Jacobi-scaled block), Cholesky inverse,
+      // P = s Vs^-1 s  (the point block's inverse mapped back to unscaled coordinates)
+      const double a00 = s[0] * s[0] * V[0] + D2[0], a01 = s[0] * s[1] * V[1], a02 = s[0] * s[2] * V[2];
+      const double a11 = s[1] * s[1] * V[3] + D2[1], a12 = s[1] * s[2] * V[4], a22 = s[2] * s[2] * V[5] + D2[2];
+      bool pd = a00 > 0.0;
+      const double l00 = sqrt(a00);
+      const double l10 = a01 / l00, l20 = a02 / l00;
+      const double d1 = a11 - l10 * l10;
+      pd = pd && d1 > 0.0;
+      const double l11 = sqrt(d1);
+      const double l21 = (a12 - l20 * l10) / l11;
+      const double d2 = a22 - l20 * l20 - l21 * l21;
+      pd = pd && d2 > 0.0;
+      const double l22 = sqrt(d2);
+      double Pm[6] = {0, 0, 0, 0, 0, 0};
+      if (pd) {
+        const double i00 = 1.0 / l00, i11 = 1.0 / l11, i22 = 1.0 / l22;
+        const double i10 = -l10 * i00 * i11;
+        const double i21 = -l21 * i11 * i22;
+        const double i20 = -(l20 * i00 + l21 * i10) * i22;
+        const double v00 = i00 * i00 + i10 * i10 + i20 * i20;
+        const double v01 = i10 * i11 + i20 * i21;
+        const double v02 = i20 * i22;
+        const double v11 = i11 * i11 + i21 * i21;
+        const double v12 = i21 * i22;
+        const double v22 = i22 * i22;
+        Pm[0] = s[0] * s[0] * v00; Pm[1] = s[0] * s[1] * v01; Pm[2] = s[0] * s[2] * v02;
+        Pm[3] = s[1] * s[1] * v11; Pm[4] = s[1] * s[2] * v12; Pm[5] = s[2] * s[2] * v22;
+      } else if (head) {
+        fail = 1;
+      }
+      if (head) {
+        double* pr = p.ptrec + 12 * (size_t)pt;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) pr[k] = Pm[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { pr[6 + k] = gp[k]; pr[9 + k] = D2[k]; }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { gmax = fmax(gmax, fabs(gp[k])); gn2 += gp[k] * gp[k]; }
+      }
+      // W_l = Ac^T M Ap (6x3), Y_l = W_l P (6x3), r_l = g_c,l - Y_l g_p, g_c,l = -Ac^T b
+      if (fa >= 0) {
+        double* so = s_obs + tid * kObsStride;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          const double w0 = Ac[0][j] * MAp[0][0] + Ac[1][j] * MAp[1][0];
+          const double w1 = Ac[0][j] * MAp[0][1] + Ac[1][j] * MAp[1][1];
+          const double w2 = Ac[0][j] * MAp[0][2] + Ac[1][j] * MAp[1][2];
+          const double y0 = w0 * Pm[0] + w1 * Pm[1] + w2 * Pm[2];
+          const double y1 = w0 * Pm[1] + w1 * Pm[3] + w2 * Pm[4];
+          const double y2 = w0 * Pm[2] + w1 * Pm[4] + w2 * Pm[5];
+          so[3 * j] = w0; so[3 * j + 1] = w1; so[3 * j + 2] = w2;
+          so[18 + 3 * j] = y0; so[18 + 3 * j + 1] = y1; so[18 + 3 * j + 2] = y2;
+          gcl[j] = -(Ac[0][j] * b[0] + Ac[1][j] * b[1]);
+          rl[j] = gcl[j] - (y0 * gp[0] + y1 * gp[1] + y2 * gp[2]);
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- P3a: reduced-matrix owners: T[(a,i),(b,:)] -= Y_la[i,:] W_lb^T -----------------------------------
+    for (int q = 0; q < n_pts; ++q) {
+      const int8_t* lo = s_lane_of + q * kMaxFrames;
+#pragma unroll
+      for (int k = 0; k < NT; ++k) {
+        if (ta[k] < 0) continue;
+        const int la = lo[ta[k]], lb = lo[tb[k]];
+        if (la < 0 || lb < 0) continue;
+        const double* Y = s_obs + la * kObsStride + 18 + 3 * ti[k];
+        const double* Wb = s_obs + lb * kObsStride;
+        const double y0 = Y[0], y1 = Y[1], y2 = Y[2];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) acc[k][j] -= y0 * Wb[3 * j] + y1 * Wb[3 * j + 1] + y2 * Wb[3 * j + 2];
+      }
+    }
+    __syncthreads();
+
+    // ---- P3b: camera-side sums: U_l = Ac^T M Ac into the diagonal blocks, rhs, g_c, diag(U) ---------------
+    if (active && fa >= 0) {
+      double* so = s_obs + tid * kObsStride;
+      double MAc[2][6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) { MAc[0][j] = M[0] * Ac[0][j] + M[1] * Ac[1][j]; MAc[1][j] = M[1] * Ac[0][j] + M[2] * Ac[1][j]; }
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = i; j < 6; ++j) so[sym6(i, j)] = Ac[0][i] * MAc[0][j] + Ac[1][i] * MAc[1][j];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) { so[21 + j] = rl[j]; so[27 + j] = gcl[j]; }
+    }
+    __syncthreads();
+    for (int q = 0; q < n_pts; ++q) {
+      const int8_t* lo = s_lane_of + q * kMaxFrames;
+#pragma unroll
+      for (int k = 0; k < NT; ++k) {
+        if (ta[k] < 0 || ta[k] != tb[k]) continue;
+        const int la = lo[ta[k]];
+        if (la < 0) continue;
+        const double* U = s_obs + la * kObsStride;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) acc[k][j] += U[sym6(ti[k], j)];
+      }
+      if (va >= 0) {
+        const int la = lo[va];
+        if (la >= 0) {
+          const double* so = s_obs + la * kObsStride;
+          acc_rhs += so[21 + vi];
+          acc_gc += so[27 + vi];
+          acc_du += so[sym6(vi, vi)];
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- per-block partials --------------------------------------------------------------------------------
+  double* out = p.partial + (size_t)blockIdx.x * p.part_stride;
+#pragma unroll
+  for (int k = 0; k < NT; ++k) {
+    const int q = tid + k * kTile;
+    if (q < p.n_tasks)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) out[q * 6 + j] = acc[k][j];
+  }
+  const int n = 6 * nf;
+  if (va >= 0) {
+    out[6 * p.n_tasks + tid] = acc_rhs;
+    out[6 * p.n_tasks + n + tid] = acc_gc;
+    out[6 * p.n_tasks + 2 * n + tid] = acc_du;
+  }
+  // block reductions of the point-gradient statistics (fixed tree)
+  s_red[tid] = gn2;
+  __syncthreads();
+  for (int s = kTile / 2; s > 0; s >>= 1) { if (tid < s) s_red[tid] += s_red[tid + s]; __syncthreads(); }
+  const double gn2_b = s_red[0];
+  __syncthreads();
+  s_red[tid] = gmax;
+  __syncthreads();
+  for (int s = kTile / 2; s > 0; s >>= 1) { if (tid < s) s_red[tid] = fmax(s_red[tid], s_red[tid + s]); __syncthreads(); }
+  const double gmax_b = s_red[0];
+  __syncthreads();
+  s_red[tid] = (double)fail;
+  __syncthreads();
+  for (int s = kTile / 2; s > 0; s >>= 1) { if (tid < s) s_red[tid] = fmax(s_red[tid], s_red[tid + s]); __syncthreads(); }
+  if (tid == 0) {
+    out[6 * p.n_tasks + 3 * n + 0] = gmax_b;
+    out[6 * p.n_tasks + 3 * n + 1] = gn2_b;
+    out[6 * p.n_tasks + 3 * n + 2] = s_red[0];
+  }
+}
+
+// Sums the per-block partials in a fixed order.  grid.x covers the entries, grid.y splits the blocks into chunks.
+//   out[chunk][stride]; the last three entries are (max, sum, max).
+__global__ void k_reduce_partials(const double* __restrict__ partial, int n_blocks, int stride, int n_chunks,
+                                  double* __restrict__ out) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int chunk = blockIdx.y;
+  if (e >= stride) return;
+  const int per = (n_blocks + n_chunks - 1) / n_chunks;
+  const int b0 = chunk * per, b1 = min(n_blocks, b0 + per);
+  const bool is_max = (e == stride - 3) || (e == stride - 1);
+  double acc = 0.0;
+  for (int b = b0; b < b1; ++b) {
+    const double v = partial[(size_t)b * stride + e];
+    acc = is_max ? fmax(acc, v) : acc + v;
+  }
+  out[(size_t)chunk * stride + e] = acc;
+}
+
+// Second level + packing for the transport: packed_sum[0, stride-3) = T | rhs | g_c | diag(U); then
+// packed_sum[stride-3] = cost at the linearisation point (sum of the Jacobian pass block costs),
+// packed_sum[stride-2] = sum g_p^2;  scal[kGmaxPts..] = max group.
+__global__ void k_pack_reduced(const double* __restrict__ red, int stride, int n_chunks,
+                               const double* __restrict__ block_cost, const int32_t* __restrict__ block_fail,
+                               int n_cost_blocks, double* __restrict__ packed_sum, double* __restrict__ scal) {
+  __shared__ double s_red[256];
+  __shared__ int s_f[256];
+  const int tid = threadIdx.x;
+  for (int e = blockIdx.x * blockDim.x + tid; e < stride; e += gridDim.x * blockDim.x) {
+    const bool is_max = (e == stride - 3) || (e == stride - 1);
+    double acc = 0.0;
+    for (int c = 0; c < n_chunks; ++c) {
+      const double v = red[(size_t)c * stride + e];
+      acc = is_max ? fmax(acc, v) : acc + v;
+    }
+    if (e < stride - 3) packed_sum[e] = acc;
+    else if (e == stride - 3) scal[kGmaxPts] = acc;
+    else if (e == stride - 2) packed_sum[stride - 2] = acc;
+    else scal[kSchurFail] = acc;
+  }
+  if (blockIdx.x == 0) {
+    // cost of the linearisation point: fixed-order sum of the Jacobian pass block partials
+    double acc = 0.0; int f = 0;
+    for (int b = tid; b < n_cost_blocks; b += 256) { acc += block_cost[b]; f |= block_fail[b]; }
+    s_red[tid] = acc; s_f[tid] = f;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (tid < s) { s_red[tid] += s_red[tid + s]; s_f[tid] |= s_f[tid + s]; } __syncthreads(); }
+    if (tid == 0) { packed_sum[stride - 3] = s_red[0]; scal[kEvalFailLin] = (double)s_f[0]; }
+  }
+}
+
+// =====================================================================================================
+// reduced camera system: scaling, damping, dense Cholesky, camera step (single workgroup)
+// =====================================================================================================
+struct SolveParams {
+  const double* packed;     // reduced (global) packed_sum
+  const double* cams;       // current cameras [n_frames][6]
+  double* cams_cand;        // candidate cameras
+  double* delta_c;          // [n_frames][6] unscaled camera step (0 for the constant camera)
+  double* sc;               // [6 n_free] Jacobi scale of the camera columns (written when init_scale)
+  double* S_dbg;            // [n*n] scaled + damped reduced matrix (test hook)
+  double* rhs_dbg;          // [n]
+  double* scal;
+  const CamGeom* geom;      // for free_index of every slot
+  int32_t n_frames, n_free, n_tasks, stride;
+  int32_t init_scale, jacobi;
+  double radius, min_diag, max_diag;
+};
+
+__global__ __launch_bounds__(256) void k_solve(SolveParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int n = 6 * p.n_free;
+  double* S = reinterpret_cast<double*>(smem);   // [n][n]
+  double* y = S + n * n;                         // [n]
+  double* sc = y + n;                            // [n]
+  double* D2 = sc + n;                           // [n]
+  double* gcs = D2 + n;                          // [n]
+  __shared__ int s_ok;
+  const int tid = threadIdx.x;
+  const double* T = p.packed;
+  const double* rhs = p.packed + 6 * p.n_tasks;
+  const double* gc = rhs + n;
+  const double* du = gc + n;
+  if (tid == 0) s_ok = 1;
+  for (int i = tid; i < n; i += 256) {
+    double s;
+    if (p.init_scale) { s = p.jacobi ? 1.0 / (1.0 + sqrt(du[i])) : 1.0; p.sc[i] = s; }
+    else s = p.sc[i];
+    sc[i] = s;
+    D2[i] = fmin(fmax(s * s * du[i], p.min_diag), p.max_diag) / p.radius;
+    gcs[i] = s * gc[i];
+  }
+  __syncthreads();
+  // scatter the task layout into the dense symmetric matrix, scale, damp
+  for (int q = tid; q < p.n_tasks; q += 256) {
+    const int pair = q / 6, i = q - pair * 6;
+    int a = 0, rem = pair;
+    while (rem >= p.n_free - a) { rem -= p.n_free - a; ++a; }
+    const int b = a + rem;
+    for (int j = 0; j < 6; ++j) {
+      const int r = 6 * a + i, c = 6 * b + j;
+      double v = sc[r] * T[q * 6 + j] * sc[c];
+      if (r == c) v += D2[r];
+      S[r * n + c] = v;
+      if (a != b) S[c * n + r] = v;
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += 256) { y[i] = sc[i] * rhs[i]; p.rhs_dbg[i] = y[i]; }
+  for (int k = tid; k < n * n; k += 256) p.S_dbg[k] = S[k];
+  __syncthreads();
+  // right-looking Cholesky, lower triangle in place
+  for (int j = 0; j < n; ++j) {
+    if (tid == 0) {
+      const double d = S[j * n + j];
+      if (!(d > 0.0) || !isfinite(d)) { s_ok = 0; S[j * n + j] = 1.0; } else S[j * n + j] = sqrt(d);
+    }
+    __syncthreads();
+    const double djj = S[j * n + j];
+    for (int i = j + 1 + tid; i < n; i += 256) S[i * n + j] /= djj;
+    __syncthreads();
+    const int m = n - j - 1;
+    for (int k = tid; k < m * m; k += 256) {
+      const int r = j + 1 + k / m, c = j + 1 + k % m;
+      if (c <= r) S[r * n + c] -= S[r * n + j] * S[c * n + j];
+    }
+    __syncthreads();
+  }
+  // forward substitution L z = y (column oriented), then L^T x = z
+  for (int j = 0; j < n; ++j) {
+    if (tid == 0) y[j] /= S[j * n + j];
+    __syncthreads();
+    const double yj = y[j];
+    for (int i = j + 1 + tid; i < n; i += 256) y[i] -= S[i * n + j] * yj;
+    __syncthreads();
+  }
+  for (int j = n - 1; j >= 0; --j) {
+    if (tid == 0) y[j] /= S[j * n + j];
+    __syncthreads();
+    const double yj = y[j];
+    for (int i = tid; i < j; i += 256) y[i] -= S[j * n + i] * yj;
+    __syncthreads();
+  }
+  // camera step delta_c = -sc * y; candidate cameras; replicated scalars
+  if (tid < 6 * p.n_frames) {
+    const int slot = tid / 6, k = tid % 6;
+    const int fa = p.geom[slot].free_index;
+    double d = 0.0;
+    if (fa >= 0) d = -sc[6 * fa + k] * y[6 * fa + k];
+    p.delta_c[tid] = d;
+    p.cams_cand[tid] = p.cams[tid] + d;
+  }
+  if (tid == 0) {
+    double mcc = 0.0, st2 = 0.0, x2 = 0.0, gmax = 0.0, gn2 = 0.0;
+    bool finite = true;
+    for (int i = 0; i < n; ++i) {
+      mcc += 0.5 * y[i] * gcs[i] + 0.5 * D2[i] * y[i] * y[i];
+      const double d = sc[i] * y[i];
+      st2 += d * d;
+      gmax = fmax(gmax, fabs(gc[i]));
+      gn2 += gc[i] * gc[i];
+      finite = finite && isfinite(y[i]);
+    }
+    for (int s = 0; s < p.n_frames; ++s)
+      if (p.geom[s].free_index >= 0)
+        for (int k = 0; k < 6; ++k) x2 += p.cams[6 * s + k] * p.cams[6 * s + k];
+    p.scal[kMccCams] = mcc; p.scal[kStep2Cams] = st2; p.scal[kX2Cams] = x2;
+    p.scal[kGmaxCams] = gmax; p.scal[kGnorm2Cams] = gn2;
+    p.scal[kSolveOk] = (s_ok && finite) ? 1.0 : 0.0;
+    p.scal[kCostLin] = p.packed[p.stride - 3];
+    p.scal[kGnorm2Pts] = p.packed[p.stride - 2];
+  }
+}
+
+// =====================================================================================================
+// back-substitution (SchurEliminator::BackSubstitute): one lane per point
+// =====================================================================================================
+struct BacksubParams {
+  const double* xyz;
+  double* xyz_cand;
+  const CamGeom* geom;
+  const double* rec;
+  const int32_t* pt_begin;
+  const uint8_t* obs_slot;
+  const double* sp;
+  const double* ptrec;
+  const double* delta_c;
+  double* block_out;     // [gridDim.x][3]: mcc, step^2, x^2
+  int64_t rec_stride;
+  int32_t n_points;
+  double fx, fy;
+};
+
+__global__ __launch_bounds__(256) void k_backsub(BacksubParams p) {
+  __shared__ double s_red[3][256];
+  const int tid = threadIdx.x;
+  const int pt = blockIdx.x * 256 + tid;
+  double mcc = 0.0, st2 = 0.0, x2 = 0.0;
+  if (pt < p.n_points) {
+    const double X[3] = {p.xyz[3 * (size_t)pt], p.xyz[3 * (size_t)pt + 1], p.xyz[3 * (size_t)pt + 2]};
+    double acc[3] = {0, 0, 0};
+    for (int o = p.pt_begin[pt]; o < p.pt_begin[pt + 1]; ++o) {
+      const int slot = p.obs_slot[o];
+      const CamGeom& g = p.geom[slot];
+      if (g.free_index < 0) continue;
+      double xw[3], Ac[2][6], Ap[2][3];
+      transform_point(g, X, xw);
+      projection_jacobians(g, X, xw, p.fx, p.fy, Ac, Ap);
+      const double* dc = p.delta_c + 6 * slot;
+      double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { t0 += Ac[0][k] * dc[k]; t1 += Ac[1][k] * dc[k]; }
+      const double m0 = p.rec[0 * p.rec_stride + o], m1 = p.rec[1 * p.rec_stride + o], m2 = p.rec[2 * p.rec_stride + o];
+      const double u0 = m0 * t0 + m1 * t1, u1 = m1 * t0 + m2 * t1;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) acc[k] += Ap[0][k] * u0 + Ap[1][k] * u1;   // W_l^T delta_c
+    }
+    const double* pr = p.ptrec + 12 * (size_t)pt;
+    const double q0 = pr[6] + acc[0], q1 = pr[7] + acc[1], q2 = pr[8] + acc[2];
+    const double d0 = -(pr[0] * q0 + pr[1] * q1 + pr[2] * q2);
+    const double d1 = -(pr[1] * q0 + pr[3] * q1 + pr[4] * q2);
+    const double d2 = -(pr[2] * q0 + pr[4] * q1 + pr[5] * q2);
+    const double d[3] = {d0, d1, d2};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const double s = p.sp[3 * (size_t)pt + k];
+      const double yk = -d[k] / s;                       // step in Jacobi-scaled coordinates is -y
+      mcc += 0.5 * yk * (s * pr[6 + k]) + 0.5 * pr[9 + k] * yk * yk;
+      st2 += d[k] * d[k];
+      x2 += X[k] * X[k];
+      p.xyz_cand[3 * (size_t)pt + k] = X[k] + d[k];
+    }
+  }
+  s_red[0][tid] = mcc; s_red[1][tid] = st2; s_red[2][tid] = x2;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) { s_red[0][tid] += s_red[0][tid + s]; s_red[1][tid] += s_red[1][tid + s]; s_red[2][tid] += s_red[2][tid + s]; }
+    __syncthreads();
+  }
+  if (tid == 0) { p.block_out[3 * blockIdx.x] = s_red[0][0]; p.block_out[3 * blockIdx.x + 1] = s_red[1][0]; p.block_out[3 * blockIdx.x + 2] = s_red[2][0]; }
+}
+
+// Fixed-order sums of the back-substitution and cost-pass block partials into the scalar block.
+__global__ __launch_bounds__(256) void k_finalize_step(const double* __restrict__ bs_out, int n_bs_blocks,
+                                                        const double* __restrict__ block_cost,
+                                                        const int32_t* __restrict__ block_fail, int n_cost_blocks,
+                                                        double* __restrict__ scal) {
+  __shared__ double s_red[4][256];
+  __shared__ int s_f[256];
+  const int tid = threadIdx.x;
+  double a0 = 0, a1 = 0, a2 = 0, a3 = 0; int f = 0;
+  for (int b = tid; b < n_bs_blocks; b += 256) { a0 += bs_out[3 * b]; a1 += bs_out[3 * b + 1]; a2 += bs_out[3 * b + 2]; }
+  for (int b = tid; b < n_cost_blocks; b += 256) { a3 += block_cost[b]; f |= block_fail[b]; }
+  s_red[0][tid] = a0; s_red[1][tid] = a1; s_red[2][tid] = a2; s_red[3][tid] = a3; s_f[tid] = f;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) {
+      for (int k = 0; k < 4; ++k) s_red[k][tid] += s_red[k][tid + s];
+      s_f[tid] |= s_f[tid + s];
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    scal[kMccPts] = s_red[0][0]; scal[kStep2Pts] = s_red[1][0]; scal[kX2Pts] = s_red[2][0];
+    scal[kCandCost] = s_red[3][0]; scal[kEvalFailCand] = (double)s_f[0];
+  }
+}
+
+}  // namespace pba

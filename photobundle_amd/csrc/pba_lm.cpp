@@ -1,0 +1,201 @@
+// pba_lm.cpp -- host Levenberg-Marquardt driver: replaces ceres::Solve at reference src/photobundle.cc:829.
+//
+// Control flow = Ceres (>= 1.12) TrustRegionMinimizer + LevenbergMarquardtStrategy with the settings of
+// GetSolverOptions (photobundle.cc:738-761) and the Ceres defaults listed in SURVEY.md 8c.  All heavy work is
+// behind the C-ABI primitives (pba_linearize / pba_step / pba_accept); this file only decides.
+//
+// One deviation in scheduling (not in results): the gradient norms of a freshly accepted point come out of the
+// same device pass that computes the NEXT trust-region step, so that step is computed speculatively right after
+// an acceptance; if the iteration then terminates the solve (gradient tolerance / iteration limit) the
+// speculative step is simply dropped (at the iteration limit only the gradient part is run).
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+
+#include "../../include/pba.h"
+
+#include "pba_internal.h"
+
+namespace {
+double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+}
+
+extern "C" int pba_solve(pba_engine* e, const pba_solver_options* o, pba_solver_summary* sum, pba_iteration_summary* its,
+                         int32_t max_out) {
+  if (!e || !o || !sum) return PBA_ERR_INVALID;
+  const double t_start = now();
+  std::memset(sum, 0, sizeof(*sum));
+  sum->termination_type = 1;
+  std::snprintf(sum->message, sizeof(sum->message), "Maximum number of iterations reached.");
+  double blocks = (double)pba_internal_local_blocks(e);
+  if (pba_internal_allreduce_host(e, &blocks, 1, 0)) return PBA_ERR_COMM;
+  sum->num_residual_blocks = (int32_t)blocks;
+  sum->num_residuals = (int32_t)(blocks * pba_internal_patch_len(e));
+  sum->fixed_cost = 0.0;   // every residual block has a free point
+  const bool verbose = o->verbose && pba_internal_rank(e) == 0;
+
+  int n_it = 0;
+  auto push = [&](const pba_iteration_summary& s) {
+    if (its && n_it < max_out) its[n_it] = s;
+    ++n_it;
+    if (verbose)
+      std::printf("%4d  cost % .6e  change % .3e  |grad| %.3e  |step| %.3e  rho % .3e  radius %.3e  %s\n", s.iteration, s.cost,
+                  s.cost_change, s.gradient_max_norm, s.step_norm, s.relative_decrease, s.trust_region_radius,
+                  s.step_is_successful ? "ok" : (s.step_is_valid ? "rejected" : "invalid"));
+  };
+
+  double radius = o->initial_trust_region_radius, decrease_factor = 2.0;
+  int num_consecutive_invalid = 0;
+  pba_step_info info;
+  std::memset(&info, 0, sizeof(info));
+
+  // ---- IterationZero -----------------------------------------------------------------------------------
+  double t_iter = now();
+  int rc = pba_linearize(e, nullptr);
+  if (rc) return rc;
+  sum->num_jacobian_passes = 1;
+  bool last = o->max_num_iterations <= 0;
+  rc = pba_internal_step(e, radius, 1, o, &info, last ? 1 : 0);
+  if (rc == PBA_ERR_NUMERIC) {
+    sum->termination_type = 2;
+    std::snprintf(sum->message, sizeof(sum->message), "Initial residual and Jacobian evaluation failed.");
+    sum->total_time_in_seconds = now() - t_start;
+    return PBA_OK;
+  }
+  if (rc) return rc;
+  if (!last) sum->num_cost_passes++;
+  bool info_valid = !last;
+  double x_cost = info.cost;
+  sum->initial_cost = x_cost;
+  double minimum_cost = x_cost;
+
+  pba_iteration_summary it;
+  std::memset(&it, 0, sizeof(it));
+  it.iteration = 0; it.eta = 1e-1;
+  it.cost = x_cost; it.gradient_max_norm = info.gradient_max_norm; it.gradient_norm = info.gradient_norm;
+  it.step_is_valid = 1; it.step_is_successful = 1;
+
+  auto finalize = [&]() -> bool {
+    // TrustRegionMinimizer::FinalizeIterationAndCheckIfMinimizerCanContinue
+    if (it.step_is_successful) {
+      ++sum->num_successful_steps;
+      if (x_cost < minimum_cost || it.iteration == 0) { minimum_cost = x_cost; it.step_is_nonmonotonic = 0; }
+      else it.step_is_nonmonotonic = 1;
+    } else {
+      ++sum->num_unsuccessful_steps;
+    }
+    it.trust_region_radius = radius;
+    const double t = now();
+    it.iteration_time_in_seconds = t - t_iter;
+    it.cumulative_time_in_seconds = t - t_start;
+    push(it);
+    if (it.iteration >= o->max_num_iterations) {
+      sum->termination_type = 1;
+      std::snprintf(sum->message, sizeof(sum->message), "Maximum number of iterations reached. Number of iterations: %d.", it.iteration);
+      return false;
+    }
+    if (it.step_is_successful && it.gradient_max_norm <= o->gradient_tolerance) {
+      sum->termination_type = 0;
+      std::snprintf(sum->message, sizeof(sum->message), "Gradient tolerance reached. Gradient max norm: %e <= %e", it.gradient_max_norm, o->gradient_tolerance);
+      return false;
+    }
+    if (radius <= o->min_trust_region_radius) {
+      sum->termination_type = 0;
+      std::snprintf(sum->message, sizeof(sum->message), "Minimum trust region radius reached. Trust region radius: %e <= %e", radius, o->min_trust_region_radius);
+      return false;
+    }
+    return true;
+  };
+  auto step_rejected = [&]() { radius = radius / decrease_factor; decrease_factor *= 2.0; };   // LM::StepRejected
+
+  while (finalize()) {
+    t_iter = now();
+    const int iteration = it.iteration + 1;
+    const double prev_gmax = it.gradient_max_norm, prev_gnorm = it.gradient_norm;
+    std::memset(&it, 0, sizeof(it));
+    it.iteration = iteration; it.eta = 1e-1;
+    it.gradient_max_norm = prev_gmax; it.gradient_norm = prev_gnorm;
+    const double t_solve = now();
+    if (!info_valid) {
+      // re-solve with the new damping from the stored linearisation (rejected / invalid predecessor)
+      rc = pba_internal_step(e, radius, 0, o, &info, 0);
+      if (rc) return rc;
+      sum->num_resolve_passes++;
+      sum->num_cost_passes++;
+      it.step_solver_time_in_seconds = now() - t_solve;
+    }
+    info_valid = false;
+    it.linear_solver_iterations = 1;
+    it.model_cost_change = info.model_cost_change;
+    const bool step_is_valid = info.linear_solver_ok && info.model_cost_change > 0.0;
+    if (!step_is_valid) {
+      // HandleInvalidStep
+      ++num_consecutive_invalid;
+      if (num_consecutive_invalid >= o->max_num_consecutive_invalid_steps) {
+        sum->termination_type = 2;
+        std::snprintf(sum->message, sizeof(sum->message), "Number of consecutive invalid steps more than Solver::Options::max_num_consecutive_invalid_steps: %d", o->max_num_consecutive_invalid_steps);
+        it.cost = x_cost; it.trust_region_radius = radius;
+        push(it);
+        break;
+      }
+      step_rejected();
+      it.cost = x_cost;
+      continue;
+    }
+    it.step_is_valid = 1;
+    num_consecutive_invalid = 0;
+    const double candidate_cost = info.eval_ok ? info.candidate_cost : std::numeric_limits<double>::max();
+    it.candidate_cost = candidate_cost;
+    // ParameterToleranceReached
+    it.step_norm = info.step_norm;
+    const double step_size_tolerance = o->parameter_tolerance * (info.x_norm + o->parameter_tolerance);
+    if (it.step_norm <= step_size_tolerance) {
+      sum->termination_type = 0;
+      std::snprintf(sum->message, sizeof(sum->message), "Parameter tolerance reached. Relative step_norm: %e <= %e.", it.step_norm / (info.x_norm + o->parameter_tolerance), o->parameter_tolerance);
+      break;
+    }
+    // FunctionToleranceReached
+    it.cost_change = x_cost - candidate_cost;
+    if (std::fabs(it.cost_change) <= o->function_tolerance * x_cost) {
+      sum->termination_type = 0;
+      std::snprintf(sum->message, sizeof(sum->message), "Function tolerance reached. |cost_change|/cost: %e <= %e", std::fabs(it.cost_change) / x_cost, o->function_tolerance);
+      break;
+    }
+    // IsStepSuccessful
+    it.relative_decrease = it.cost_change / info.model_cost_change;
+    if (it.relative_decrease > o->min_relative_decrease) {
+      // HandleSuccessfulStep: x <- candidate, re-linearise, LM::StepAccepted
+      if ((rc = pba_accept(e))) return rc;
+      if ((rc = pba_linearize(e, nullptr))) return rc;
+      sum->num_jacobian_passes++;
+      x_cost = candidate_cost;
+      radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * it.relative_decrease - 1.0, 3));
+      radius = std::min(o->max_trust_region_radius, radius);
+      decrease_factor = 2.0;
+      last = iteration >= o->max_num_iterations;
+      rc = pba_internal_step(e, radius, 0, o, &info, last ? 1 : 0);
+      if (rc == PBA_ERR_NUMERIC) {
+        sum->termination_type = 2;
+        std::snprintf(sum->message, sizeof(sum->message), "Residual and Jacobian evaluation failed.");
+        break;
+      }
+      if (rc) return rc;
+      if (!last) sum->num_cost_passes++;
+      info_valid = !last;
+      it.step_is_successful = 1;
+      it.cost = x_cost;
+      it.gradient_max_norm = info.gradient_max_norm;
+      it.gradient_norm = info.gradient_norm;
+    } else {
+      // HandleUnsuccessfulStep
+      step_rejected();
+      it.cost = candidate_cost;
+    }
+  }
+  sum->final_cost = minimum_cost;
+  sum->num_iterations = n_it < max_out ? n_it : max_out;
+  sum->total_time_in_seconds = now() - t_start;
+  return PBA_OK;
+}

@@ -1,0 +1,189 @@
+"""Python mirror of the engine's C-ABI (include/pba.h): thin, no compute.  The product path is
+WindowProblem -> Engine.load() -> Engine.solve(); everything numerical happens in libpba_hip.so on the GPU."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import EngineUnavailable  # noqa: F401
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def default_solver_options(**kw):
+    o = _lib.SolverOptions()
+    _lib.lib().pba_default_solver_options(C.byref(o))
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise AttributeError(k)
+        setattr(o, k, v)
+    return o
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Engine:
+    """One engine = one GPU = one shard of points (all cameras and frames replicated)."""
+
+    def __init__(self, rows, cols, K, radius, max_frames, huber=0.0, device=0):
+        self._L = _lib.lib()
+        cfg = _lib.Config()
+        cfg.rows, cfg.cols, cfg.max_frames, cfg.radius = int(rows), int(cols), int(max_frames), int(radius)
+        cfg.fx, cfg.fy, cfg.cx, cfg.cy = [float(v) for v in K]
+        cfg.huber = float(huber)
+        cfg.device = int(device)
+        self._h = C.c_void_p()
+        rc = self._L.pba_create(C.byref(cfg), C.byref(self._h))
+        if rc != 0:
+            self._h = None
+            raise EngineError("pba_create: %s" % self._L.pba_status_string(rc).decode())
+        self.cfg = cfg
+        self.n_points = self.n_obs = self.n_frames = 0
+        self._cb = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.pba_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise EngineError("%s: %s (%s)" % (what, self._L.pba_status_string(rc).decode(),
+                                               self._L.pba_last_error(self._h).decode()))
+
+    # ---- data ------------------------------------------------------------------------------------------
+    def set_frame(self, slot, image_u8):
+        img = np.ascontiguousarray(image_u8, dtype=np.uint8)
+        assert img.shape == (self.cfg.rows, self.cfg.cols)
+        self._check(self._L.pba_set_frame_u8(self._h, int(slot), _ptr(img)), "pba_set_frame_u8")
+
+    def get_frame_planes(self, slot):
+        out = np.empty((3, self.cfg.rows, self.cfg.cols), np.float32)
+        self._check(self._L.pba_get_frame_planes(self._h, int(slot), _ptr(out[0]), _ptr(out[1]), _ptr(out[2])),
+                    "pba_get_frame_planes")
+        return out
+
+    def set_problem(self, xyz, desc, obs_point, obs_slot, weights):
+        xyz = np.ascontiguousarray(xyz, np.float64)
+        desc = np.ascontiguousarray(desc, np.float64)
+        op = np.ascontiguousarray(obs_point, np.int32)
+        os_ = np.ascontiguousarray(obs_slot, np.int32)
+        w = np.ascontiguousarray(weights, np.float64)
+        self._check(self._L.pba_set_problem(self._h, xyz.shape[0], _ptr(xyz), _ptr(desc), op.shape[0], _ptr(op),
+                                            _ptr(os_), _ptr(w)), "pba_set_problem")
+        self.n_points, self.n_obs = xyz.shape[0], op.shape[0]
+
+    def set_cameras(self, cams, fixed_slot=0):
+        cams = np.ascontiguousarray(cams, np.float64)
+        self._check(self._L.pba_set_cameras(self._h, _ptr(cams), cams.shape[0], int(fixed_slot)), "pba_set_cameras")
+        self.n_frames = cams.shape[0]
+        self.n_free = self.n_frames - (1 if fixed_slot >= 0 else 0)
+
+    def load(self, prob):
+        """Uploads a WindowProblem (frames from prob.images)."""
+        assert prob.images is not None, "the engine consumes u8 frames (addFrame's input), not float planes"
+        for s in range(prob.n_frames):
+            self.set_frame(s, prob.images[s])
+        self.set_problem(prob.xyz, prob.desc, prob.obs_point, prob.obs_slot, prob.weights)
+        self.set_cameras(prob.cams, prob.fixed_slot)
+        return self
+
+    def get_state(self):
+        cams = np.zeros((self.n_frames, 6))
+        xyz = np.zeros((self.n_points, 3))
+        self._check(self._L.pba_get_state(self._h, _ptr(cams), _ptr(xyz)), "pba_get_state")
+        return cams, xyz
+
+    # ---- primitive passes --------------------------------------------------------------------------------
+    def linearize(self, want_cost=True):
+        c = C.c_double(0.0)
+        self._check(self._L.pba_linearize(self._h, C.byref(c) if want_cost else None), "pba_linearize")
+        return c.value
+
+    def step(self, radius, init_scale=False, options=None):
+        o = options or default_solver_options()
+        info = _lib.StepInfo()
+        self._check(self._L.pba_step(self._h, float(radius), int(bool(init_scale)), C.byref(o), C.byref(info)), "pba_step")
+        return {f: getattr(info, f) for f, _ in _lib.StepInfo._fields_}
+
+    def accept(self):
+        self._check(self._L.pba_accept(self._h), "pba_accept")
+
+    def reduced_system(self):
+        n = C.c_int32(0)
+        nn = 6 * self.n_free
+        S = np.zeros((nn, nn))
+        rhs = np.zeros(nn)
+        self._check(self._L.pba_get_reduced_system(self._h, _ptr(S), _ptr(rhs), C.byref(n)), "pba_get_reduced_system")
+        assert n.value == nn
+        return S, rhs
+
+    def obs_records(self):
+        rec = np.zeros((self.n_obs, 6))
+        self._check(self._L.pba_get_obs_records(self._h, _ptr(rec)), "pba_get_obs_records")
+        return rec
+
+    # ---- the LM loop ---------------------------------------------------------------------------------------
+    def solve(self, options=None, max_iterations_out=512):
+        o = options or default_solver_options()
+        s = _lib.SolverSummary()
+        its = (_lib.IterationSummary * max_iterations_out)()
+        self._check(self._L.pba_solve(self._h, C.byref(o), C.byref(s), its, max_iterations_out), "pba_solve")
+        res = {f: getattr(s, f) for f, _ in _lib.SolverSummary._fields_}
+        res["message"] = s.message.decode()
+        res["iterations"] = [{f: getattr(its[i], f) for f, _ in _lib.IterationSummary._fields_}
+                             for i in range(s.num_iterations)]
+        res["cams"], res["xyz"] = self.get_state()
+        return res
+
+    # ---- multi-GPU -------------------------------------------------------------------------------------------
+    @staticmethod
+    def comm_unique_id():
+        buf = (C.c_char * 128)()
+        rc = _lib.lib().pba_comm_unique_id(buf)
+        if rc != 0:
+            raise EngineError("pba_comm_unique_id failed (librccl not loadable?)")
+        return bytes(buf)
+
+    def comm_init_rccl(self, unique_id, rank, world):
+        buf = (C.c_char * 128).from_buffer_copy(unique_id)
+        self._check(self._L.pba_comm_init_rccl(self._h, buf, int(rank), int(world)), "pba_comm_init_rccl")
+
+    def comm_init_callback(self, fn, rank, world):
+        """fn(numpy float64 view, op) must all-reduce in place (op 0 = sum, 1 = max)."""
+        def tramp(ptr, n, op, ctx):
+            try:
+                a = np.ctypeslib.as_array(ptr, shape=(n,))
+                fn(a, int(op))
+                return 0
+            except Exception:
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._cb = _lib.ALLREDUCE_FN(tramp)
+        self._check(self._L.pba_comm_init_callback(self._h, self._cb, None, int(rank), int(world)), "pba_comm_init_callback")
+
+    # ---- counters ----------------------------------------------------------------------------------------------
+    def reset_counters(self):
+        self._check(self._L.pba_reset_counters(self._h), "pba_reset_counters")
+
+    def counters(self):
+        c = _lib.Counters()
+        self._check(self._L.pba_get_counters(self._h, C.byref(c)), "pba_get_counters")
+        return {f: getattr(c, f) for f, _ in _lib.Counters._fields_}
