@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py -- LM iterations/sec of the MI355X photometric BA engine on the BASELINE.json workload.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+One "step" = one trust-region LM iteration of the reference's solve (reference src/photobundle.cc:829): damped Schur
+solve of the stored linearisation + candidate cost pass, and -- when the step is accepted -- the Jacobian pass at the
+new point.  Workload at N = 1: BASELINE.json configs[1] (8-frame window, 50k points, 5x5 patch, single level, synthetic
+KITTI-shaped frames).  N > 1 is WEAK scaling: every rank owns 50k points of one N*50k-point window, all
+cameras/frames replicated, one RCCL all-reduce of the reduced camera system per solve; `value` is the whole-job rate
+in 50k-point-window LM iterations per second (= N * iterations/sec), `residuals_per_sec` is the same thing in scalar
+residual evaluations.  Inputs are resident in HBM before the timed region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12   # bytes/s, MI355X HBM3E spec (MI355X_MICROARCH.md)
+
+
+def algorithmic_bytes(radius, n_bar):
+    """SURVEY.md 8d byte model per observation (C = 1)."""
+    F = (2 * radius + 2) ** 2
+    P = (2 * radius + 1) ** 2
+    sample_jac = 12 * F + 4 * P + 24 + 8          # footprint (I, Gx, Gy fp32) + descriptor + XYZ + obs index
+    schur = 144 + 72.0 / n_bar                    # W_pc write + V_p, g_p per point
+    b_jac = sample_jac + schur
+    b_cost = 4 * F + 4 * P + 24 + 8
+    b_res = 144 + 72.0 / n_bar
+    return dict(sample_jac=sample_jac, schur=schur, b_jac=b_jac, b_cost=b_cost, b_res=b_res)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=8)
+    ap.add_argument("--points", type=int, default=50000, help="points per GPU")
+    ap.add_argument("--radius", type=int, default=2)
+    ap.add_argument("--huber", type=float, default=0.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-points", type=int, default=12500, help="points of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-steps", type=int, default=4)
+    args = ap.parse_args()
+
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from photobundle_amd import synthetic
+    from photobundle_amd.engine import Engine, default_solver_options
+
+    # ---- synthetic window: identical frames/cameras on every rank, rank-specific points ----------------------
+    t0 = time.time()
+    prob = synthetic.make_window(n_frames=args.frames, n_points=args.points, radius=args.radius, huber=args.huber,
+                                 visibility="dense", point_seed_offset=rank)
+    t_gen = time.time() - t0
+    rows, cols = prob.images.shape[1:]
+    P = prob.patch_len
+    n_obs_local = prob.n_obs
+    n_bar = n_obs_local / prob.n_points
+
+    eng = Engine(rows, cols, prob.K, prob.radius, prob.n_frames, huber=prob.huber, device=local_rank)
+    eng.load(prob)
+    if world > 1:
+        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            uid.copy_(torch.frombuffer(bytearray(Engine.comm_unique_id()), dtype=torch.uint8))
+        dist.broadcast(uid, 0)
+        eng.comm_init_rccl(bytes(uid.cpu().numpy().tobytes()), rank, world)
+
+    def reset_state():
+        eng.set_problem(prob.xyz, prob.desc, prob.obs_point, prob.obs_slot, prob.weights)
+        eng.set_cameras(prob.cams, prob.fixed_slot)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def opts(k):
+        # fixed iteration count: tolerances disabled (SURVEY.md 8d "Fixed 10 LM iterations for throughput")
+        return default_solver_options(max_num_iterations=k, function_tolerance=0.0, gradient_tolerance=0.0,
+                                      parameter_tolerance=0.0)
+
+    if args.warmup > 0:
+        eng.solve(opts(args.warmup))
+        reset_state()
+    eng.reset_counters()
+    barrier()
+    t1 = time.perf_counter()
+    res = eng.solve(opts(args.steps))
+    barrier()
+    elapsed = time.perf_counter() - t1
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ctr = eng.counters()
+
+    iters_done = len(res["iterations"]) - 1
+    n_jac, n_cost, n_res = res["num_jacobian_passes"], res["num_cost_passes"], res["num_resolve_passes"]
+    n_obs_global = res["num_residual_blocks"]
+    iters_per_sec = iters_done / elapsed
+    value = world * iters_per_sec
+    residuals_per_sec = n_obs_global * P * (n_jac + n_cost) / elapsed
+
+    ab = algorithmic_bytes(prob.radius, n_bar)
+    run_bytes = n_obs_global * (n_jac * ab["b_jac"] + n_cost * ab["b_cost"] + n_res * ab["b_res"])
+    # dominant kernel, timed live with HIP events on the engine's stream (rank-local launch = local observations)
+    kern = {
+        "k_sample<JAC> (Jacobian pass)": (ctr["linearize_ms"], ctr["linearize_launches"], ab["sample_jac"]),
+        "k_sample<cost> (cost pass)": (ctr["cost_ms"], ctr["cost_launches"], ab["b_cost"]),
+        "k_schur (point elimination)": (ctr["schur_ms"], ctr["schur_launches"], ab["schur"]),
+    }
+    dom = max(kern, key=lambda k: kern[k][0])
+    ms, launches, bytes_per_obs = kern[dom]
+    avg_s = (ms / max(1, launches)) * 1e-3
+    achieved = n_obs_local * bytes_per_obs / avg_s if avg_s > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(dom.split(" ")[0])
+        except Exception:
+            traffic = None
+    roofline = {
+        "bound": "hbm", "kernel": dom, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+        "frac": achieved / HBM_PEAK, "traffic": traffic,
+        "avg_launch_us": avg_s * 1e6, "algorithmic_bytes_per_obs": bytes_per_obs,
+        "whole_iteration_frac": (run_bytes / elapsed) / (HBM_PEAK * world),
+        "kernels_ms_per_launch": {k: (v[0] / max(1, v[1])) for k, v in kern.items()},
+    }
+
+    out = {
+        "metric": "LM iters/sec + residuals/sec, 8-frame KITTI window, 50k pts, 5x5 patch",
+        "value": value, "unit": "LM iters/s (50k-point windows; x N under weak scaling)",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(1, iters_done),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "configs[1]: %d-frame window, %d points/GPU, %dx%d patch, single level, dense visibility"
+                               % (prob.n_frames, prob.n_points, 2 * prob.radius + 1, 2 * prob.radius + 1),
+                   "image": "%dx%d u8" % (cols, rows), "observations": int(n_obs_global), "huber": prob.huber,
+                   "parallelism": "points sharded x%d, cameras+frames replicated, RCCL all-reduce of the reduced camera system" % world},
+        "iters_per_sec": iters_per_sec, "residuals_per_sec": residuals_per_sec,
+        "lm": {"iterations": iters_done, "successful": res["num_successful_steps"] - 1, "jacobian_passes": n_jac,
+               "cost_passes": n_cost, "resolve_passes": n_res, "initial_cost": res["initial_cost"],
+               "final_cost": res["final_cost"], "message": res["message"]},
+        "roofline": roofline,
+        "gen_seconds": t_gen,
+    }
+
+    # ---- CPU baseline: the oracle ("restated Ceres-equivalent CPU path") on a bounded sample, rank 0, N = 1 ----
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle
+        n_cpu = min(args.cpu_points, prob.n_points)
+        sub = prob.shard(0, 1)
+        hi = int(np.searchsorted(prob.obs_point, n_cpu, side="left"))
+        sub.xyz, sub.desc = prob.xyz[:n_cpu].copy(), prob.desc[:n_cpu]
+        sub.obs_point, sub.obs_slot = prob.obs_point[:hi], prob.obs_slot[:hi]
+        threads = min(os.cpu_count() or 1, 4)            # reference default: min(omp_get_max_threads(), 4)
+        o = oracle.default_options(max_num_iterations=args.cpu_steps, function_tolerance=0.0, gradient_tolerance=0.0,
+                                   parameter_tolerance=0.0, num_threads=threads, use_autodiff=1)
+        tc = time.perf_counter()
+        cres = oracle.solve(sub, o)
+        cpu_s = time.perf_counter() - tc
+        it_cpu = len(cres["iterations"]) - 1
+        frac = hi / float(n_obs_local)
+        cpu_iters_per_sec_full = (it_cpu / cpu_s) * frac   # time scales linearly with the observation count
+        out["cpu_baseline"] = {
+            "value": cpu_iters_per_sec_full, "unit": "LM iters/s (extrapolated to the full 50k-point window)",
+            "cores": threads, "kind": "port",
+            "sample": "%d of %d points (%d observations), %d LM iterations, dual-number autodiff + materialised Jacobian "
+                      "+ Schur, %d OpenMP threads, %.1f s wall" % (n_cpu, prob.n_points, hi, it_cpu, threads, cpu_s),
+            "sample_iters_per_sec": it_cpu / cpu_s,
+            "residuals_per_sec": hi * P * (cres["num_jacobian_passes"] + cres["num_cost_passes"]) / cpu_s,
+        }
+        out["speedup_vs_cpu_baseline"] = iters_per_sec / cpu_iters_per_sec_full
+
+    if rank == 0:
+        print(json.dumps(out))
+    eng.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

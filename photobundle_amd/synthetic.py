@@ -110,13 +110,15 @@ def project(K, T_cw, X):
 
 
 def make_window(n_frames=8, n_points=50000, radius=2, size=KITTI_SIZE, K=KITTI_K, visibility="dense",
-                huber=0.0, gaussian=False, depth_noise=0.01, rot_deg=0.1, trans=0.02, seed_offset=0):
+                huber=0.0, gaussian=False, depth_noise=0.01, rot_deg=0.1, trans=0.02, seed_offset=0,
+                point_seed_offset=0):
     """Builds a WindowProblem of the named shape.
 
     visibility = "dense": every point is born in frame 0 and observed in every frame (sites whose ground-truth
                           projection leaves the margin in any frame are not drawn) -> n_obs = n_frames * n_points.
                  "causal": points are born uniformly over frames 0..n_frames-3 and observed from birth on while
                           inside the margin (mirrors the selection rule of reference photobundle.cc:789).
+    point_seed_offset only changes the drawn points (multi-GPU shards share frames and cameras).
     """
     rows, cols = size
     tex = Texture(seed=SEED_TEXTURE + seed_offset)
@@ -130,7 +132,7 @@ def make_window(n_frames=8, n_points=50000, radius=2, size=KITTI_SIZE, K=KITTI_K
     images = np.stack(images)
     planes = np.stack([imgproc.planes_from_u8(im) for im in images])
 
-    rng = np.random.default_rng(SEED_POINTS + seed_offset)
+    rng = np.random.default_rng(SEED_POINTS + seed_offset + 1000 * point_seed_offset)
     margin = radius + 2
     fx, fy, cx, cy = K
     T_cw_gt = [np.linalg.inv(T) for T in T_gt]
