@@ -57,7 +57,7 @@ typedef struct pba_config {
   double fx, fy, cx, cy;     /* pinhole intrinsics */
   double huber;              /* Options::robustThreshold; <= 0 disables the loss (photobundle.cc:797-798) */
   int32_t device;            /* HIP device ordinal */
-  int32_t flags;             /* reserved, 0 */
+  int32_t flags;             /* bit 0: keep a copy of the reduced system for pba_get_reduced_system (test hook) */
 } pba_config;
 
 /* ceres::Solver::Options as configured by GetSolverOptions (photobundle.cc:738-761) + the Ceres defaults

@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -31,6 +32,8 @@ struct pba_engine {
   // problem
   int n_points = 0, n_obs = 0, n_frames = 0, fixed_slot = -1, n_free = 0;
   bool have_problem = false, have_cams = false, have_lin = false;
+  bool lin_valid[2] = {false, false};   // rec[k] holds a Jacobian pass of point k
+  bool speculate = true;            // candidate pass = Jacobian pass (skips the re-linearisation after an accept)
   int cur = 0;                      // ping-pong index of the current point
   double* d_xyz[2] = {nullptr, nullptr};
   double* d_cams[2] = {nullptr, nullptr};
@@ -40,11 +43,13 @@ struct pba_engine {
   int32_t* d_obs_point = nullptr;
   uint8_t* d_obs_slot = nullptr;
   int32_t* d_pt_begin = nullptr;
-  int32_t* d_tile_obs = nullptr;
+  int4* d_tile_info = nullptr;
+  uint8_t* d_obs_l0 = nullptr;
+  uint8_t* d_obs_cnt = nullptr;
   int n_tiles = 0;
   // linearisation + solve scratch
   int64_t rec_stride = 0;
-  double* d_rec = nullptr;          // [6][rec_stride]
+  double* d_rec[2] = {nullptr, nullptr};   // [6][rec_stride] per point parity
   double* d_sp = nullptr;           // [n_points][3]
   double* d_ptrec = nullptr;        // [n_points][12]
   double* d_sc = nullptr;           // [6 * kMaxFrames]
@@ -54,14 +59,17 @@ struct pba_engine {
   double* d_packed = nullptr;       // [part_stride]
   double* d_S = nullptr;            // [n*n] debug copy
   double* d_rhs = nullptr;          // [n]
-  double* d_block_cost[2] = {nullptr, nullptr};   // [sample_grid] (0: Jacobian pass, 1: cost pass)
+  double* d_block_cost[2] = {nullptr, nullptr};   // [sample_grid] block costs of the last pass at point parity k
   int32_t* d_block_fail[2] = {nullptr, nullptr};
   double* d_bs_out = nullptr;       // [backsub_grid][3]
   double* d_scal = nullptr;         // [kNumScal]
-  double* h_scal = nullptr;         // pinned
+  double* h_scal = nullptr;         // pinned + mapped: [kNumScal] doubles then one u64 sequence number
+  double* h_scal_dev = nullptr;     // device view of h_scal
+  unsigned long long seq = 0;
+  int64_t jac_passes = 0, cost_passes = 0;
   int schur_grid = 0, sample_grid = 0, backsub_grid = 0, sample_waves = 4;
-  int n_tasks = 0, part_stride = 0;
-  static constexpr int kChunks = 8;
+  int n_pairs = 0, part_stride = 0;
+  static constexpr int kChunks = 32;
 
   Comm comm;
 
@@ -121,24 +129,34 @@ size_t schur_smem_bytes() {
   return sizeof(double) * (kTile * kObsStride + kTile * 9 + kTile) + kTile * kMaxFrames;
 }
 
-template <int NT>
-void launch_schur_nt(pba_engine* e, const SchurParams& sp) {
-  hipLaunchKernelGGL((k_schur<NT>), dim3(e->schur_grid), dim3(kTile), schur_smem_bytes(), e->stream, sp);
+template <int NF>
+void launch_solve_wave(pba_engine* e, const SolveParams& so) {
+  hipLaunchKernelGGL((k_solve_wave<NF>), dim3(1), dim3(256), 0, e->stream, so);
 }
-void launch_schur(pba_engine* e, const SchurParams& sp) {
-  const int nt = (e->n_tasks + kTile - 1) / kTile;
-  switch (nt) {
-    case 1: launch_schur_nt<1>(e, sp); break;
-    case 2: launch_schur_nt<2>(e, sp); break;
-    case 3: launch_schur_nt<3>(e, sp); break;
-    case 4: launch_schur_nt<4>(e, sp); break;
-    case 5: launch_schur_nt<5>(e, sp); break;
-    case 6: launch_schur_nt<6>(e, sp); break;
-    default: launch_schur_nt<7>(e, sp); break;
+void launch_solve(pba_engine* e, const SolveParams& so, int n) {
+  switch (e->n_free) {
+    case 1: launch_solve_wave<1>(e, so); return;
+    case 2: launch_solve_wave<2>(e, so); return;
+    case 3: launch_solve_wave<3>(e, so); return;
+    case 4: launch_solve_wave<4>(e, so); return;
+    case 5: launch_solve_wave<5>(e, so); return;
+    case 6: launch_solve_wave<6>(e, so); return;
+    case 7: launch_solve_wave<7>(e, so); return;
+    case 8: launch_solve_wave<8>(e, so); return;
+    case 9: launch_solve_wave<9>(e, so); return;
+    case 10: launch_solve_wave<10>(e, so); return;
+    default: break;
   }
+  const size_t solve_smem = sizeof(double) * ((size_t)n * (n + 1) + 5 * n);
+  hipLaunchKernelGGL(k_solve_generic, dim3(1), dim3(kSolveThreads), solve_smem, e->stream, so);
 }
 
-SampleParams make_sample_params(pba_engine* e, int which_point, int which_out) {
+void launch_schur(pba_engine* e, const SchurParams& sp) {
+  hipLaunchKernelGGL(k_schur, dim3(e->schur_grid), dim3(kTile), schur_smem_bytes(), e->stream, sp);
+}
+
+SampleParams make_sample_params(pba_engine* e, int which_point) {
+  const int which_out = which_point;
   SampleParams sp{};
   sp.frames = e->d_frames;
   sp.geom = e->d_geom[which_point];
@@ -147,7 +165,7 @@ SampleParams make_sample_params(pba_engine* e, int which_point, int which_out) {
   sp.w2 = e->d_w2;
   sp.obs_point = e->d_obs_point;
   sp.obs_slot = e->d_obs_slot;
-  sp.rec = e->d_rec;
+  sp.rec = e->d_rec[which_point];
   sp.block_cost = e->d_block_cost[which_out];
   sp.block_fail = e->d_block_fail[which_out];
   sp.rec_stride = e->rec_stride;
@@ -241,7 +259,10 @@ int pba_create(const pba_config* cfg, pba_engine** out) {
   if ((rc = dev_alloc(e, &e->d_S, (size_t)36 * kMaxFrames * kMaxFrames))) return bail(rc);
   if ((rc = dev_alloc(e, &e->d_rhs, (size_t)6 * kMaxFrames))) return bail(rc);
   if (hipMemsetAsync(e->d_scal, 0, kNumScal * sizeof(double), e->stream) != hipSuccess) return bail(PBA_ERR_HIP);
-  if (hipHostMalloc(reinterpret_cast<void**>(&e->h_scal), kNumScal * sizeof(double)) != hipSuccess) return bail(PBA_ERR_HIP);
+  if (hipHostMalloc(reinterpret_cast<void**>(&e->h_scal), (kNumScal + 1) * sizeof(double), hipHostMallocMapped) != hipSuccess) return bail(PBA_ERR_HIP);
+  std::memset(e->h_scal, 0, (kNumScal + 1) * sizeof(double));
+  if (hipHostGetDevicePointer(reinterpret_cast<void**>(&e->h_scal_dev), e->h_scal, 0) != hipSuccess) return bail(PBA_ERR_HIP);
+  if (const char* sv = getenv("PBA_SPECULATE")) e->speculate = atoi(sv) != 0;
   for (int k = 0; k < 6; ++k)
     if (hipEventCreate(&e->ev[k]) != hipSuccess) return bail(PBA_ERR_HIP);
   e->sample_waves = sample_waves_for_radius(cfg->radius);
@@ -258,7 +279,7 @@ void pba_destroy(pba_engine* e) {
   dev_free(&e->d_frames); dev_free(&e->d_img_stage);
   for (int k = 0; k < 2; ++k) { dev_free(&e->d_xyz[k]); dev_free(&e->d_cams[k]); dev_free(&e->d_geom[k]); dev_free(&e->d_block_cost[k]); dev_free(&e->d_block_fail[k]); }
   dev_free(&e->d_desc); dev_free(&e->d_w2); dev_free(&e->d_obs_point); dev_free(&e->d_obs_slot); dev_free(&e->d_pt_begin);
-  dev_free(&e->d_tile_obs); dev_free(&e->d_rec); dev_free(&e->d_sp); dev_free(&e->d_ptrec); dev_free(&e->d_sc);
+  dev_free(&e->d_tile_info); dev_free(&e->d_obs_l0); dev_free(&e->d_obs_cnt); dev_free(&e->d_rec[0]); dev_free(&e->d_rec[1]); dev_free(&e->d_sp); dev_free(&e->d_ptrec); dev_free(&e->d_sc);
   dev_free(&e->d_delta_c); dev_free(&e->d_partial); dev_free(&e->d_red); dev_free(&e->d_packed); dev_free(&e->d_S);
   dev_free(&e->d_rhs); dev_free(&e->d_bs_out); dev_free(&e->d_scal);
   if (e->h_scal) (void)hipHostFree(e->h_scal);
@@ -327,6 +348,17 @@ int pba_set_problem(pba_engine* e, int32_t n_points, const double* xyz, const do
     tiles.push_back(n_obs);
   }
   e->n_tiles = (int)tiles.size() - 1;
+  std::vector<int4> tinfo(e->n_tiles);
+  std::vector<uint8_t> obs_l0(n_obs), obs_cnt(n_obs);
+  for (int t = 0; t < e->n_tiles; ++t) {
+    const int o0 = tiles[t], o1 = tiles[t + 1];
+    tinfo[t] = make_int4(o0, o1 - o0, obs_point[o0], obs_point[o1 - 1] - obs_point[o0] + 1);
+    for (int o = o0; o < o1; ++o) {
+      const int p = obs_point[o];
+      obs_l0[o] = (uint8_t)(pt_begin[p] - o0);
+      obs_cnt[o] = (uint8_t)(pt_begin[p + 1] - pt_begin[p]);
+    }
+  }
   e->n_points = n_points;
   e->n_obs = n_obs;
   e->ctr.n_obs = n_obs; e->ctr.n_points = n_points;
@@ -343,9 +375,11 @@ int pba_set_problem(pba_engine* e, int32_t n_points, const double* xyz, const do
   if ((rc = dev_alloc(e, &e->d_obs_point, (size_t)n_obs))) return rc;
   if ((rc = dev_alloc(e, &e->d_obs_slot, (size_t)n_obs))) return rc;
   if ((rc = dev_alloc(e, &e->d_pt_begin, (size_t)n_points + 1))) return rc;
-  if ((rc = dev_alloc(e, &e->d_tile_obs, tiles.size()))) return rc;
+  if ((rc = dev_alloc(e, &e->d_tile_info, tinfo.size()))) return rc;
+  if ((rc = dev_alloc(e, &e->d_obs_l0, (size_t)n_obs))) return rc;
+  if ((rc = dev_alloc(e, &e->d_obs_cnt, (size_t)n_obs))) return rc;
   e->rec_stride = ((int64_t)n_obs + 255) / 256 * 256;
-  if ((rc = dev_alloc(e, &e->d_rec, (size_t)6 * e->rec_stride))) return rc;
+  for (int k = 0; k < 2; ++k) if ((rc = dev_alloc(e, &e->d_rec[k], (size_t)6 * e->rec_stride))) return rc;
   if ((rc = dev_alloc(e, &e->d_sp, (size_t)3 * n_points))) return rc;
   if ((rc = dev_alloc(e, &e->d_ptrec, (size_t)12 * n_points))) return rc;
   e->sample_grid = (n_obs + e->sample_waves * 64 - 1) / (e->sample_waves * 64);
@@ -363,11 +397,14 @@ int pba_set_problem(pba_engine* e, int32_t n_points, const double* xyz, const do
   HIP_TRY(e, hipMemcpyAsync(e->d_obs_point, obs_point, sizeof(int32_t) * n_obs, hipMemcpyHostToDevice, e->stream));
   HIP_TRY(e, hipMemcpyAsync(e->d_obs_slot, slot8.data(), n_obs, hipMemcpyHostToDevice, e->stream));
   HIP_TRY(e, hipMemcpyAsync(e->d_pt_begin, pt_begin.data(), sizeof(int32_t) * (n_points + 1), hipMemcpyHostToDevice, e->stream));
-  HIP_TRY(e, hipMemcpyAsync(e->d_tile_obs, tiles.data(), sizeof(int32_t) * tiles.size(), hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(e, hipMemcpyAsync(e->d_tile_info, tinfo.data(), sizeof(int4) * tinfo.size(), hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(e, hipMemcpyAsync(e->d_obs_l0, obs_l0.data(), n_obs, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(e, hipMemcpyAsync(e->d_obs_cnt, obs_cnt.data(), n_obs, hipMemcpyHostToDevice, e->stream));
   HIP_TRY(e, hipStreamSynchronize(e->stream));
   e->cur = 0;
   e->have_problem = true;
   e->have_lin = false;
+  e->lin_valid[0] = e->lin_valid[1] = false;
   return PBA_OK;
 }
 
@@ -377,8 +414,9 @@ int pba_set_cameras(pba_engine* e, const double* cams6, int32_t n_frames, int32_
   e->n_frames = n_frames;
   e->fixed_slot = fixed_slot < 0 ? -1 : fixed_slot;
   e->n_free = n_frames - (e->fixed_slot >= 0 ? 1 : 0);
-  e->n_tasks = 6 * (e->n_free * (e->n_free + 1) / 2);
-  e->part_stride = 6 * e->n_tasks + 3 * 6 * e->n_free + 3;
+  e->n_pairs = e->n_free * (e->n_free + 1) / 2;
+  e->part_stride = 36 * e->n_pairs + 3 * 6 * e->n_free + 3;
+  if (e->n_pairs > kTile) return fail(e, PBA_ERR_INVALID, "too many free cameras for the Schur tile (%d pairs)", e->n_pairs);
   int rc;
   if ((rc = dev_alloc(e, &e->d_partial, (size_t)std::max(1, 256 * 3) * e->part_stride))) return rc;
   if ((rc = dev_alloc(e, &e->d_red, (size_t)pba_engine::kChunks * e->part_stride))) return rc;
@@ -389,12 +427,13 @@ int pba_set_cameras(pba_engine* e, const double* cams6, int32_t n_frames, int32_
   HIP_TRY(e, hipStreamSynchronize(e->stream));
   e->have_cams = true;
   e->have_lin = false;
+  e->lin_valid[0] = e->lin_valid[1] = false;
   return PBA_OK;
 }
 
 int pba_get_state(pba_engine* e, double* cams6, double* xyz) {
   if (!e) return PBA_ERR_INVALID;
-  if (!e->have_problem || !e->have_cams) return fail(e, PBA_ERR_STATE, "pba_get_state before set_problem/set_cameras");
+  if (!e->have_problem || !e->have_cams) return fail(e, PBA_ERR_STATE, "call order violated: pba_get_state before set_problem/set_cameras");
   HIP_TRY(e, hipSetDevice(e->cfg.device));
   if (cams6) HIP_TRY(e, hipMemcpyAsync(cams6, e->d_cams[e->cur], sizeof(double) * 6 * e->n_frames, hipMemcpyDeviceToHost, e->stream));
   if (xyz) HIP_TRY(e, hipMemcpyAsync(xyz, e->d_xyz[e->cur], sizeof(double) * 3 * e->n_points, hipMemcpyDeviceToHost, e->stream));
@@ -404,17 +443,21 @@ int pba_get_state(pba_engine* e, double* cams6, double* xyz) {
 
 int pba_linearize(pba_engine* e, double* cost) {
   if (!e) return PBA_ERR_INVALID;
-  if (!e->have_problem || !e->have_cams) return fail(e, PBA_ERR_STATE, "pba_linearize before set_problem/set_cameras");
+  if (!e->have_problem || !e->have_cams) return fail(e, PBA_ERR_STATE, "call order violated: pba_linearize before set_problem/set_cameras");
   HIP_TRY(e, hipSetDevice(e->cfg.device));
-  SampleParams sp = make_sample_params(e, e->cur, 0);
-  ev_begin(e, 0);
-  launch_sample<true>(e, sp);
-  ev_end(e, 0);
-  HIP_TRY(e, hipGetLastError());
+  if (!e->lin_valid[e->cur]) {
+    SampleParams sp = make_sample_params(e, e->cur);
+    ev_begin(e, 0);
+    launch_sample<true>(e, sp);
+    ev_end(e, 0);
+    HIP_TRY(e, hipGetLastError());
+    e->lin_valid[e->cur] = true;
+    e->jac_passes++;
+  }
   e->have_lin = true;
   if (cost) {
     std::vector<double> bc(e->sample_grid);
-    HIP_TRY(e, hipMemcpyAsync(bc.data(), e->d_block_cost[0], sizeof(double) * e->sample_grid, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(bc.data(), e->d_block_cost[e->cur], sizeof(double) * e->sample_grid, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     ev_collect(e);
     double c = 0.0;
@@ -435,66 +478,91 @@ int pba_step(pba_engine* e, double radius, int32_t init_scale, const pba_solver_
 int pba_internal_step(pba_engine* e, double radius, int32_t init_scale, const pba_solver_options* o, pba_step_info* out,
                       int grad_only) {
   if (!e || !o || !out || !(radius > 0.0)) return PBA_ERR_INVALID;
-  if (!e->have_lin) return fail(e, PBA_ERR_STATE, "pba_step before pba_linearize");
+  if (!e->have_lin) return fail(e, PBA_ERR_STATE, "call order violated: pba_step before pba_linearize");
   HIP_TRY(e, hipSetDevice(e->cfg.device));
   const int cur = e->cur, cand = 1 - e->cur;
   const int n = 6 * e->n_free;
+  const bool multi = e->comm.world > 1;
 
   SchurParams sc{};
-  sc.xyz = e->d_xyz[cur]; sc.geom = e->d_geom[cur]; sc.rec = e->d_rec; sc.obs_point = e->d_obs_point;
-  sc.obs_slot = e->d_obs_slot; sc.tile_obs = e->d_tile_obs; sc.pt_begin = e->d_pt_begin; sc.sp = e->d_sp;
+  sc.xyz = e->d_xyz[cur]; sc.geom = e->d_geom[cur]; sc.rec = e->d_rec[cur]; sc.obs_point = e->d_obs_point;
+  sc.obs_slot = e->d_obs_slot; sc.tile_info = e->d_tile_info; sc.obs_l0 = e->d_obs_l0; sc.obs_cnt = e->d_obs_cnt; sc.sp = e->d_sp;
   sc.ptrec = e->d_ptrec; sc.partial = e->d_partial; sc.rec_stride = e->rec_stride; sc.n_tiles = e->n_tiles;
-  sc.n_free = e->n_free; sc.n_tasks = e->n_tasks; sc.part_stride = e->part_stride; sc.init_scale = init_scale;
-  sc.jacobi = o->jacobi_scaling; sc.fx = e->cfg.fx; sc.fy = e->cfg.fy; sc.radius = radius;
+  sc.n_free = e->n_free; sc.n_pairs = e->n_pairs; sc.part_stride = e->part_stride; sc.init_scale = init_scale;
+  sc.jacobi = o->jacobi_scaling; sc.fx = e->cfg.fx; sc.fy = e->cfg.fy; sc.radius = radius; sc.inv_radius = 1.0 / radius;
   sc.min_diag = o->min_lm_diagonal; sc.max_diag = o->max_lm_diagonal;
   ev_begin(e, 2);
   launch_schur(e, sc);
   ev_end(e, 2);
-  const int chunks = pba_engine::kChunks;
-  hipLaunchKernelGGL(k_reduce_partials, dim3((e->part_stride + 63) / 64, chunks), dim3(64), 0, e->stream, e->d_partial,
-                     e->schur_grid, e->part_stride, chunks, e->d_red);
-  hipLaunchKernelGGL(k_pack_reduced, dim3(std::min(64, (e->part_stride + 255) / 256)), dim3(256), 0, e->stream, e->d_red,
-                     e->part_stride, chunks, e->d_block_cost[0], e->d_block_fail[0], e->sample_grid, e->d_packed, e->d_scal);
+  hipLaunchKernelGGL(k_reduce_final, dim3((e->part_stride + 31) / 32 + 1), dim3(1024), 0, e->stream, e->d_partial,
+                     e->schur_grid, e->part_stride, e->d_block_cost[cur], e->d_block_fail[cur], e->sample_grid, e->d_packed,
+                     e->d_scal);
   HIP_TRY(e, hipGetLastError());
-  if (e->comm.world > 1) {
+  if (multi) {
     if (e->comm.allreduce_device(e->d_packed, (size_t)e->part_stride - 1, 0, e->stream))
       return fail(e, PBA_ERR_COMM, "allreduce(reduced system) failed: %s", e->comm.err.c_str());
   }
   SolveParams so{};
-  so.packed = e->d_packed; so.cams = e->d_cams[cur]; so.cams_cand = e->d_cams[cand]; so.delta_c = e->d_delta_c;
-  so.sc = e->d_sc; so.S_dbg = e->d_S; so.rhs_dbg = e->d_rhs; so.scal = e->d_scal; so.geom = e->d_geom[cur];
-  so.n_frames = e->n_frames; so.n_free = e->n_free; so.n_tasks = e->n_tasks; so.stride = e->part_stride;
+  so.packed = e->d_packed;
+  so.cams = e->d_cams[cur]; so.cams_cand = e->d_cams[cand]; so.delta_c = e->d_delta_c;
+  so.sc = e->d_sc; so.S_dbg = (e->cfg.flags & 1) ? e->d_S : nullptr; so.rhs_dbg = e->d_rhs; so.scal = e->d_scal; so.geom = e->d_geom[cur];
+  so.n_frames = e->n_frames; so.n_free = e->n_free; so.n_pairs = e->n_pairs; so.stride = e->part_stride;
   so.init_scale = init_scale; so.jacobi = o->jacobi_scaling; so.radius = radius; so.min_diag = o->min_lm_diagonal;
   so.max_diag = o->max_lm_diagonal;
-  const size_t solve_smem = sizeof(double) * ((size_t)n * n + 4 * n);
-  hipLaunchKernelGGL(k_solve, dim3(1), dim3(256), solve_smem, e->stream, so);
+  launch_solve(e, so, n);
+  const unsigned long long seq = ++e->seq;
+  unsigned long long* h_seq_dev = reinterpret_cast<unsigned long long*>(e->h_scal_dev + kNumScal);
   if (!grad_only) {
-  BacksubParams bs{};
-  bs.xyz = e->d_xyz[cur]; bs.xyz_cand = e->d_xyz[cand]; bs.geom = e->d_geom[cur]; bs.rec = e->d_rec;
-  bs.pt_begin = e->d_pt_begin; bs.obs_slot = e->d_obs_slot; bs.sp = e->d_sp; bs.ptrec = e->d_ptrec;
-  bs.delta_c = e->d_delta_c; bs.block_out = e->d_bs_out; bs.rec_stride = e->rec_stride; bs.n_points = e->n_points;
-  bs.fx = e->cfg.fx; bs.fy = e->cfg.fy;
-  hipLaunchKernelGGL(k_backsub, dim3(e->backsub_grid), dim3(256), 0, e->stream, bs);
-
-  // candidate point: geometry + cost pass
-  hipLaunchKernelGGL(k_cam_geom, dim3(1), dim3(64), 0, e->stream, e->d_cams[cand], e->d_geom[cand], e->n_frames, e->fixed_slot);
-  SampleParams sp = make_sample_params(e, cand, 1);
-  ev_begin(e, 1);
-  launch_sample<false>(e, sp);
-  ev_end(e, 1);
-  hipLaunchKernelGGL(k_finalize_step, dim3(1), dim3(256), 0, e->stream, e->d_bs_out, e->backsub_grid, e->d_block_cost[1],
-                     e->d_block_fail[1], e->sample_grid, e->d_scal);
+    BacksubParams bs{};
+    bs.xyz = e->d_xyz[cur]; bs.xyz_cand = e->d_xyz[cand]; bs.geom = e->d_geom[cur]; bs.rec = e->d_rec[cur];
+    bs.pt_begin = e->d_pt_begin; bs.obs_slot = e->d_obs_slot; bs.sp = e->d_sp; bs.ptrec = e->d_ptrec;
+    bs.delta_c = e->d_delta_c; bs.block_out = e->d_bs_out; bs.rec_stride = e->rec_stride; bs.n_points = e->n_points;
+    bs.fx = e->cfg.fx; bs.fy = e->cfg.fy;
+    bs.cams_cand = e->d_cams[cand]; bs.geom_cand = e->d_geom[cand]; bs.n_frames = e->n_frames; bs.fixed_slot = e->fixed_slot;
+    hipLaunchKernelGGL(k_backsub, dim3(e->backsub_grid), dim3(256), 0, e->stream, bs);
+    // candidate point: Jacobian pass when speculating on acceptance, else cost pass
+    SampleParams sp = make_sample_params(e, cand);
+    if (e->speculate) {
+      ev_begin(e, 0);
+      launch_sample<true>(e, sp);
+      ev_end(e, 0);
+      e->jac_passes++;
+    } else {
+      ev_begin(e, 1);
+      launch_sample<false>(e, sp);
+      ev_end(e, 1);
+      e->cost_passes++;
+    }
+    e->lin_valid[cand] = e->speculate;
+    hipLaunchKernelGGL(k_finalize_step, dim3(1), dim3(256), 0, e->stream, e->d_bs_out, e->backsub_grid, e->d_block_cost[cand],
+                       e->d_block_fail[cand], e->sample_grid, e->d_scal, multi ? nullptr : e->h_scal_dev, h_seq_dev, seq);
   }
   HIP_TRY(e, hipGetLastError());
-  if (e->comm.world > 1) {
+  if (multi) {
     if ((!grad_only && e->comm.allreduce_device(e->d_scal + kCandCost, kSumBCount, 0, e->stream)) ||
         e->comm.allreduce_device(e->d_scal + kGmaxPts, kMaxCount, 1, e->stream))
       return fail(e, PBA_ERR_COMM, "allreduce(step scalars) failed: %s", e->comm.err.c_str());
   }
-  HIP_TRY(e, hipMemcpyAsync(e->h_scal, e->d_scal, sizeof(double) * kNumScal, hipMemcpyDeviceToHost, e->stream));
-  HIP_TRY(e, hipStreamSynchronize(e->stream));
-  ev_collect(e);
-  const double* s = e->h_scal;
+  if (multi || grad_only) {
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, e->stream, e->d_scal, e->h_scal_dev, h_seq_dev, seq);
+    HIP_TRY(e, hipGetLastError());
+  }
+  // wait for the device to publish this step's scalar block (host-mapped memory, no driver round trip)
+  {
+    volatile unsigned long long* h_seq = reinterpret_cast<volatile unsigned long long*>(e->h_scal + kNumScal);
+    unsigned long spins = 0;
+    while (*h_seq != seq) {
+      if ((++spins & 0x3fff) == 0) {
+        const hipError_t q = hipStreamQuery(e->stream);
+        if (q != hipSuccess && q != hipErrorNotReady) return fail(e, PBA_ERR_HIP, "stream error while waiting: %s", hipGetErrorString(q));
+        if (q == hipSuccess && *h_seq != seq) return fail(e, PBA_ERR_HIP, "step finished without publishing its scalars");
+      }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  }
+  if (e->profile) { HIP_TRY(e, hipStreamSynchronize(e->stream)); ev_collect(e); }
+  double s[kNumScal];
+  for (int k = 0; k < kNumScal; ++k) s[k] = reinterpret_cast<volatile double*>(e->h_scal)[k];
   out->cost = s[kCostLin];
   out->gradient_max_norm = std::max(s[kGmaxPts], s[kGmaxCams]);
   out->gradient_norm = std::sqrt(s[kGnorm2Pts] + s[kGnorm2Cams]);
@@ -510,14 +578,16 @@ int pba_internal_step(pba_engine* e, double radius, int32_t init_scale, const pb
 
 int pba_accept(pba_engine* e) {
   if (!e) return PBA_ERR_INVALID;
-  if (!e->have_lin) return fail(e, PBA_ERR_STATE, "pba_accept before pba_step");
+  if (!e->have_lin) return fail(e, PBA_ERR_STATE, "call order violated: pba_accept before pba_step");
+  e->lin_valid[e->cur] = false;
   e->cur = 1 - e->cur;
-  e->have_lin = false;
+  e->have_lin = e->lin_valid[e->cur];
   return PBA_OK;
 }
 
 int pba_get_reduced_system(pba_engine* e, double* S, double* rhs, int32_t* n_out) {
   if (!e || !n_out) return PBA_ERR_INVALID;
+  if (!(e->cfg.flags & 1)) return fail(e, PBA_ERR_STATE, "call order violated: pba_get_reduced_system needs pba_config.flags bit 0 (keep reduced system)");
   HIP_TRY(e, hipSetDevice(e->cfg.device));
   const int n = 6 * e->n_free;
   *n_out = n;
@@ -532,7 +602,7 @@ int pba_get_obs_records(pba_engine* e, double* rec6) {
   if (!e->have_problem) return fail(e, PBA_ERR_STATE, "no problem");
   HIP_TRY(e, hipSetDevice(e->cfg.device));
   std::vector<double> tmp((size_t)6 * e->rec_stride);
-  HIP_TRY(e, hipMemcpyAsync(tmp.data(), e->d_rec, sizeof(double) * tmp.size(), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(e, hipMemcpyAsync(tmp.data(), e->d_rec[e->cur], sizeof(double) * tmp.size(), hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(e, hipStreamSynchronize(e->stream));
   for (int o = 0; o < e->n_obs; ++o)
     for (int k = 0; k < 6; ++k) rec6[(size_t)o * 6 + k] = tmp[(size_t)k * e->rec_stride + o];
@@ -578,6 +648,12 @@ int pba_internal_world(const pba_engine* e) { return e->comm.world; }
 int pba_internal_rank(const pba_engine* e) { return e->comm.rank; }
 int64_t pba_internal_local_blocks(const pba_engine* e) { return e->n_obs; }
 int pba_internal_patch_len(const pba_engine* e) { return (2 * e->cfg.radius + 1) * (2 * e->cfg.radius + 1); }
+void pba_internal_set_speculate(pba_engine* e, int on) {
+  static const bool forced_off = [] { const char* sv = getenv("PBA_SPECULATE"); return sv && atoi(sv) == 0; }();
+  e->speculate = on != 0 && !forced_off;
+}
+void pba_internal_pass_counts(const pba_engine* e, int64_t* jac, int64_t* cost) { *jac = e->jac_passes; *cost = e->cost_passes; }
+void pba_internal_reset_pass_counts(pba_engine* e) { e->jac_passes = 0; e->cost_passes = 0; }
 int pba_internal_allreduce_host(pba_engine* e, double* v, int n, int op) {
   if (e->comm.world <= 1) return 0;
   return e->comm.allreduce_host(v, n, op);

@@ -11,4 +11,8 @@ int pba_internal_rank(const pba_engine* e);
 int64_t pba_internal_local_blocks(const pba_engine* e);
 int pba_internal_patch_len(const pba_engine* e);
 int pba_internal_allreduce_host(pba_engine* e, double* v, int n, int op);
+// candidate pass = Jacobian pass (speculative linearisation) on/off
+void pba_internal_set_speculate(pba_engine* e, int on);
+void pba_internal_pass_counts(const pba_engine* e, int64_t* jac, int64_t* cost);
+void pba_internal_reset_pass_counts(pba_engine* e);
 }

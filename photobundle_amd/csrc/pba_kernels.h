@@ -46,12 +46,26 @@ __global__ void k_unpack_frame(const uint32_t* __restrict__ tex, float* I, float
   Gy[i] = 0.5f * tex_gy2(t);
 }
 
+// fp64 reciprocal / reciprocal square root from the hardware estimate + two Newton steps (~1 ulp): the IEEE division
+// and sqrt sequences are ~10x longer and sit on latency-critical paths of the solve kernels.  Not used where the
+// reference's rounding matters (pixel coordinates).
+__device__ __forceinline__ double fast_rcp(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  y = fma(fma(-x, y, 1.0), y, y);
+  y = fma(fma(-x, y, 1.0), y, y);
+  return y;
+}
+__device__ __forceinline__ double fast_rsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * fma(-0.5 * x * y, y, 1.5);
+  y = y * fma(-0.5 * x * y, y, 1.5);
+  return y;
+}
+
 // =====================================================================================================
 // camera geometry
 // =====================================================================================================
-__global__ void k_cam_geom(const double* __restrict__ cams, CamGeom* __restrict__ geom, int n_frames, int fixed_slot) {
-  const int c = threadIdx.x;
-  if (c >= n_frames) return;
+__device__ inline void cam_geom_one(const double* __restrict__ cams, CamGeom* __restrict__ geom, int c, int fixed_slot) {
   CamGeom g;
   const double* p = cams + 6 * c;
   for (int k = 0; k < 3; ++k) { g.aa[k] = p[k]; g.t[k] = p[3 + k]; }
@@ -105,6 +119,11 @@ __global__ void k_cam_geom(const double* __restrict__ cams, CamGeom* __restrict_
   geom[c] = g;
 }
 
+__global__ void k_cam_geom(const double* __restrict__ cams, CamGeom* __restrict__ geom, int n_frames, int fixed_slot) {
+  const int c = threadIdx.x;
+  if (c < n_frames) cam_geom_one(cams, geom, c, fixed_slot);
+}
+
 // xw = R(aa) X + t in the operation order of ceres::AngleAxisRotatePoint, then Calibration::project.
 // Contraction is off so that (u, v) round exactly like the (FMA-free) reference build.
 __device__ __forceinline__ void transform_point(const CamGeom& g, const double X[3], double xw[3]) {
@@ -138,7 +157,7 @@ __device__ __forceinline__ void project_point(const double xw[3], double fx, dou
 // Analytic 2x6 / 2x3 Jacobians of (u, v) w.r.t. camera [w, t] and point.
 __device__ __forceinline__ void projection_jacobians(const CamGeom& g, const double X[3], const double xw[3],
                                                      double fx, double fy, double Ac[2][6], double Ap[2][3]) {
-  const double iz = 1.0 / xw[2];
+  const double iz = fast_rcp(xw[2]);
   const double ju0 = fx * iz, ju2 = -fx * xw[0] * iz * iz;
   const double jv1 = fy * iz, jv2 = -fy * xw[1] * iz * iz;
 #pragma unroll
@@ -272,15 +291,25 @@ __global__ __launch_bounds__(WAVES * 64) void k_sample(SampleParams p) {
   __syncthreads();
 
   // ---- phase 2: cooperative footprint staging global -> LDS ----------------------------------------------
-#pragma unroll 4
-  for (int n = 0; n < FF; ++n) {
-    const int g = n * 64 + lane;
-    const int o = g / FF;
-    const int t = g - o * FF;
-    const int base = s_base[wave][o];
-    uint32_t tx = 0;
-    if (base >= 0) tx = p.frames[(size_t)base + (t / F) * p.cols + (t % F)];
-    s_tex[wave][t * LSTRIDE + o] = tx;
+  // all loads of a batch are issued before the first LDS store so that the L2 latency is paid once per batch
+  constexpr int BATCH = (FF <= 64) ? FF : (FF == 100 ? 25 : 36);
+  static_assert(FF % BATCH == 0, "footprint batches");
+#pragma unroll 1
+  for (int n0 = 0; n0 < FF; n0 += BATCH) {
+    uint32_t tx[BATCH];
+    int oo[BATCH], tt[BATCH];
+#pragma unroll
+    for (int k = 0; k < BATCH; ++k) {
+      const int g = (n0 + k) * 64 + lane;
+      const int o = g / FF;
+      const int t = g - o * FF;
+      const int base = s_base[wave][o];
+      oo[k] = o; tt[k] = t;
+      tx[k] = 0;
+      if (base >= 0) tx[k] = p.frames[(size_t)base + (t / F) * p.cols + (t % F)];
+    }
+#pragma unroll
+    for (int k = 0; k < BATCH; ++k) s_tex[wave][tt[k] * LSTRIDE + oo[k]] = tx[k];
   }
   __syncthreads();
 
@@ -393,8 +422,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_sample(SampleParams p) {
 
 // =====================================================================================================
 // Schur elimination of the points (SchurEliminator::Eliminate restated for the device)
-//   one lane per observation, whole points per tile, owner-computes accumulation (no atomics: the order of
-//   every floating-point sum is fixed by the tile/grid decomposition, so runs are reproducible)
+//   tiles of <= 128 observations holding whole points; one lane per observation for the per-block algebra,
+//   then every thread owns one full 6x6 block (camera pair a <= b) of the reduced matrix for a subset of the
+//   tile's points and accumulates it in registers across all tiles of the (persistent) workgroup.  No atomics:
+//   the order of every floating-point sum is fixed by the tile / grid decomposition, so runs are reproducible.
 // =====================================================================================================
 constexpr int kTile = 128;              // observations (= threads) per tile
 constexpr int kObsStride = 37;          // doubles per observation in LDS (36 + 1 pad)
@@ -405,20 +436,21 @@ struct SchurParams {
   const double* rec;            // SoA [6][rec_stride]
   const int32_t* obs_point;
   const uint8_t* obs_slot;
-  const int32_t* tile_obs;      // [n_tiles + 1] observation range of each tile (whole points)
-  const int32_t* pt_begin;      // [n_points + 1] CSR
+  const int4* tile_info;        // [n_tiles] {first observation, observations, first point, points} (whole points)
+  const uint8_t* obs_l0;        // [n_obs] lane (within its tile) of the first observation of the observation's point
+  const uint8_t* obs_cnt;       // [n_obs] number of observations of that point
   double* sp;                   // [n_points][3] Jacobi scale of the point columns (written when init_scale)
   double* ptrec;                // [n_points][12]: P (6, sym packed 00 01 02 11 12 22), g_p (3), D_p^2 (3)
   double* partial;              // [gridDim.x][part_stride]
   int64_t rec_stride;
   int32_t n_tiles;
   int32_t n_free;               // free cameras
-  int32_t n_tasks;              // 6 * n_free (n_free + 1) / 2
-  int32_t part_stride;          // n_tasks * 6 + 3 * 6 * n_free + 3
+  int32_t n_pairs;              // n_free (n_free + 1) / 2
+  int32_t part_stride;          // 36 n_pairs + 3 * 6 n_free + 3
   int32_t init_scale;
   int32_t jacobi;
   double fx, fy;
-  double radius, min_diag, max_diag;
+  double radius, inv_radius, min_diag, max_diag;
 };
 
 __device__ __forceinline__ int sym6(int i, int j) {  // packed upper triangle of a symmetric 6x6 (21 entries)
@@ -427,11 +459,9 @@ __device__ __forceinline__ int sym6(int i, int j) {  // packed upper triangle of
 }
 
 // Packed / partial layout (doubles), n = 6 * n_free:
-//   [0, 6 n_tasks)            T: task q = (pair(a<=b), row i) -> 6 entries of block (a, b), row i
+//   [0, 36 n_pairs)           T: pair (a <= b, enumerated row by row) -> row-major 6x6 block (a, b)
 //   [.., +n) rhs   [.., +n) g_c   [.., +n) diag(U)
 //   partial only: +0 gmax_pts, +1 gnorm2_pts, +2 schur_fail
-// NT = owner tasks per thread.
-template <int NT>
 __global__ __launch_bounds__(kTile) void k_schur(SchurParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* s_obs = reinterpret_cast<double*>(smem);                       // [kTile][kObsStride]
@@ -441,25 +471,19 @@ __global__ __launch_bounds__(kTile) void k_schur(SchurParams p) {
 
   const int tid = threadIdx.x;
   const int nf = p.n_free;
-
-  int ta[NT], tb[NT], ti[NT];
-#pragma unroll
-  for (int k = 0; k < NT; ++k) {
-    const int q = tid + k * kTile;
-    ta[k] = -1; tb[k] = 0; ti[k] = 0;
-    if (q < p.n_tasks) {
-      const int pair = q / 6;
-      ti[k] = q - pair * 6;
-      int a = 0, rem = pair;
-      while (rem >= nf - a) { rem -= nf - a; ++a; }   // pairs enumerated row by row: (a, a..nf-1)
-      ta[k] = a; tb[k] = a + rem;
-    }
+  const int n_groups = kTile / p.n_pairs;          // >= 1 (n_pairs <= 136 is clamped by kMaxFrames = 16 -> 120/136)
+  const int grp = tid / p.n_pairs;
+  const int pair = tid - grp * p.n_pairs;
+  const bool owner = grp < n_groups;
+  int pa = 0, pb = 0;
+  {
+    int a = 0, rem = pair;
+    while (rem >= nf - a) { rem -= nf - a; ++a; }   // pairs enumerated row by row: (a, a..nf-1)
+    pa = a; pb = a + rem;
   }
-  double acc[NT][6];
+  double acc[36];
 #pragma unroll
-  for (int k = 0; k < NT; ++k)
-#pragma unroll
-    for (int j = 0; j < 6; ++j) acc[k][j] = 0.0;
+  for (int k = 0; k < 36; ++k) acc[k] = 0.0;
   // vector owners: thread tid < 6 nf owns entry (camera tid / 6, row tid % 6) of rhs, g_c and diag(U)
   const int va = (tid < 6 * nf) ? tid / 6 : -1;
   const int vi = tid % 6;
@@ -467,11 +491,11 @@ __global__ __launch_bounds__(kTile) void k_schur(SchurParams p) {
   double gmax = 0.0, gn2 = 0.0;
   int fail = 0;
 
+  int4 ti_next = p.tile_info[min((int)blockIdx.x, p.n_tiles - 1)];
   for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
-    const int o0 = p.tile_obs[tile], o1 = p.tile_obs[tile + 1];
-    const int n_here = o1 - o0;
-    const int pt0 = p.obs_point[o0];
-    const int n_pts = p.obs_point[o1 - 1] - pt0 + 1;
+    const int4 ti = ti_next;
+    ti_next = p.tile_info[min(tile + (int)gridDim.x, p.n_tiles - 1)];   // prefetch the next tile's descriptor
+    const int o0 = ti.x, n_here = ti.y, pt0 = ti.z, n_pts = ti.w;
     const bool active = tid < n_here;
     const int obs = o0 + tid;
 
@@ -479,12 +503,15 @@ __global__ __launch_bounds__(kTile) void k_schur(SchurParams p) {
     __syncthreads();
 
     // ---- P1: per observation geometry and point-side contributions -----------------------------------
-    int pt = 0, fa = -1;
+    int pt = 0, fa = -1, l0 = 0, l1 = 0;
     double Ac[2][6], Ap[2][3], M[3] = {0, 0, 0}, b[2] = {0, 0};
     double MAp[2][3];
+    double s_pt[3] = {1.0, 1.0, 1.0};
     if (active) {
       pt = p.obs_point[obs];
       const int slot = p.obs_slot[obs];
+      l0 = p.obs_l0[obs]; l1 = l0 + p.obs_cnt[obs];
+      if (!p.init_scale) { s_pt[0] = p.sp[3 * (size_t)pt]; s_pt[1] = p.sp[3 * (size_t)pt + 1]; s_pt[2] = p.sp[3 * (size_t)pt + 2]; }
       const CamGeom& g = p.geom[slot];
       fa = g.free_index;
       const double X[3] = {p.xyz[3 * (size_t)pt], p.xyz[3 * (size_t)pt + 1], p.xyz[3 * (size_t)pt + 2]};
@@ -512,7 +539,6 @@ __global__ __launch_bounds__(kTile) void k_schur(SchurParams p) {
     // ---- P2: point totals, damping, effective inverse, per-observation Schur factors -------------------
     double rl[6] = {0, 0, 0, 0, 0, 0}, gcl[6] = {0, 0, 0, 0, 0, 0};
     if (active) {
-      const int l0 = p.pt_begin[pt] - o0, l1 = p.pt_begin[pt + 1] - o0;
       double V[6] = {0, 0, 0, 0, 0, 0}, gp[3] = {0, 0, 0};
       for (int l = l0; l < l1; ++l) {
         const double* vg = s_vg + l * 9;
@@ -530,28 +556,27 @@ __global__ __launch_bounds__(kTile) void k_schur(SchurParams p) {
         if (head) { p.sp[3 * (size_t)pt] = s[0]; p.sp[3 * (size_t)pt + 1] = s[1]; p.sp[3 * (size_t)pt + 2] = s[2]; }
       } else {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) s[k] = p.sp[3 * (size_t)pt + k];
+        for (int k = 0; k < 3; ++k) s[k] = s_pt[k];
       }
       double D2[3];
 #pragma unroll
-      for (int k = 0; k < 3; ++k) D2[k] = fmin(fmax(s[k] * s[k] * vd[k], p.min_diag), p.max_diag) / p.radius;
+      for (int k = 0; k < 3; ++k) D2[k] = fmin(fmax(s[k] * s[k] * vd[k], p.min_diag), p.max_diag) * p.inv_radius;
       // Vs = s V s + D^2 (LevenbergMarquardtStrategy diagonal on the Jacobi-scaled block), Cholesky inverse,
       // P = s Vs^-1 s  (the point block's inverse mapped back to unscaled coordinates)
       const double a00 = s[0] * s[0] * V[0] + D2[0], a01 = s[0] * s[1] * V[1], a02 = s[0] * s[2] * V[2];
       const double a11 = s[1] * s[1] * V[3] + D2[1], a12 = s[1] * s[2] * V[4], a22 = s[2] * s[2] * V[5] + D2[2];
       bool pd = a00 > 0.0;
-      const double l00 = sqrt(a00);
-      const double l10 = a01 / l00, l20 = a02 / l00;
+      const double i00 = fast_rsqrt(a00);
+      const double l10 = a01 * i00, l20 = a02 * i00;
       const double d1 = a11 - l10 * l10;
       pd = pd && d1 > 0.0;
-      const double l11 = sqrt(d1);
-      const double l21 = (a12 - l20 * l10) / l11;
+      const double i11 = fast_rsqrt(d1);
+      const double l21 = (a12 - l20 * l10) * i11;
       const double d2 = a22 - l20 * l20 - l21 * l21;
       pd = pd && d2 > 0.0;
-      const double l22 = sqrt(d2);
+      const double i22 = fast_rsqrt(d2);
       double Pm[6] = {0, 0, 0, 0, 0, 0};
       if (pd) {
-        const double i00 = 1.0 / l00, i11 = 1.0 / l11, i22 = 1.0 / l22;
         const double i10 = -l10 * i00 * i11;
         const double i21 = -l21 * i11 * i22;
         const double i20 = -(l20 * i00 + l21 * i10) * i22;
@@ -595,19 +620,23 @@ __global__ __launch_bounds__(kTile) void k_schur(SchurParams p) {
     }
     __syncthreads();
 
-    // ---- P3a: reduced-matrix owners: T[(a,i),(b,:)] -= Y_la[i,:] W_lb^T -----------------------------------
-    for (int q = 0; q < n_pts; ++q) {
-      const int8_t* lo = s_lane_of + q * kMaxFrames;
-#pragma unroll
-      for (int k = 0; k < NT; ++k) {
-        if (ta[k] < 0) continue;
-        const int la = lo[ta[k]], lb = lo[tb[k]];
+    // ---- P3a: block owners: T(a, b) -= Y_la W_lb^T over this group's points ----------------------------------
+    if (owner) {
+      for (int q = grp; q < n_pts; q += n_groups) {
+        const int8_t* lo = s_lane_of + q * kMaxFrames;
+        const int la = lo[pa], lb = lo[pb];
         if (la < 0 || lb < 0) continue;
-        const double* Y = s_obs + la * kObsStride + 18 + 3 * ti[k];
+        const double* Y = s_obs + la * kObsStride + 18;
         const double* Wb = s_obs + lb * kObsStride;
-        const double y0 = Y[0], y1 = Y[1], y2 = Y[2];
+        double wb[18];
 #pragma unroll
-        for (int j = 0; j < 6; ++j) acc[k][j] -= y0 * Wb[3 * j] + y1 * Wb[3 * j + 1] + y2 * Wb[3 * j + 2];
+        for (int k = 0; k < 18; ++k) wb[k] = Wb[k];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          const double y0 = Y[3 * i], y1 = Y[3 * i + 1], y2 = Y[3 * i + 2];
+#pragma unroll
+          for (int j = 0; j < 6; ++j) acc[6 * i + j] -= y0 * wb[3 * j] + y1 * wb[3 * j + 1] + y2 * wb[3 * j + 2];
+        }
       }
     }
     __syncthreads();
@@ -626,19 +655,20 @@ __global__ __launch_bounds__(kTile) void k_schur(SchurParams p) {
       for (int j = 0; j < 6; ++j) { so[21 + j] = rl[j]; so[27 + j] = gcl[j]; }
     }
     __syncthreads();
-    for (int q = 0; q < n_pts; ++q) {
-      const int8_t* lo = s_lane_of + q * kMaxFrames;
-#pragma unroll
-      for (int k = 0; k < NT; ++k) {
-        if (ta[k] < 0 || ta[k] != tb[k]) continue;
-        const int la = lo[ta[k]];
+    if (owner && pa == pb) {
+      for (int q = grp; q < n_pts; q += n_groups) {
+        const int la = s_lane_of[q * kMaxFrames + pa];
         if (la < 0) continue;
         const double* U = s_obs + la * kObsStride;
 #pragma unroll
-        for (int j = 0; j < 6; ++j) acc[k][j] += U[sym6(ti[k], j)];
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+          for (int j = 0; j < 6; ++j) acc[6 * i + j] += U[sym6(i, j)];
       }
-      if (va >= 0) {
-        const int la = lo[va];
+    }
+    if (va >= 0) {
+      for (int q = 0; q < n_pts; ++q) {
+        const int la = s_lane_of[q * kMaxFrames + va];
         if (la >= 0) {
           const double* so = s_obs + la * kObsStride;
           acc_rhs += so[21 + vi];
@@ -650,21 +680,30 @@ __global__ __launch_bounds__(kTile) void k_schur(SchurParams p) {
     __syncthreads();
   }
 
-  // ---- per-block partials --------------------------------------------------------------------------------
+  // ---- combine the point groups (fixed order), then per-block partials -----------------------------------
   double* out = p.partial + (size_t)blockIdx.x * p.part_stride;
+  if (owner && grp > 0) {
+    double* dst = s_obs + ((grp - 1) * p.n_pairs + pair) * 36;
 #pragma unroll
-  for (int k = 0; k < NT; ++k) {
-    const int q = tid + k * kTile;
-    if (q < p.n_tasks)
+    for (int k = 0; k < 36; ++k) dst[k] = acc[k];
+  }
+  __syncthreads();
+  if (owner && grp == 0) {
+    for (int g = 1; g < n_groups; ++g) {
+      const double* src = s_obs + ((g - 1) * p.n_pairs + pair) * 36;
 #pragma unroll
-      for (int j = 0; j < 6; ++j) out[q * 6 + j] = acc[k][j];
+      for (int k = 0; k < 36; ++k) acc[k] += src[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 36; ++k) out[pair * 36 + k] = acc[k];
   }
   const int n = 6 * nf;
   if (va >= 0) {
-    out[6 * p.n_tasks + tid] = acc_rhs;
-    out[6 * p.n_tasks + n + tid] = acc_gc;
-    out[6 * p.n_tasks + 2 * n + tid] = acc_du;
+    out[36 * p.n_pairs + tid] = acc_rhs;
+    out[36 * p.n_pairs + n + tid] = acc_gc;
+    out[36 * p.n_pairs + 2 * n + tid] = acc_du;
   }
+  __syncthreads();
   // block reductions of the point-gradient statistics (fixed tree)
   s_red[tid] = gn2;
   __syncthreads();
@@ -680,155 +719,132 @@ __global__ __launch_bounds__(kTile) void k_schur(SchurParams p) {
   __syncthreads();
   for (int s = kTile / 2; s > 0; s >>= 1) { if (tid < s) s_red[tid] = fmax(s_red[tid], s_red[tid + s]); __syncthreads(); }
   if (tid == 0) {
-    out[6 * p.n_tasks + 3 * n + 0] = gmax_b;
-    out[6 * p.n_tasks + 3 * n + 1] = gn2_b;
-    out[6 * p.n_tasks + 3 * n + 2] = s_red[0];
+    out[36 * p.n_pairs + 3 * n + 0] = gmax_b;
+    out[36 * p.n_pairs + 3 * n + 1] = gn2_b;
+    out[36 * p.n_pairs + 3 * n + 2] = s_red[0];
   }
 }
 
-// Sums the per-block partials in a fixed order.  grid.x covers the entries, grid.y splits the blocks into chunks.
-//   out[chunk][stride]; the last three entries are (max, sum, max).
-__global__ void k_reduce_partials(const double* __restrict__ partial, int n_blocks, int stride, int n_chunks,
-                                  double* __restrict__ out) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  const int chunk = blockIdx.y;
-  if (e >= stride) return;
-  const int per = (n_blocks + n_chunks - 1) / n_chunks;
-  const int b0 = chunk * per, b1 = min(n_blocks, b0 + per);
-  const bool is_max = (e == stride - 3) || (e == stride - 1);
-  double acc = 0.0;
-  for (int b = b0; b < b1; ++b) {
-    const double v = partial[(size_t)b * stride + e];
-    acc = is_max ? fmax(acc, v) : acc + v;
-  }
-  out[(size_t)chunk * stride + e] = acc;
-}
-
-// Second level + packing for the transport: packed_sum[0, stride-3) = T | rhs | g_c | diag(U); then
-// packed_sum[stride-3] = cost at the linearisation point (sum of the Jacobian pass block costs),
-// packed_sum[stride-2] = sum g_p^2;  scal[kGmaxPts..] = max group.
-__global__ void k_pack_reduced(const double* __restrict__ red, int stride, int n_chunks,
-                               const double* __restrict__ block_cost, const int32_t* __restrict__ block_fail,
-                               int n_cost_blocks, double* __restrict__ packed_sum, double* __restrict__ scal) {
-  __shared__ double s_red[256];
-  __shared__ int s_f[256];
+// Fixed-order reduction of the per-block partials + packing for the reduced solve / the multi-rank transport.
+// Workgroup = 32 entries x 32 sub-chunks: thread (ex, sub) sums blocks sub, sub + 32, ... of entry ex, then the 32
+// sub-sums are combined by a fixed LDS tree.
+//   packed[0, stride-3) = T | rhs | g_c | diag(U);  packed[stride-3] = cost at the linearisation point (sum of the
+//   Jacobian-pass block costs);  packed[stride-2] = sum g_p^2;  scal[kGmaxPts / kSchurFail / kEvalFailLin] = max group.
+__global__ __launch_bounds__(1024) void k_reduce_final(const double* __restrict__ partial, int n_blocks, int stride,
+                                                        const double* __restrict__ block_cost,
+                                                        const int32_t* __restrict__ block_fail, int n_cost_blocks,
+                                                        double* __restrict__ packed, double* __restrict__ scal) {
+  __shared__ double s_red[32][33];
+  __shared__ int s_f[1024];
   const int tid = threadIdx.x;
-  for (int e = blockIdx.x * blockDim.x + tid; e < stride; e += gridDim.x * blockDim.x) {
+  const int ex = tid & 31, sub = tid >> 5;
+  if ((int)blockIdx.x < (int)gridDim.x - 1) {
+    const int e = blockIdx.x * 32 + ex;
+    const bool valid = e < stride;
     const bool is_max = (e == stride - 3) || (e == stride - 1);
     double acc = 0.0;
-    for (int c = 0; c < n_chunks; ++c) {
-      const double v = red[(size_t)c * stride + e];
-      acc = is_max ? fmax(acc, v) : acc + v;
+    if (valid) {
+      for (int b = sub; b < n_blocks; b += 32) {
+        const double v = partial[(size_t)b * stride + e];
+        acc = is_max ? fmax(acc, v) : acc + v;
+      }
     }
-    if (e < stride - 3) packed_sum[e] = acc;
-    else if (e == stride - 3) scal[kGmaxPts] = acc;
-    else if (e == stride - 2) packed_sum[stride - 2] = acc;
-    else scal[kSchurFail] = acc;
-  }
-  if (blockIdx.x == 0) {
-    // cost of the linearisation point: fixed-order sum of the Jacobian pass block partials
-    double acc = 0.0; int f = 0;
-    for (int b = tid; b < n_cost_blocks; b += 256) { acc += block_cost[b]; f |= block_fail[b]; }
-    s_red[tid] = acc; s_f[tid] = f;
+    s_red[sub][ex] = acc;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) { if (tid < s) { s_red[tid] += s_red[tid + s]; s_f[tid] |= s_f[tid + s]; } __syncthreads(); }
-    if (tid == 0) { packed_sum[stride - 3] = s_red[0]; scal[kEvalFailLin] = (double)s_f[0]; }
+    for (int s = 16; s > 0; s >>= 1) {
+      if (sub < s) s_red[sub][ex] = is_max ? fmax(s_red[sub][ex], s_red[sub + s][ex]) : s_red[sub][ex] + s_red[sub + s][ex];
+      __syncthreads();
+    }
+    if (sub == 0 && valid) {
+      const double v = s_red[0][ex];
+      if (e < stride - 3) packed[e] = v;
+      else if (e == stride - 3) scal[kGmaxPts] = v;
+      else if (e == stride - 2) packed[stride - 2] = v;
+      else scal[kSchurFail] = v;
+    }
+  } else {
+    // last workgroup: cost of the linearisation point = fixed-order sum of the Jacobian-pass block partials
+    double* flat = &s_red[0][0];
+    double acc = 0.0; int f = 0;
+    for (int b = tid; b < n_cost_blocks; b += 1024) { acc += block_cost[b]; f |= block_fail[b]; }
+    flat[tid] = acc; s_f[tid] = f;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) { if (tid < s) { flat[tid] += flat[tid + s]; s_f[tid] |= s_f[tid + s]; } __syncthreads(); }
+    if (tid == 0) { packed[stride - 3] = flat[0]; scal[kEvalFailLin] = (double)s_f[0]; }
   }
 }
 
 // =====================================================================================================
-// reduced camera system: scaling, damping, dense Cholesky, camera step (single workgroup)
+// reduced camera system: (level-2 reduction,) scaling, damping, dense Cholesky, camera step, candidate cameras
+// and their geometry.  One workgroup of 128 threads; thread r owns row r of the (<= 96 x 96) matrix in LDS.
 // =====================================================================================================
 struct SolveParams {
-  const double* packed;     // reduced (global) packed_sum
+  const double* packed;     // reduced (and, multi-rank, all-reduced) packed sums
   const double* cams;       // current cameras [n_frames][6]
   double* cams_cand;        // candidate cameras
   double* delta_c;          // [n_frames][6] unscaled camera step (0 for the constant camera)
   double* sc;               // [6 n_free] Jacobi scale of the camera columns (written when init_scale)
-  double* S_dbg;            // [n*n] scaled + damped reduced matrix (test hook)
+  double* S_dbg;            // [n*n] scaled + damped reduced matrix (test hook), may be null
   double* rhs_dbg;          // [n]
   double* scal;
-  const CamGeom* geom;      // for free_index of every slot
-  int32_t n_frames, n_free, n_tasks, stride;
+  const CamGeom* geom;      // current geometry (free_index of every slot)
+  int32_t n_frames, n_free, n_pairs, stride;
   int32_t init_scale, jacobi;
   double radius, min_diag, max_diag;
 };
 
-__global__ __launch_bounds__(256) void k_solve(SolveParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int n = 6 * p.n_free;
-  double* S = reinterpret_cast<double*>(smem);   // [n][n]
-  double* y = S + n * n;                         // [n]
-  double* sc = y + n;                            // [n]
-  double* D2 = sc + n;                           // [n]
-  double* gcs = D2 + n;                          // [n]
-  __shared__ int s_ok;
-  const int tid = threadIdx.x;
-  const double* T = p.packed;
-  const double* rhs = p.packed + 6 * p.n_tasks;
-  const double* gc = rhs + n;
-  const double* du = gc + n;
-  if (tid == 0) s_ok = 1;
-  for (int i = tid; i < n; i += 256) {
+__device__ __forceinline__ double readlane_f64(double v, int src_lane) {
+  const unsigned lo = __builtin_amdgcn_readlane((unsigned)__double2loint(v), src_lane);
+  const unsigned hi = __builtin_amdgcn_readlane((unsigned)__double2hiint(v), src_lane);
+  return __hiloint2double((int)hi, (int)lo);
+}
+
+// Shared prologue: scale / damp / scatter the packed pair blocks into the dense symmetric matrix S (LDS, leading
+// dimension ld), right-hand side into y.  T threads.
+template <int T>
+__device__ __forceinline__ void solve_prologue(const SolveParams& p, int n, int ld, double* S, double* y, double* sc,
+                                               double* D2, double* gcs, double* gc, int tid) {
+  const int nT = 36 * p.n_pairs;
+  const double* src = p.packed;
+  for (int i = tid; i < n; i += T) {
+    const double du = src[nT + 2 * n + i];
+    const double g = src[nT + n + i];
     double s;
-    if (p.init_scale) { s = p.jacobi ? 1.0 / (1.0 + sqrt(du[i])) : 1.0; p.sc[i] = s; }
+    if (p.init_scale) { s = p.jacobi ? 1.0 / (1.0 + sqrt(du)) : 1.0; p.sc[i] = s; }
     else s = p.sc[i];
     sc[i] = s;
-    D2[i] = fmin(fmax(s * s * du[i], p.min_diag), p.max_diag) / p.radius;
-    gcs[i] = s * gc[i];
+    D2[i] = fmin(fmax(s * s * du, p.min_diag), p.max_diag) / p.radius;
+    gc[i] = g;
+    gcs[i] = s * g;
+    y[i] = s * src[nT + i];
   }
   __syncthreads();
-  // scatter the task layout into the dense symmetric matrix, scale, damp
-  for (int q = tid; q < p.n_tasks; q += 256) {
-    const int pair = q / 6, i = q - pair * 6;
+  for (int e = tid; e < nT; e += T) {
+    const int pair = e / 36, k = e - pair * 36;
+    const int i = k / 6, j = k - i * 6;
     int a = 0, rem = pair;
     while (rem >= p.n_free - a) { rem -= p.n_free - a; ++a; }
     const int b = a + rem;
-    for (int j = 0; j < 6; ++j) {
-      const int r = 6 * a + i, c = 6 * b + j;
-      double v = sc[r] * T[q * 6 + j] * sc[c];
-      if (r == c) v += D2[r];
-      S[r * n + c] = v;
-      if (a != b) S[c * n + r] = v;
-    }
+    const int r = 6 * a + i, c = 6 * b + j;
+    double v = sc[r] * src[e] * sc[c];
+    if (r == c) v += D2[r];
+    if (a != b || c >= r) S[r * ld + c] = v;   // diagonal blocks: take the upper triangle, mirror below
+    if (a != b || c > r) S[c * ld + r] = v;
   }
   __syncthreads();
-  for (int i = tid; i < n; i += 256) { y[i] = sc[i] * rhs[i]; p.rhs_dbg[i] = y[i]; }
-  for (int k = tid; k < n * n; k += 256) p.S_dbg[k] = S[k];
+  if (p.S_dbg) {
+    for (int k = tid; k < n * n; k += T) p.S_dbg[k] = S[(k / n) * ld + (k % n)];
+    for (int i = tid; i < n; i += T) p.rhs_dbg[i] = y[i];
+  }
   __syncthreads();
-  // right-looking Cholesky, lower triangle in place
-  for (int j = 0; j < n; ++j) {
-    if (tid == 0) {
-      const double d = S[j * n + j];
-      if (!(d > 0.0) || !isfinite(d)) { s_ok = 0; S[j * n + j] = 1.0; } else S[j * n + j] = sqrt(d);
-    }
-    __syncthreads();
-    const double djj = S[j * n + j];
-    for (int i = j + 1 + tid; i < n; i += 256) S[i * n + j] /= djj;
-    __syncthreads();
-    const int m = n - j - 1;
-    for (int k = tid; k < m * m; k += 256) {
-      const int r = j + 1 + k / m, c = j + 1 + k % m;
-      if (c <= r) S[r * n + c] -= S[r * n + j] * S[c * n + j];
-    }
-    __syncthreads();
-  }
-  // forward substitution L z = y (column oriented), then L^T x = z
-  for (int j = 0; j < n; ++j) {
-    if (tid == 0) y[j] /= S[j * n + j];
-    __syncthreads();
-    const double yj = y[j];
-    for (int i = j + 1 + tid; i < n; i += 256) y[i] -= S[i * n + j] * yj;
-    __syncthreads();
-  }
-  for (int j = n - 1; j >= 0; --j) {
-    if (tid == 0) y[j] /= S[j * n + j];
-    __syncthreads();
-    const double yj = y[j];
-    for (int i = tid; i < j; i += 256) y[i] -= S[j * n + i] * yj;
-    __syncthreads();
-  }
-  // camera step delta_c = -sc * y; candidate cameras; replicated scalars
+}
+
+// Shared epilogue: camera step delta_c = -sc * y, candidate cameras, replicated scalars (wave 0 reduces them with a
+// fixed butterfly).  The candidate camera geometry is produced by the first workgroup of k_backsub.
+template <int T>
+__device__ __forceinline__ void solve_epilogue(const SolveParams& p, int n, const double* y, const double* sc,
+                                               const double* D2, const double* gcs, const double* gc, bool chol_ok,
+                                               int tid) {
   if (tid < 6 * p.n_frames) {
     const int slot = tid / 6, k = tid % 6;
     const int fa = p.geom[slot].free_index;
@@ -837,26 +853,147 @@ __global__ __launch_bounds__(256) void k_solve(SolveParams p) {
     p.delta_c[tid] = d;
     p.cams_cand[tid] = p.cams[tid] + d;
   }
-  if (tid == 0) {
-    double mcc = 0.0, st2 = 0.0, x2 = 0.0, gmax = 0.0, gn2 = 0.0;
-    bool finite = true;
-    for (int i = 0; i < n; ++i) {
+  if (tid < 64) {
+    double mcc = 0.0, st2 = 0.0, x2 = 0.0, gmax = 0.0, gn2 = 0.0, bad = 0.0;
+    for (int i = tid; i < n; i += 64) {
       mcc += 0.5 * y[i] * gcs[i] + 0.5 * D2[i] * y[i] * y[i];
       const double d = sc[i] * y[i];
       st2 += d * d;
       gmax = fmax(gmax, fabs(gc[i]));
       gn2 += gc[i] * gc[i];
-      finite = finite && isfinite(y[i]);
+      if (!isfinite(y[i])) bad = 1.0;
     }
-    for (int s = 0; s < p.n_frames; ++s)
-      if (p.geom[s].free_index >= 0)
-        for (int k = 0; k < 6; ++k) x2 += p.cams[6 * s + k] * p.cams[6 * s + k];
-    p.scal[kMccCams] = mcc; p.scal[kStep2Cams] = st2; p.scal[kX2Cams] = x2;
-    p.scal[kGmaxCams] = gmax; p.scal[kGnorm2Cams] = gn2;
-    p.scal[kSolveOk] = (s_ok && finite) ? 1.0 : 0.0;
-    p.scal[kCostLin] = p.packed[p.stride - 3];
-    p.scal[kGnorm2Pts] = p.packed[p.stride - 2];
+    for (int i = tid; i < 6 * p.n_frames; i += 64)
+      if (p.geom[i / 6].free_index >= 0) x2 += p.cams[i] * p.cams[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      mcc += __shfl_xor(mcc, off); st2 += __shfl_xor(st2, off); x2 += __shfl_xor(x2, off);
+      gn2 += __shfl_xor(gn2, off); gmax = fmax(gmax, __shfl_xor(gmax, off)); bad = fmax(bad, __shfl_xor(bad, off));
+    }
+    if (tid == 0) {
+      p.scal[kMccCams] = mcc; p.scal[kStep2Cams] = st2; p.scal[kX2Cams] = x2;
+      p.scal[kGmaxCams] = gmax; p.scal[kGnorm2Cams] = gn2;
+      p.scal[kSolveOk] = (chol_ok && bad == 0.0) ? 1.0 : 0.0;
+      p.scal[kCostLin] = p.packed[p.stride - 3];
+      p.scal[kGnorm2Pts] = p.packed[p.stride - 2];
+    }
   }
+}
+
+// Fast path, n = 6 NF <= 60: wave 0 keeps row r of the matrix in lane r's registers (compile-time indexed).  Per
+// column ONE LDS round trip broadcasts the unscaled column v = A[:, j]; with t_r = v_r / v_j the trailing update is
+// a[c] -= t_r * v_c and the factor entry is L_rj = v_r * rsqrt(v_j): no second broadcast, no barriers (one wave).
+// The other three waves only help with the prologue / epilogue.
+template <int NF>
+__global__ __launch_bounds__(256) void k_solve_wave(SolveParams p) {
+  constexpr int N = 6 * NF;
+  constexpr int LD = N + 1;
+  __shared__ double S[N * LD];
+  __shared__ __attribute__((aligned(16))) double s_col[64];
+  __shared__ double y_s[N], sc[N], D2[N], gcs[N], gc[N];
+  __shared__ int s_ok;
+  const int tid = threadIdx.x;
+  solve_prologue<256>(p, N, LD, S, y_s, sc, D2, gcs, gc, tid);
+  if (tid < 64) {
+    const int lane = tid;
+    const int r = lane < N ? lane : N - 1;
+    double a[N];
+#pragma unroll
+    for (int c = 0; c < N; ++c) a[c] = (lane < N && c <= lane) ? S[r * LD + c] : 0.0;
+    double y = lane < N ? y_s[r] : 0.0;
+    double d_own = 1.0;      // 1 / L_rr of this lane's row
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      s_col[lane] = a[j];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const double piv = s_col[j];
+      ok = ok && (piv > 0.0) && isfinite(piv);
+      const double pv = (piv > 0.0) ? piv : 1.0;
+      const double inv = fast_rsqrt(pv);
+      const double t = a[j] * fast_rcp(pv);
+      if (lane == j) d_own = inv;
+      a[j] = a[j] * inv;                 // L_rj (lane j: sqrt(piv))
+#pragma unroll
+      for (int c = j + 1; c < N; ++c) a[c] = fma(-t, s_col[c], a[c]);   // meaningful for lanes >= c
+      __builtin_amdgcn_wave_barrier();
+    }
+    // L to LDS (row-major) for the transposed access of the backward sweep
+#pragma unroll
+    for (int c = 0; c < N; ++c) if (lane < N && c <= lane) S[r * LD + c] = a[c];
+    // forward substitution L z = y
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      if (lane == j) y *= d_own;
+      const double zj = readlane_f64(y, j);
+      if (lane > j) y = fma(-a[j], zj, y);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // backward substitution L^T x = z: lane r reads L[j][r] (row j, contiguous across lanes)
+#pragma unroll
+    for (int j = N - 1; j >= 0; --j) {
+      const double ljr = (lane < j) ? S[j * LD + r] : 0.0;
+      if (lane == j) y *= d_own;
+      const double xj = readlane_f64(y, j);
+      if (lane < j) y = fma(-ljr, xj, y);
+    }
+    if (lane < N) y_s[lane] = y;
+    if (lane == 0) s_ok = ok ? 1 : 0;
+  }
+  __syncthreads();
+  solve_epilogue<256>(p, N, y_s, sc, D2, gcs, gc, s_ok != 0, tid);
+}
+
+// Generic path (any n <= 96): matrix in LDS, 256 threads, 2-D trailing update, one barrier pair per column.
+constexpr int kSolveThreads = 256;
+
+__global__ __launch_bounds__(kSolveThreads) void k_solve_generic(SolveParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int n = 6 * p.n_free;
+  const int ld = n + 1;
+  double* S = reinterpret_cast<double*>(smem);   // [n][ld]
+  double* y = S + n * ld;
+  double* sc = y + n;
+  double* D2 = sc + n;
+  double* gcs = D2 + n;
+  double* gc = gcs + n;
+  __shared__ int s_ok;
+  const int tid = threadIdx.x;
+  if (tid == 0) s_ok = 1;
+  solve_prologue<kSolveThreads>(p, n, ld, S, y, sc, D2, gcs, gc, tid);
+  const int tx = tid & 15, ty = tid >> 4;
+  for (int j = 0; j < n; ++j) {
+    const double d = S[j * ld + j];
+    const double dj = (d > 0.0) ? sqrt(d) : 1.0;
+    if (tid == 0 && (!(d > 0.0) || !isfinite(d))) s_ok = 0;
+    __syncthreads();
+    for (int r = j + tid; r < n; r += kSolveThreads) S[r * ld + j] = (r == j) ? dj : S[r * ld + j] / dj;
+    __syncthreads();
+    for (int r = j + 1 + ty; r < n; r += 16) {
+      const double lrj = S[r * ld + j];
+      for (int c = j + 1 + tx; c <= r; c += 16) S[r * ld + c] -= lrj * S[c * ld + j];
+    }
+    __syncthreads();
+  }
+  for (int j = 0; j < n; ++j) {
+    if (tid == 0) y[j] /= S[j * ld + j];
+    __syncthreads();
+    const double yj = y[j];
+    for (int r = j + 1 + tid; r < n; r += kSolveThreads) y[r] -= S[r * ld + j] * yj;
+    __syncthreads();
+  }
+  for (int j = n - 1; j >= 0; --j) {
+    if (tid == 0) y[j] /= S[j * ld + j];
+    __syncthreads();
+    const double yj = y[j];
+    for (int r = tid; r < j; r += kSolveThreads) y[r] -= S[j * ld + r] * yj;
+    __syncthreads();
+  }
+  solve_epilogue<kSolveThreads>(p, n, y, sc, D2, gcs, gc, s_ok != 0, tid);
 }
 
 // =====================================================================================================
@@ -873,8 +1010,10 @@ struct BacksubParams {
   const double* ptrec;
   const double* delta_c;
   double* block_out;     // [gridDim.x][3]: mcc, step^2, x^2
+  const double* cams_cand;   // candidate cameras (k_solve) -> geometry for the candidate pass, by workgroup 0
+  CamGeom* geom_cand;
   int64_t rec_stride;
-  int32_t n_points;
+  int32_t n_points, n_frames, fixed_slot;
   double fx, fy;
 };
 
@@ -882,6 +1021,7 @@ __global__ __launch_bounds__(256) void k_backsub(BacksubParams p) {
   __shared__ double s_red[3][256];
   const int tid = threadIdx.x;
   const int pt = blockIdx.x * 256 + tid;
+  if (blockIdx.x == gridDim.x - 1 && tid >= 256 - p.n_frames) cam_geom_one(p.cams_cand, p.geom_cand, 255 - tid, p.fixed_slot);
   double mcc = 0.0, st2 = 0.0, x2 = 0.0;
   if (pt < p.n_points) {
     const double X[3] = {p.xyz[3 * (size_t)pt], p.xyz[3 * (size_t)pt + 1], p.xyz[3 * (size_t)pt + 2]};
@@ -927,11 +1067,13 @@ __global__ __launch_bounds__(256) void k_backsub(BacksubParams p) {
   if (tid == 0) { p.block_out[3 * blockIdx.x] = s_red[0][0]; p.block_out[3 * blockIdx.x + 1] = s_red[1][0]; p.block_out[3 * blockIdx.x + 2] = s_red[2][0]; }
 }
 
-// Fixed-order sums of the back-substitution and cost-pass block partials into the scalar block.
+// Fixed-order sums of the back-substitution and candidate-pass block partials into the scalar block; with
+// `publish` the whole block is also written to host-mapped memory followed by a sequence number the host polls.
 __global__ __launch_bounds__(256) void k_finalize_step(const double* __restrict__ bs_out, int n_bs_blocks,
                                                         const double* __restrict__ block_cost,
                                                         const int32_t* __restrict__ block_fail, int n_cost_blocks,
-                                                        double* __restrict__ scal) {
+                                                        double* __restrict__ scal, double* host_scal,
+                                                        unsigned long long* host_seq, unsigned long long seq) {
   __shared__ double s_red[4][256];
   __shared__ int s_f[256];
   const int tid = threadIdx.x;
@@ -951,6 +1093,24 @@ __global__ __launch_bounds__(256) void k_finalize_step(const double* __restrict_
     scal[kMccPts] = s_red[0][0]; scal[kStep2Pts] = s_red[1][0]; scal[kX2Pts] = s_red[2][0];
     scal[kCandCost] = s_red[3][0]; scal[kEvalFailCand] = (double)s_f[0];
   }
+  if (host_scal) {
+    __syncthreads();
+    if (tid < kNumScal) host_scal[tid] = scal[tid];
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) { *reinterpret_cast<volatile unsigned long long*>(host_seq) = seq; __threadfence_system(); }
+  }
+}
+
+// Publishes the (already reduced) scalar block to host-mapped memory: used after the multi-rank all-reduces and
+// for gradient-only steps.
+__global__ void k_publish(const double* __restrict__ scal, double* host_scal, unsigned long long* host_seq,
+                          unsigned long long seq) {
+  const int tid = threadIdx.x;
+  if (tid < kNumScal) host_scal[tid] = scal[tid];
+  __threadfence_system();
+  __syncthreads();
+  if (tid == 0) { *reinterpret_cast<volatile unsigned long long*>(host_seq) = seq; __threadfence_system(); }
 }
 
 }  // namespace pba

@@ -53,9 +53,10 @@ extern "C" int pba_solve(pba_engine* e, const pba_solver_options* o, pba_solver_
 
   // ---- IterationZero -----------------------------------------------------------------------------------
   double t_iter = now();
+  pba_internal_reset_pass_counts(e);
+  pba_internal_set_speculate(e, 1);
   int rc = pba_linearize(e, nullptr);
   if (rc) return rc;
-  sum->num_jacobian_passes = 1;
   bool last = o->max_num_iterations <= 0;
   rc = pba_internal_step(e, radius, 1, o, &info, last ? 1 : 0);
   if (rc == PBA_ERR_NUMERIC) {
@@ -65,7 +66,6 @@ extern "C" int pba_solve(pba_engine* e, const pba_solver_options* o, pba_solver_
     return PBA_OK;
   }
   if (rc) return rc;
-  if (!last) sum->num_cost_passes++;
   bool info_valid = !last;
   double x_cost = info.cost;
   sum->initial_cost = x_cost;
@@ -123,7 +123,6 @@ extern "C" int pba_solve(pba_engine* e, const pba_solver_options* o, pba_solver_
       rc = pba_internal_step(e, radius, 0, o, &info, 0);
       if (rc) return rc;
       sum->num_resolve_passes++;
-      sum->num_cost_passes++;
       it.step_solver_time_in_seconds = now() - t_solve;
     }
     info_valid = false;
@@ -140,6 +139,7 @@ extern "C" int pba_solve(pba_engine* e, const pba_solver_options* o, pba_solver_
         push(it);
         break;
       }
+      pba_internal_set_speculate(e, 0);
       step_rejected();
       it.cost = x_cost;
       continue;
@@ -167,9 +167,9 @@ extern "C" int pba_solve(pba_engine* e, const pba_solver_options* o, pba_solver_
     it.relative_decrease = it.cost_change / info.model_cost_change;
     if (it.relative_decrease > o->min_relative_decrease) {
       // HandleSuccessfulStep: x <- candidate, re-linearise, LM::StepAccepted
+      pba_internal_set_speculate(e, 1);   // accepted: keep betting on acceptance
       if ((rc = pba_accept(e))) return rc;
-      if ((rc = pba_linearize(e, nullptr))) return rc;
-      sum->num_jacobian_passes++;
+      if ((rc = pba_linearize(e, nullptr))) return rc;   // no-op when the candidate pass was a Jacobian pass
       x_cost = candidate_cost;
       radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * it.relative_decrease - 1.0, 3));
       radius = std::min(o->max_trust_region_radius, radius);
@@ -182,7 +182,6 @@ extern "C" int pba_solve(pba_engine* e, const pba_solver_options* o, pba_solver_
         break;
       }
       if (rc) return rc;
-      if (!last) sum->num_cost_passes++;
       info_valid = !last;
       it.step_is_successful = 1;
       it.cost = x_cost;
@@ -190,10 +189,12 @@ extern "C" int pba_solve(pba_engine* e, const pba_solver_options* o, pba_solver_
       it.gradient_norm = info.gradient_norm;
     } else {
       // HandleUnsuccessfulStep
+      pba_internal_set_speculate(e, 0);   // rejected: the retry only needs the cost
       step_rejected();
       it.cost = candidate_cost;
     }
   }
+  pba_internal_pass_counts(e, &sum->num_jacobian_passes, &sum->num_cost_passes);
   sum->final_cost = minimum_cost;
   sum->num_iterations = n_it < max_out ? n_it : max_out;
   sum->total_time_in_seconds = now() - t_start;

@@ -5,9 +5,10 @@ from oracle import oracle
 from photobundle_amd.engine import Engine
 
 
-def make_engine(prob, device=0):
+def make_engine(prob, device=0, keep_reduced_system=True):
     _, _, rows, cols = prob.planes.shape
-    e = Engine(rows, cols, prob.K, prob.radius, prob.n_frames, huber=prob.huber, device=device)
+    e = Engine(rows, cols, prob.K, prob.radius, prob.n_frames, huber=prob.huber, device=device,
+               keep_reduced_system=keep_reduced_system)
     e.load(prob)
     return e
 
