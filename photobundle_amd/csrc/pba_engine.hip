@@ -61,13 +61,16 @@ struct pba_engine {
   double* d_rhs = nullptr;          // [n]
   double* d_block_cost[2] = {nullptr, nullptr};   // [sample_grid] block costs of the last pass at point parity k
   int32_t* d_block_fail[2] = {nullptr, nullptr};
+  int cost_blocks[2] = {0, 0};      // valid entries in d_block_cost[k] (grid of the pass that wrote them)
   double* d_bs_out = nullptr;       // [backsub_grid][3]
   double* d_scal = nullptr;         // [kNumScal]
   double* h_scal = nullptr;         // pinned + mapped: [kNumScal] doubles then one u64 sequence number
   double* h_scal_dev = nullptr;     // device view of h_scal
   unsigned long long seq = 0;
   int64_t jac_passes = 0, cost_passes = 0;
-  int schur_grid = 0, sample_grid = 0, backsub_grid = 0, sample_waves = 4;
+  int schur_grid = 0, sample_grid = 0, backsub_grid = 0, sample_waves = 4, fused_grid = 0;
+  bool fuse = true;                 // back-substitution + finalisation fused into the candidate pass (radius <= 3)
+  unsigned int* d_ticket = nullptr;
   int n_pairs = 0, part_stride = 0;
   static constexpr int kChunks = 32;
 
@@ -108,21 +111,27 @@ int dev_alloc(pba_engine* e, T** p, size_t n) {
 template <class T>
 void dev_free(T** p) { if (*p) { (void)hipFree(*p); *p = nullptr; } }
 
-template <int R, bool JAC>
+template <int R, bool JAC, bool FUSED>
 void launch_sample_r(pba_engine* e, const SampleParams& sp) {
   constexpr int WAVES = (R <= 2) ? 4 : (R == 3 ? 2 : 1);
-  hipLaunchKernelGGL((k_sample<R, JAC, WAVES>), dim3(e->sample_grid), dim3(WAVES * 64), 0, e->stream, sp);
-}
-template <bool JAC>
-void launch_sample(pba_engine* e, const SampleParams& sp) {
-  switch (e->cfg.radius) {
-    case 1: launch_sample_r<1, JAC>(e, sp); break;
-    case 2: launch_sample_r<2, JAC>(e, sp); break;
-    case 3: launch_sample_r<3, JAC>(e, sp); break;
-    case 4: launch_sample_r<4, JAC>(e, sp); break;
-    default: launch_sample_r<5, JAC>(e, sp); break;
+  if constexpr (FUSED && WAVES < 2) {
+    (void)e; (void)sp;   // unreachable: fused_capable() is false for these radii
+  } else {
+    const int grid = FUSED ? e->fused_grid : e->sample_grid;
+    hipLaunchKernelGGL((k_sample<R, JAC, WAVES, FUSED>), dim3(grid), dim3(WAVES * 64), 0, e->stream, sp);
   }
 }
+template <bool JAC, bool FUSED = false>
+void launch_sample(pba_engine* e, const SampleParams& sp) {
+  switch (e->cfg.radius) {
+    case 1: launch_sample_r<1, JAC, FUSED>(e, sp); break;
+    case 2: launch_sample_r<2, JAC, FUSED>(e, sp); break;
+    case 3: launch_sample_r<3, JAC, FUSED>(e, sp); break;
+    case 4: launch_sample_r<4, JAC, FUSED>(e, sp); break;
+    default: launch_sample_r<5, JAC, FUSED>(e, sp); break;
+  }
+}
+bool fused_capable(const pba_engine* e) { return e->cfg.radius <= 3 && e->fuse; }
 int sample_waves_for_radius(int R) { return (R <= 2) ? 4 : (R == 3 ? 2 : 1); }
 
 size_t schur_smem_bytes() {
@@ -170,6 +179,7 @@ SampleParams make_sample_params(pba_engine* e, int which_point) {
   sp.block_fail = e->d_block_fail[which_out];
   sp.rec_stride = e->rec_stride;
   sp.n_obs = e->n_obs;
+  sp.n_frames = e->n_frames;
   sp.rows = e->cfg.rows;
   sp.cols = e->cfg.cols;
   sp.fx = e->cfg.fx; sp.fy = e->cfg.fy; sp.cx = e->cfg.cx; sp.cy = e->cfg.cy;
@@ -263,6 +273,9 @@ int pba_create(const pba_config* cfg, pba_engine** out) {
   std::memset(e->h_scal, 0, (kNumScal + 1) * sizeof(double));
   if (hipHostGetDevicePointer(reinterpret_cast<void**>(&e->h_scal_dev), e->h_scal, 0) != hipSuccess) return bail(PBA_ERR_HIP);
   if (const char* sv = getenv("PBA_SPECULATE")) e->speculate = atoi(sv) != 0;
+  if (const char* sv = getenv("PBA_FUSE")) e->fuse = atoi(sv) != 0;
+  if ((rc = dev_alloc(e, &e->d_ticket, (size_t)1))) return bail(rc);
+  if (hipMemsetAsync(e->d_ticket, 0, sizeof(unsigned int), e->stream) != hipSuccess) return bail(PBA_ERR_HIP);
   for (int k = 0; k < 6; ++k)
     if (hipEventCreate(&e->ev[k]) != hipSuccess) return bail(PBA_ERR_HIP);
   e->sample_waves = sample_waves_for_radius(cfg->radius);
@@ -281,7 +294,7 @@ void pba_destroy(pba_engine* e) {
   dev_free(&e->d_desc); dev_free(&e->d_w2); dev_free(&e->d_obs_point); dev_free(&e->d_obs_slot); dev_free(&e->d_pt_begin);
   dev_free(&e->d_tile_info); dev_free(&e->d_obs_l0); dev_free(&e->d_obs_cnt); dev_free(&e->d_rec[0]); dev_free(&e->d_rec[1]); dev_free(&e->d_sp); dev_free(&e->d_ptrec); dev_free(&e->d_sc);
   dev_free(&e->d_delta_c); dev_free(&e->d_partial); dev_free(&e->d_red); dev_free(&e->d_packed); dev_free(&e->d_S);
-  dev_free(&e->d_rhs); dev_free(&e->d_bs_out); dev_free(&e->d_scal);
+  dev_free(&e->d_rhs); dev_free(&e->d_bs_out); dev_free(&e->d_scal); dev_free(&e->d_ticket);
   if (e->h_scal) (void)hipHostFree(e->h_scal);
   for (int k = 0; k < 6; ++k) if (e->ev[k]) (void)hipEventDestroy(e->ev[k]);
   if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -383,12 +396,18 @@ int pba_set_problem(pba_engine* e, int32_t n_points, const double* xyz, const do
   if ((rc = dev_alloc(e, &e->d_sp, (size_t)3 * n_points))) return rc;
   if ((rc = dev_alloc(e, &e->d_ptrec, (size_t)12 * n_points))) return rc;
   e->sample_grid = (n_obs + e->sample_waves * 64 - 1) / (e->sample_waves * 64);
+  {
+    const int tiles_per_block = std::max(1, e->sample_waves * 64 / kTile);
+    e->fused_grid = (e->n_tiles + tiles_per_block - 1) / tiles_per_block;
+  }
+  const int cost_blocks = std::max(e->sample_grid, e->fused_grid);
   for (int k = 0; k < 2; ++k) {
-    if ((rc = dev_alloc(e, &e->d_block_cost[k], (size_t)e->sample_grid))) return rc;
-    if ((rc = dev_alloc(e, &e->d_block_fail[k], (size_t)e->sample_grid))) return rc;
+    if ((rc = dev_alloc(e, &e->d_block_cost[k], (size_t)cost_blocks))) return rc;
+    if ((rc = dev_alloc(e, &e->d_block_fail[k], (size_t)cost_blocks))) return rc;
+    e->cost_blocks[k] = 0;
   }
   e->backsub_grid = (n_points + 255) / 256;
-  if ((rc = dev_alloc(e, &e->d_bs_out, (size_t)3 * e->backsub_grid))) return rc;
+  if ((rc = dev_alloc(e, &e->d_bs_out, (size_t)3 * std::max(e->backsub_grid, e->fused_grid)))) return rc;
   e->schur_grid = std::min(e->n_tiles, 256 * 3);
 
   HIP_TRY(e, hipMemcpyAsync(e->d_xyz[0], xyz, sizeof(double) * 3 * n_points, hipMemcpyHostToDevice, e->stream));
@@ -451,13 +470,14 @@ int pba_linearize(pba_engine* e, double* cost) {
     launch_sample<true>(e, sp);
     ev_end(e, 0);
     HIP_TRY(e, hipGetLastError());
+    e->cost_blocks[e->cur] = e->sample_grid;
     e->lin_valid[e->cur] = true;
     e->jac_passes++;
   }
   e->have_lin = true;
   if (cost) {
-    std::vector<double> bc(e->sample_grid);
-    HIP_TRY(e, hipMemcpyAsync(bc.data(), e->d_block_cost[e->cur], sizeof(double) * e->sample_grid, hipMemcpyDeviceToHost, e->stream));
+    std::vector<double> bc(e->cost_blocks[e->cur]);
+    HIP_TRY(e, hipMemcpyAsync(bc.data(), e->d_block_cost[e->cur], sizeof(double) * bc.size(), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     ev_collect(e);
     double c = 0.0;
@@ -487,7 +507,7 @@ int pba_internal_step(pba_engine* e, double radius, int32_t init_scale, const pb
   SchurParams sc{};
   sc.xyz = e->d_xyz[cur]; sc.geom = e->d_geom[cur]; sc.rec = e->d_rec[cur]; sc.obs_point = e->d_obs_point;
   sc.obs_slot = e->d_obs_slot; sc.tile_info = e->d_tile_info; sc.obs_l0 = e->d_obs_l0; sc.obs_cnt = e->d_obs_cnt; sc.sp = e->d_sp;
-  sc.ptrec = e->d_ptrec; sc.partial = e->d_partial; sc.rec_stride = e->rec_stride; sc.n_tiles = e->n_tiles;
+  sc.ptrec = e->d_ptrec; sc.partial = e->d_partial; sc.rec_stride = e->rec_stride; sc.n_tiles = e->n_tiles; sc.n_frames = e->n_frames;
   sc.n_free = e->n_free; sc.n_pairs = e->n_pairs; sc.part_stride = e->part_stride; sc.init_scale = init_scale;
   sc.jacobi = o->jacobi_scaling; sc.fx = e->cfg.fx; sc.fy = e->cfg.fy; sc.radius = radius; sc.inv_radius = 1.0 / radius;
   sc.min_diag = o->min_lm_diagonal; sc.max_diag = o->max_lm_diagonal;
@@ -495,7 +515,7 @@ int pba_internal_step(pba_engine* e, double radius, int32_t init_scale, const pb
   launch_schur(e, sc);
   ev_end(e, 2);
   hipLaunchKernelGGL(k_reduce_final, dim3((e->part_stride + 31) / 32 + 1), dim3(1024), 0, e->stream, e->d_partial,
-                     e->schur_grid, e->part_stride, e->d_block_cost[cur], e->d_block_fail[cur], e->sample_grid, e->d_packed,
+                     e->schur_grid, e->part_stride, e->d_block_cost[cur], e->d_block_fail[cur], e->cost_blocks[cur], e->d_packed,
                      e->d_scal);
   HIP_TRY(e, hipGetLastError());
   if (multi) {
@@ -507,12 +527,34 @@ int pba_internal_step(pba_engine* e, double radius, int32_t init_scale, const pb
   so.cams = e->d_cams[cur]; so.cams_cand = e->d_cams[cand]; so.delta_c = e->d_delta_c;
   so.sc = e->d_sc; so.S_dbg = (e->cfg.flags & 1) ? e->d_S : nullptr; so.rhs_dbg = e->d_rhs; so.scal = e->d_scal; so.geom = e->d_geom[cur];
   so.n_frames = e->n_frames; so.n_free = e->n_free; so.n_pairs = e->n_pairs; so.stride = e->part_stride;
+  so.fixed_slot = e->fixed_slot;
+  so.geom_cand = (!grad_only && fused_capable(e)) ? e->d_geom[cand] : nullptr;
   so.init_scale = init_scale; so.jacobi = o->jacobi_scaling; so.radius = radius; so.min_diag = o->min_lm_diagonal;
   so.max_diag = o->max_lm_diagonal;
   launch_solve(e, so, n);
   const unsigned long long seq = ++e->seq;
   unsigned long long* h_seq_dev = reinterpret_cast<unsigned long long*>(e->h_scal_dev + kNumScal);
-  if (!grad_only) {
+  if (!grad_only && fused_capable(e)) {
+    // one kernel: back-substitution -> candidate pass (Jacobian pass when speculating) -> step finalisation
+    SampleParams sp = make_sample_params(e, cand);
+    sp.tile_info = e->d_tile_info; sp.obs_l0 = e->d_obs_l0; sp.obs_cnt = e->d_obs_cnt; sp.geom_prev = e->d_geom[cur];
+    sp.xyz_prev = e->d_xyz[cur]; sp.rec_prev = e->d_rec[cur]; sp.sp = e->d_sp; sp.ptrec = e->d_ptrec;
+    sp.delta_c = e->d_delta_c; sp.block_bs = e->d_bs_out; sp.ticket = e->d_ticket; sp.scal = e->d_scal;
+    sp.host_scal = multi ? nullptr : e->h_scal_dev; sp.host_seq = h_seq_dev; sp.seq = seq; sp.n_tiles = e->n_tiles;
+    if (e->speculate) {
+      ev_begin(e, 0);
+      launch_sample<true, true>(e, sp);
+      ev_end(e, 0);
+      e->jac_passes++;
+    } else {
+      ev_begin(e, 1);
+      launch_sample<false, true>(e, sp);
+      ev_end(e, 1);
+      e->cost_passes++;
+    }
+    e->cost_blocks[cand] = e->fused_grid;
+    e->lin_valid[cand] = e->speculate;
+  } else if (!grad_only) {
     BacksubParams bs{};
     bs.xyz = e->d_xyz[cur]; bs.xyz_cand = e->d_xyz[cand]; bs.geom = e->d_geom[cur]; bs.rec = e->d_rec[cur];
     bs.pt_begin = e->d_pt_begin; bs.obs_slot = e->d_obs_slot; bs.sp = e->d_sp; bs.ptrec = e->d_ptrec;
@@ -533,6 +575,7 @@ int pba_internal_step(pba_engine* e, double radius, int32_t init_scale, const pb
       ev_end(e, 1);
       e->cost_passes++;
     }
+    e->cost_blocks[cand] = e->sample_grid;
     e->lin_valid[cand] = e->speculate;
     hipLaunchKernelGGL(k_finalize_step, dim3(1), dim3(256), 0, e->stream, e->d_bs_out, e->backsub_grid, e->d_block_cost[cand],
                        e->d_block_fail[cand], e->sample_grid, e->d_scal, multi ? nullptr : e->h_scal_dev, h_seq_dev, seq);

@@ -14,6 +14,48 @@
 
 namespace pba {
 
+// Agent-scope relaxed 8-byte store / load (gfx950: write-through `sc1` store, L1-bypassing `sc1` load).  Used for the
+// tiny per-workgroup partials that another workgroup of the SAME launch consumes: no release/acquire fence is
+// needed (an agent-scope release fence is a whole-L2 write-back, ~us per workgroup).
+__device__ __forceinline__ void store_agent(double* p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v),
+                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double load_agent(const double* p) {
+  return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p),
+                                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+// Fixed-order (butterfly) wave reductions: no LDS, no barriers, reproducible.
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off));
+  return v;
+}
+
+// Cooperative copy of the per-camera geometry table into LDS (8-byte words, coalesced): the per-lane gathers of
+// ~50 doubles per observation then hit LDS instead of going through the vector memory path.
+template <int NT>
+__device__ __forceinline__ void stage_geom(const CamGeom* __restrict__ src, CamGeom* dst, int n_frames, int tid) {
+  static_assert(sizeof(CamGeom) % 8 == 0, "CamGeom is copied as 8-byte words");
+  const unsigned long long* s = reinterpret_cast<const unsigned long long*>(src);
+  unsigned long long* d = reinterpret_cast<unsigned long long*>(dst);
+  const int n = n_frames * (int)(sizeof(CamGeom) / 8);
+  for (int k = tid; k < n; k += NT) d[k] = s[k];
+}
+
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, i.e. it waits for every
+// outstanding global STORE of the wave (~1 us round trip) although nothing after the barrier depends on it.
+// Global LOADS stay correct: the compiler still waits for a load's result before its first use.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // =====================================================================================================
 // frames
 // =====================================================================================================
@@ -230,10 +272,27 @@ struct SampleParams {
   double* block_cost;         // [gridDim.x] per-block cost partial
   int32_t* block_fail;        // [gridDim.x] non-finite flag
   int64_t rec_stride;
-  int32_t n_obs;
+  int32_t n_obs, n_frames;
   int32_t rows, cols;
   double fx, fy, cx, cy;
   double huber;
+  // ---- FUSED only: back-substitution of the step that leads to the point being sampled, and step finalisation ----
+  const int4* tile_info;      // [n_tiles] whole-point tiles of <= 128 observations (shared with k_schur)
+  const uint8_t* obs_l0;      // [n_obs]
+  const uint8_t* obs_cnt;     // [n_obs]
+  const CamGeom* geom_prev;   // geometry at the CURRENT point (the linearisation the step was computed from)
+  const double* xyz_prev;     // current points; `xyz` is then the OUTPUT (candidate points)
+  const double* rec_prev;     // Jacobian-pass records of the current point
+  const double* sp;           // [n_points][3]
+  const double* ptrec;        // [n_points][12]
+  const double* delta_c;      // [n_frames][6]
+  double* block_bs;           // [gridDim.x][3] mcc, step^2, x^2 partials
+  unsigned int* ticket;       // arrival counter (zero between launches)
+  double* scal;               // device scalar block
+  double* host_scal;          // host-mapped copy (null: multi-rank, published later)
+  unsigned long long* host_seq;
+  unsigned long long seq;
+  int32_t n_tiles;
 };
 
 // One LANE per observation (residual block); each wave stages the (2R+2)^2 texel footprints of its 64
@@ -243,35 +302,117 @@ struct SampleParams {
 // bot(i, j) and top(i+1, j) are the same expression (sample_eigen.h:82-83).
 //   JAC = true : Jacobian pass. Emits per observation M = sum w^2 g g^T, b = sum w^2 g e (rho'-scaled) and rho/2.
 //   JAC = false: cost pass (intensity only).
-template <int R, bool JAC, int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void k_sample(SampleParams p) {
+//   FUSED      : the workgroup first back-substitutes the step for its own (whole) points
+//                (SchurEliminator::BackSubstitute), samples at the candidate it just formed, and the last workgroup
+//                to finish reduces the per-block partials in a fixed order and publishes the step's scalar block.
+template <int R, bool JAC, int WAVES, bool FUSED>
+__global__ __launch_bounds__(WAVES * 64, (R <= 2 ? 4 : 1)) void k_sample(SampleParams p) {
+  static_assert(!FUSED || (WAVES * 64) % 128 == 0, "fused tiles are 128 observations");
   constexpr int W = 2 * R + 1;      // patch side
   constexpr int F = 2 * R + 2;      // footprint side
   constexpr int FF = F * F;
   constexpr int LSTRIDE = 65;       // texel-major LDS layout [t][lane], odd stride: conflict-free both ways
-  __shared__ uint32_t s_tex[WAVES][FF * LSTRIDE];
+  constexpr size_t kTexBytes = sizeof(uint32_t) * WAVES * FF * LSTRIDE;
+  constexpr size_t kPreBytes = sizeof(double) * 3 * WAVES * 64 + 2 * kMaxFrames * sizeof(CamGeom);
+  __shared__ __attribute__((aligned(16))) char s_raw[kTexBytes > kPreBytes ? kTexBytes : kPreBytes];
+  uint32_t (*s_tex)[FF * LSTRIDE] = reinterpret_cast<uint32_t (*)[FF * LSTRIDE]>(s_raw);
   __shared__ int32_t s_base[WAVES][64];
   __shared__ double s_red[WAVES * 64];
   __shared__ int32_t s_fail;
 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int obs = blockIdx.x * (WAVES * 64) + threadIdx.x;
-  const bool active = obs < p.n_obs;
+  int obs = blockIdx.x * (WAVES * 64) + threadIdx.x;
+  bool active = obs < p.n_obs;
   if (threadIdx.x == 0) s_fail = 0;
 
-  // ---- phase 1: geometry, one lane per observation (fp64) ------------------------------------------------
+  // camera geometry tables -> LDS (the texel region is free until the staging phase)
+  CamGeom* s_geom = reinterpret_cast<CamGeom*>(s_raw + sizeof(double) * 3 * WAVES * 64);
+  CamGeom* s_geom_prev = s_geom + kMaxFrames;
+  stage_geom<WAVES * 64>(p.geom, s_geom, p.n_frames, threadIdx.x);
+  if (FUSED) stage_geom<WAVES * 64>(p.geom_prev, s_geom_prev, p.n_frames, threadIdx.x);
+  lds_barrier();
+
   int pt = 0, slot = 0;
+  double X[3] = {0.0, 0.0, 0.0};
+  double bs_mcc = 0.0, bs_st2 = 0.0, bs_x2 = 0.0;
+  if (FUSED) {
+    // ---- phase 0: back-substitution for this workgroup's points ----------------------------------------
+    // delta_p = -P (g_p + sum_l W_l^T delta_c[slot_l]),  W_l^T delta_c = Ap^T M' (Ac delta_c)
+    double* s_bs = reinterpret_cast<double*>(&s_tex[0][0]);       // [WAVES * 64][3], reused before the staging
+    const int half = threadIdx.x >> 7, lt = threadIdx.x & 127;
+    const int tile = blockIdx.x * ((WAVES * 64) / 128) + half;
+    int4 ti = make_int4(0, 0, 0, 0);
+    if (tile < p.n_tiles) ti = p.tile_info[tile];
+    active = lt < ti.y;
+    obs = ti.x + lt;
+    int l0 = 0, cnt = 0;
+    double c3[3] = {0.0, 0.0, 0.0};
+    double pr[12], spk[3] = {1.0, 1.0, 1.0};
+#pragma unroll
+    for (int k = 0; k < 12; ++k) pr[k] = 0.0;
+    if (active) {
+      pt = p.obs_point[obs];
+      slot = p.obs_slot[obs];
+      l0 = p.obs_l0[obs]; cnt = p.obs_cnt[obs];
+      X[0] = p.xyz_prev[3 * (size_t)pt]; X[1] = p.xyz_prev[3 * (size_t)pt + 1]; X[2] = p.xyz_prev[3 * (size_t)pt + 2];
+      // issued here (same dependency level as X) so that they are in flight across the barrier below
+#pragma unroll
+      for (int k = 0; k < 12; ++k) pr[k] = p.ptrec[12 * (size_t)pt + k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) spk[k] = p.sp[3 * (size_t)pt + k];
+      const CamGeom& g = s_geom_prev[slot];
+      if (g.free_index >= 0) {
+        double xw[3], Ac[2][6], Ap[2][3];
+        transform_point(g, X, xw);
+        projection_jacobians(g, X, xw, p.fx, p.fy, Ac, Ap);
+        const double* dc = p.delta_c + 6 * slot;
+        double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { t0 += Ac[0][k] * dc[k]; t1 += Ac[1][k] * dc[k]; }
+        const double m0 = p.rec_prev[0 * p.rec_stride + obs], m1 = p.rec_prev[1 * p.rec_stride + obs], m2 = p.rec_prev[2 * p.rec_stride + obs];
+        const double u0 = m0 * t0 + m1 * t1, u1 = m1 * t0 + m2 * t1;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) c3[k] = Ap[0][k] * u0 + Ap[1][k] * u1;
+      }
+    }
+    s_bs[threadIdx.x * 3 + 0] = c3[0]; s_bs[threadIdx.x * 3 + 1] = c3[1]; s_bs[threadIdx.x * 3 + 2] = c3[2];
+    lds_barrier();
+    if (active) {
+      double acc[3] = {0.0, 0.0, 0.0};
+      const double* src = s_bs + (half * 128 + l0) * 3;
+      for (int l = 0; l < cnt; ++l) { acc[0] += src[3 * l]; acc[1] += src[3 * l + 1]; acc[2] += src[3 * l + 2]; }
+      const double q0 = pr[6] + acc[0], q1 = pr[7] + acc[1], q2 = pr[8] + acc[2];
+      const double d[3] = {-(pr[0] * q0 + pr[1] * q1 + pr[2] * q2), -(pr[1] * q0 + pr[3] * q1 + pr[4] * q2),
+                           -(pr[2] * q0 + pr[4] * q1 + pr[5] * q2)};
+      const bool head = (lt == l0);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        if (head) {
+          const double sk = spk[k];
+          const double yk = -d[k] * fast_rcp(sk);             // step in Jacobi-scaled coordinates is -y
+          bs_mcc += 0.5 * yk * (sk * pr[6 + k]) + 0.5 * pr[9 + k] * yk * yk;
+          bs_st2 += d[k] * d[k];
+          bs_x2 += X[k] * X[k];
+          const_cast<double*>(p.xyz)[3 * (size_t)pt + k] = X[k] + d[k];
+        }
+        X[k] = X[k] + d[k];
+      }
+    }
+  } else if (active) {
+    pt = p.obs_point[obs];
+    slot = p.obs_slot[obs];
+    X[0] = p.xyz[3 * (size_t)pt]; X[1] = p.xyz[3 * (size_t)pt + 1]; X[2] = p.xyz[3 * (size_t)pt + 2];
+  }
+
+  // ---- phase 1: geometry, one lane per observation (fp64) ------------------------------------------------
   double u = 0.0, v = 0.0;
   float xf[W], yf[W];
   int bx = 0, by = 0;
   bool regular = false;
   if (active) {
-    pt = p.obs_point[obs];
-    slot = p.obs_slot[obs];
-    const double X[3] = {p.xyz[3 * (size_t)pt], p.xyz[3 * (size_t)pt + 1], p.xyz[3 * (size_t)pt + 2]};
     double xw[3];
-    transform_point(p.geom[slot], X, xw);
+    transform_point(s_geom[slot], X, xw);
     project_point(xw, p.fx, p.fy, p.cx, p.cy, u, v);
     // photobundle.cc:715-717: v + T(y), u + T(x) in double, rounded to float in SampleWithDerivative (:117-118)
     bool reg = true;
@@ -288,7 +429,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_sample(SampleParams p) {
     regular = reg;
   }
   s_base[wave][lane] = (active && regular) ? (int32_t)(slot * (p.rows * p.cols) + by * p.cols + bx) : -1;
-  __syncthreads();
+  lds_barrier();
 
   // ---- phase 2: cooperative footprint staging global -> LDS ----------------------------------------------
   // all loads of a batch are issued before the first LDS store so that the L2 latency is paid once per batch
@@ -297,21 +438,23 @@ __global__ __launch_bounds__(WAVES * 64) void k_sample(SampleParams p) {
 #pragma unroll 1
   for (int n0 = 0; n0 < FF; n0 += BATCH) {
     uint32_t tx[BATCH];
-    int oo[BATCH], tt[BATCH];
 #pragma unroll
     for (int k = 0; k < BATCH; ++k) {
       const int g = (n0 + k) * 64 + lane;
       const int o = g / FF;
       const int t = g - o * FF;
       const int base = s_base[wave][o];
-      oo[k] = o; tt[k] = t;
       tx[k] = 0;
       if (base >= 0) tx[k] = p.frames[(size_t)base + (t / F) * p.cols + (t % F)];
     }
 #pragma unroll
-    for (int k = 0; k < BATCH; ++k) s_tex[wave][tt[k] * LSTRIDE + oo[k]] = tx[k];
+    for (int k = 0; k < BATCH; ++k) {
+      const int g = (n0 + k) * 64 + lane;
+      const int o = g / FF;
+      s_tex[wave][(g - o * FF) * LSTRIDE + o] = tx[k];
+    }
   }
-  __syncthreads();
+  lds_barrier();
 
   // ---- phase 3: per-lane patch walk ------------------------------------------------------------------------
   double m11 = 0, m12 = 0, m22 = 0, b1 = 0, b2 = 0, cc = 0;
@@ -406,19 +549,84 @@ __global__ __launch_bounds__(WAVES * 64) void k_sample(SampleParams p) {
       p.rec[5 * p.rec_stride + obs] = cost_obs;
     }
   }
-  // deterministic block reduction (fixed tree)
-  s_red[threadIdx.x] = cost_obs;
-  __syncthreads();
-  for (int s = WAVES * 32; s > 0; s >>= 1) {
-    if ((int)threadIdx.x < s) s_red[threadIdx.x] += s_red[threadIdx.x + s];
-    __syncthreads();
+  // deterministic block reductions: butterfly inside each wave, then the waves in order
+  constexpr int NTH = WAVES * 64;
+  constexpr int NQ = FUSED ? 4 : 1;
+  double red_out[NQ];
+  {
+    double v[NQ];
+    v[0] = wave_sum(cost_obs);
+    if (FUSED) { v[NQ > 1 ? 1 : 0] = wave_sum(bs_mcc); v[NQ > 2 ? 2 : 0] = wave_sum(bs_st2); v[NQ > 3 ? 3 : 0] = wave_sum(bs_x2); }
+    if (lane == 0) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) s_red[q * WAVES + wave] = v[q];
+    }
+    lds_barrier();
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      double a = 0.0;
+#pragma unroll
+      for (int w = 0; w < WAVES; ++w) a += s_red[q * WAVES + w];
+      red_out[q] = a;
+    }
   }
   if (threadIdx.x == 0) {
-    p.block_cost[blockIdx.x] = s_red[0];
-    p.block_fail[blockIdx.x] = s_fail;
+    if (FUSED) {
+      // consumed by the last workgroup of THIS launch: write-through stores; a non-finite block poisons its cost
+      store_agent(p.block_cost + blockIdx.x, s_fail ? __longlong_as_double(0x7ff8000000000000ll) : red_out[0]);
+      store_agent(p.block_bs + 3 * blockIdx.x, red_out[NQ > 1 ? 1 : 0]);
+      store_agent(p.block_bs + 3 * blockIdx.x + 1, red_out[NQ > 2 ? 2 : 0]);
+      store_agent(p.block_bs + 3 * blockIdx.x + 2, red_out[NQ > 3 ? 3 : 0]);
+      p.block_fail[blockIdx.x] = s_fail;
+    } else {
+      p.block_cost[blockIdx.x] = red_out[0];
+      p.block_fail[blockIdx.x] = s_fail;
+    }
+  }
+  if (FUSED) {
+    // ---- step finalisation by the last workgroup to arrive (agent-scope release / acquire around the ticket) ----
+    __shared__ int s_last;
+    if (threadIdx.x == 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the write-through partials have left this CU
+      const unsigned t = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_last = (t == gridDim.x - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if (s_last) {
+      int* s_f = &s_base[0][0];                              // [NTH] ints, free by now
+      double* s_r4 = reinterpret_cast<double*>(&s_tex[0][0]);   // [4][NTH] doubles, free by now
+      double a0 = 0, a1 = 0, a2 = 0, a3 = 0; int f = 0;
+      for (int b = threadIdx.x; b < (int)gridDim.x; b += NTH) {
+        a0 += load_agent(p.block_bs + 3 * b); a1 += load_agent(p.block_bs + 3 * b + 1); a2 += load_agent(p.block_bs + 3 * b + 2);
+        const double c = load_agent(p.block_cost + b);
+        a3 += c; f |= (c != c) ? 1 : 0;
+      }
+      a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3);
+      f = __any(f) ? 1 : 0;
+      if (lane == 0) { s_r4[wave] = a0; s_r4[WAVES + wave] = a1; s_r4[2 * WAVES + wave] = a2; s_r4[3 * WAVES + wave] = a3; s_f[wave] = f; }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        for (int w = 1; w < WAVES; ++w) {
+          s_r4[0] += s_r4[w]; s_r4[WAVES] += s_r4[WAVES + w]; s_r4[2 * WAVES] += s_r4[2 * WAVES + w]; s_r4[3 * WAVES] += s_r4[3 * WAVES + w];
+          s_f[0] |= s_f[w];
+        }
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        p.scal[kMccPts] = s_r4[0]; p.scal[kStep2Pts] = s_r4[WAVES]; p.scal[kX2Pts] = s_r4[2 * WAVES];
+        p.scal[kCandCost] = s_r4[3 * WAVES]; p.scal[kEvalFailCand] = (double)s_f[0];
+        *p.ticket = 0;
+      }
+      if (p.host_scal) {
+        __syncthreads();
+        if (threadIdx.x < kNumScal) p.host_scal[threadIdx.x] = p.scal[threadIdx.x];
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) { *reinterpret_cast<volatile unsigned long long*>(p.host_seq) = p.seq; __threadfence_system(); }
+      }
+    }
   }
 }
-
 
 // =====================================================================================================
 // Schur elimination of the points (SchurEliminator::Eliminate restated for the device)
@@ -443,7 +651,7 @@ struct SchurParams {
   double* ptrec;                // [n_points][12]: P (6, sym packed 00 01 02 11 12 22), g_p (3), D_p^2 (3)
   double* partial;              // [gridDim.x][part_stride]
   int64_t rec_stride;
-  int32_t n_tiles;
+  int32_t n_tiles, n_frames;
   int32_t n_free;               // free cameras
   int32_t n_pairs;              // n_free (n_free + 1) / 2
   int32_t part_stride;          // 36 n_pairs + 3 * 6 n_free + 3
@@ -500,7 +708,9 @@ __global__ __launch_bounds__(kTile) void k_schur(SchurParams p) {
     const int obs = o0 + tid;
 
     for (int k = tid; k < n_pts * kMaxFrames; k += kTile) s_lane_of[k] = -1;
-    __syncthreads();
+    CamGeom* s_geom = reinterpret_cast<CamGeom*>(s_obs);   // P1 only; P2 overwrites the region with W | Y
+    stage_geom<kTile>(p.geom, s_geom, p.n_frames, tid);
+    lds_barrier();
 
     // ---- P1: per observation geometry and point-side contributions -----------------------------------
     int pt = 0, fa = -1, l0 = 0, l1 = 0;
@@ -512,7 +722,7 @@ __global__ __launch_bounds__(kTile) void k_schur(SchurParams p) {
       const int slot = p.obs_slot[obs];
       l0 = p.obs_l0[obs]; l1 = l0 + p.obs_cnt[obs];
       if (!p.init_scale) { s_pt[0] = p.sp[3 * (size_t)pt]; s_pt[1] = p.sp[3 * (size_t)pt + 1]; s_pt[2] = p.sp[3 * (size_t)pt + 2]; }
-      const CamGeom& g = p.geom[slot];
+      const CamGeom& g = s_geom[slot];
       fa = g.free_index;
       const double X[3] = {p.xyz[3 * (size_t)pt], p.xyz[3 * (size_t)pt + 1], p.xyz[3 * (size_t)pt + 2]};
       double xw[3];
@@ -534,7 +744,7 @@ __global__ __launch_bounds__(kTile) void k_schur(SchurParams p) {
       for (int k = 0; k < 3; ++k) vg[6 + k] = -(Ap[0][k] * b[0] + Ap[1][k] * b[1]);
       if (fa >= 0) s_lane_of[(pt - pt0) * kMaxFrames + fa] = (int8_t)tid;
     }
-    __syncthreads();
+    lds_barrier();
 
     // ---- P2: point totals, damping, effective inverse, per-observation Schur factors -------------------
     double rl[6] = {0, 0, 0, 0, 0, 0}, gcl[6] = {0, 0, 0, 0, 0, 0};
@@ -618,7 +828,7 @@ __global__ __launch_bounds__(kTile) void k_schur(SchurParams p) {
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
 
     // ---- P3a: block owners: T(a, b) -= Y_la W_lb^T over this group's points ----------------------------------
     if (owner) {
@@ -639,7 +849,7 @@ __global__ __launch_bounds__(kTile) void k_schur(SchurParams p) {
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
 
     // ---- P3b: camera-side sums: U_l = Ac^T M Ac into the diagonal blocks, rhs, g_c, diag(U) ---------------
     if (active && fa >= 0) {
@@ -654,7 +864,7 @@ __global__ __launch_bounds__(kTile) void k_schur(SchurParams p) {
 #pragma unroll
       for (int j = 0; j < 6; ++j) { so[21 + j] = rl[j]; so[27 + j] = gcl[j]; }
     }
-    __syncthreads();
+    lds_barrier();
     if (owner && pa == pb) {
       for (int q = grp; q < n_pts; q += n_groups) {
         const int la = s_lane_of[q * kMaxFrames + pa];
@@ -677,7 +887,7 @@ __global__ __launch_bounds__(kTile) void k_schur(SchurParams p) {
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
   }
 
   // ---- combine the point groups (fixed order), then per-block partials -----------------------------------
@@ -687,7 +897,7 @@ __global__ __launch_bounds__(kTile) void k_schur(SchurParams p) {
 #pragma unroll
     for (int k = 0; k < 36; ++k) dst[k] = acc[k];
   }
-  __syncthreads();
+  lds_barrier();
   if (owner && grp == 0) {
     for (int g = 1; g < n_groups; ++g) {
       const double* src = s_obs + ((g - 1) * p.n_pairs + pair) * 36;
@@ -703,25 +913,19 @@ __global__ __launch_bounds__(kTile) void k_schur(SchurParams p) {
     out[36 * p.n_pairs + n + tid] = acc_gc;
     out[36 * p.n_pairs + 2 * n + tid] = acc_du;
   }
-  __syncthreads();
-  // block reductions of the point-gradient statistics (fixed tree)
-  s_red[tid] = gn2;
-  __syncthreads();
-  for (int s = kTile / 2; s > 0; s >>= 1) { if (tid < s) s_red[tid] += s_red[tid + s]; __syncthreads(); }
-  const double gn2_b = s_red[0];
-  __syncthreads();
-  s_red[tid] = gmax;
-  __syncthreads();
-  for (int s = kTile / 2; s > 0; s >>= 1) { if (tid < s) s_red[tid] = fmax(s_red[tid], s_red[tid + s]); __syncthreads(); }
-  const double gmax_b = s_red[0];
-  __syncthreads();
-  s_red[tid] = (double)fail;
-  __syncthreads();
-  for (int s = kTile / 2; s > 0; s >>= 1) { if (tid < s) s_red[tid] = fmax(s_red[tid], s_red[tid + s]); __syncthreads(); }
-  if (tid == 0) {
-    out[36 * p.n_pairs + 3 * n + 0] = gmax_b;
-    out[36 * p.n_pairs + 3 * n + 1] = gn2_b;
-    out[36 * p.n_pairs + 3 * n + 2] = s_red[0];
+  lds_barrier();
+  // block reductions of the point-gradient statistics (butterfly per wave, then the two waves in order)
+  {
+    const double g2 = wave_sum(gn2), gm = wave_max(gmax), fl = wave_max((double)fail);
+    if ((tid & 63) == 0) { s_red[(tid >> 6) * 3] = g2; s_red[(tid >> 6) * 3 + 1] = gm; s_red[(tid >> 6) * 3 + 2] = fl; }
+    lds_barrier();
+    if (tid == 0) {
+      double a = 0.0, m = 0.0, f = 0.0;
+      for (int w = 0; w < kTile / 64; ++w) { a += s_red[3 * w]; m = fmax(m, s_red[3 * w + 1]); f = fmax(f, s_red[3 * w + 2]); }
+      out[36 * p.n_pairs + 3 * n + 0] = m;
+      out[36 * p.n_pairs + 3 * n + 1] = a;
+      out[36 * p.n_pairs + 3 * n + 2] = f;
+    }
   }
 }
 
@@ -788,7 +992,8 @@ struct SolveParams {
   double* rhs_dbg;          // [n]
   double* scal;
   const CamGeom* geom;      // current geometry (free_index of every slot)
-  int32_t n_frames, n_free, n_pairs, stride;
+  CamGeom* geom_cand;       // candidate geometry output (null: produced elsewhere)
+  int32_t n_frames, n_free, n_pairs, stride, fixed_slot;
   int32_t init_scale, jacobi;
   double radius, min_diag, max_diag;
 };
@@ -852,6 +1057,16 @@ __device__ __forceinline__ void solve_epilogue(const SolveParams& p, int n, cons
     if (fa >= 0) d = -sc[6 * fa + k] * y[6 * fa + k];
     p.delta_c[tid] = d;
     p.cams_cand[tid] = p.cams[tid] + d;
+  }
+  if (p.geom_cand) {
+    // candidate camera geometry by the last wave (reads cams + delta directly: no dependency on the stores above)
+    const int c = tid - (T - 64);
+    if (c >= 0 && c < p.n_frames) {
+      double cam6[6];
+      const int fa = p.geom[c].free_index;
+      for (int k = 0; k < 6; ++k) cam6[k] = p.cams[6 * c + k] + (fa >= 0 ? -sc[6 * fa + k] * y[6 * fa + k] : 0.0);
+      cam_geom_one(cam6 - 6 * c, p.geom_cand, c, p.fixed_slot);
+    }
   }
   if (tid < 64) {
     double mcc = 0.0, st2 = 0.0, x2 = 0.0, gmax = 0.0, gn2 = 0.0, bad = 0.0;
@@ -1021,7 +1236,7 @@ __global__ __launch_bounds__(256) void k_backsub(BacksubParams p) {
   __shared__ double s_red[3][256];
   const int tid = threadIdx.x;
   const int pt = blockIdx.x * 256 + tid;
-  if (blockIdx.x == gridDim.x - 1 && tid >= 256 - p.n_frames) cam_geom_one(p.cams_cand, p.geom_cand, 255 - tid, p.fixed_slot);
+  if (p.geom_cand && blockIdx.x == gridDim.x - 1 && tid >= 256 - p.n_frames) cam_geom_one(p.cams_cand, p.geom_cand, 255 - tid, p.fixed_slot);
   double mcc = 0.0, st2 = 0.0, x2 = 0.0;
   if (pt < p.n_points) {
     const double X[3] = {p.xyz[3 * (size_t)pt], p.xyz[3 * (size_t)pt + 1], p.xyz[3 * (size_t)pt + 2]};
