@@ -1,0 +1,89 @@
+// run_kitti.cc -- the reference's driver loop (reference apps/run_kitti.cc:17-59) on the MI355X engine.
+//
+// OpenCV / the stereo matcher are outside the hot path and absent from this image, so frames come from a directory
+// of precomputed inputs instead of Dataset::Create:
+//     <data>/image_%06d.pgm   binary PGM (P5, 8 bit)
+//     <data>/depth_%06d.bin   rows*cols float32 depth map (what disparityToDepth would hand over; <= 0 invalid)
+//     <data>/calib.txt        fx fy cx cy baseline
+// The config file is the reference's (config/kitti_stereo.cfg keys) plus `DataDirectory`; `Trajectory` is the KITTI
+// pose text file of frame-to-frame initial poses (reference data/kitti_init_poor/*.txt).
+#include <csignal>
+#include <cstdio>
+#include <fstream>
+#include <string>
+#include <vector>
+
+#include "../host/photobundle.h"
+#include "../host/pose_utils.h"
+#include "../host/utils.h"
+
+static volatile bool gStop = false;
+static void sigHandler(int) { gStop = true; }
+
+static bool readPgm(const std::string& fn, std::vector<uint8_t>& img, int& rows, int& cols) {
+  std::ifstream ifs(fn, std::ios::binary);
+  if (!ifs.is_open()) return false;
+  std::string magic;
+  int maxval = 0;
+  ifs >> magic;
+  if (magic != "P5") return false;
+  auto skip = [&]() { while (ifs.peek() == '#' || std::isspace(ifs.peek())) { if (ifs.peek() == '#') { std::string l; std::getline(ifs, l); } else ifs.get(); } };
+  skip(); ifs >> cols; skip(); ifs >> rows; skip(); ifs >> maxval;
+  ifs.get();
+  if (maxval != 255) return false;
+  img.resize((size_t)rows * cols);
+  ifs.read(reinterpret_cast<char*>(img.data()), img.size());
+  return (bool)ifs;
+}
+
+int main(int argc, char** argv) {
+  signal(SIGINT, sigHandler);
+  std::string config = "../config/kitti_stereo.cfg", output = "refined_poses.txt";
+  for (int i = 1; i < argc; ++i) {
+    const std::string a = argv[i];
+    if ((a == "-c" || a == "--config") && i + 1 < argc) config = argv[++i];
+    else if ((a == "-o" || a == "--output") && i + 1 < argc) output = argv[++i];
+    else { std::fprintf(stderr, "usage: %s [-c config] [-o output]\n", argv[0]); return 1; }
+  }
+  try {
+    utils::ConfigFile cf(config);
+    const std::string data = cf.get<std::string>("DataDirectory");
+    double c5[5];
+    {
+      std::ifstream ifs(data + "/calib.txt");
+      if (!(ifs >> c5[0] >> c5[1] >> c5[2] >> c5[3] >> c5[4])) throw std::runtime_error("bad calib.txt");
+    }
+    Calibration calib;
+    calib.setParameters(c5);
+    calib.baseline() = c5[4];
+    const auto T_init = loadPosesKittiFormat(cf.get<std::string>("trajectory"));
+
+    std::vector<uint8_t> img;
+    std::vector<float> depth;
+    int rows = 0, cols = 0;
+    char name[64];
+    std::snprintf(name, sizeof(name), "/image_%06d.pgm", 0);
+    if (!readPgm(data + name, img, rows, cols)) throw std::runtime_error("cannot read the first frame");
+
+    PhotometricBundleAdjustment::Result result;
+    PhotometricBundleAdjustment photoba(calib, ImageSize(rows, cols), {cf});
+    for (int f_i = 0; f_i < (int)T_init.size() && !gStop; ++f_i) {
+      std::snprintf(name, sizeof(name), "/image_%06d.pgm", f_i);
+      int r2, c2;
+      if (!readPgm(data + name, img, r2, c2)) break;
+      if (r2 != rows || c2 != cols) throw std::runtime_error("frame size changed");
+      std::snprintf(name, sizeof(name), "/depth_%06d.bin", f_i);
+      depth.resize((size_t)rows * cols);
+      std::ifstream dfs(data + name, std::ios::binary);
+      if (!dfs.read(reinterpret_cast<char*>(depth.data()), depth.size() * sizeof(float))) throw std::runtime_error("bad depth file");
+      std::printf("Frame %05d\n", f_i);
+      photoba.addFrame(img.data(), depth.data(), T_init[f_i], &result);
+    }
+    std::fprintf(stderr, "Writing refined poses to %s\n", output.c_str());
+    writePosesKittiFormat(output, result.poses);
+  } catch (const std::exception& ex) {
+    std::fprintf(stderr, "error: %s\n", ex.what());
+    return 1;
+  }
+  return 0;
+}

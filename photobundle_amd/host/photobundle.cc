@@ -1,0 +1,429 @@
+// photobundle.cc -- PhotometricBundleAdjustment on the MI355X engine.
+//
+// addFrame() restates the reference's CPU front-end (reference src/photobundle.cc:482-615: trajectory update,
+// ZNCC visibility test, saliency non-maximum selection, descriptor extraction); optimize() assembles the same
+// problem the reference hands to Ceres (reference :764-876) and solves it through the C-ABI of include/pba.h.
+#include "photobundle.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <stdexcept>
+
+#include "../../include/pba.h"
+#include "utils.h"
+
+namespace {
+
+typedef PhotometricBundleAdjustment::Options::DescriptorType DescriptorType;
+
+DescriptorType DescriptorTypeFromString(std::string s) {
+  std::transform(s.begin(), s.end(), s.begin(), [](unsigned char c) { return std::tolower(c); });
+  if (s == "intensity") return DescriptorType::Intensity;
+  if (s == "intensityandgradient") return DescriptorType::IntensityAndGradient;
+  if (s == "bitplanes") return DescriptorType::BitPlanes;
+  std::fprintf(stderr, "unknown descriptorType %s, using Intensity\n", s.c_str());
+  return DescriptorType::Intensity;
+}
+
+inline int PatchSizeFromRadius(int r) { return (2 * r + 1) * (2 * r + 1); }
+
+// reference photobundle.cc:262-294: floor-based bilinear lookup with fill value at the far border
+template <class Image>
+inline float interp2(const Image& I, float xf, float yf, float fillval = 0.0f) {
+  const int max_cols = I.cols() - 1, max_rows = I.rows() - 1;
+  const int xi = (int)std::floor(xf), yi = (int)std::floor(yf);
+  xf -= xi; yf -= yi;
+  if (xi >= 0 && xi < max_cols && yi >= 0 && yi < max_rows) {
+    const float wx = 1.0 - xf;
+    return (1.0 - yf) * (I(yi, xi) * wx + I(yi, xi + 1) * xf) + yf * (I(yi + 1, xi) * wx + I(yi + 1, xi + 1) * xf);
+  }
+  if (xi == max_cols && yi < max_rows) return (xf > 0) ? fillval : (1.0 - yf) * I(yi, xi) + yf * I(yi + 1, xi);
+  if (yi == max_rows && xi < max_cols) return (yf > 0) ? fillval : (1.0 - xf) * I(yi, xi) + xf * I(yi, xi + 1);
+  if (xi == max_cols && yi == max_rows) return (xf > 0 || yf > 0) ? fillval : I(yi, xi);
+  return fillval;
+}
+
+// reference photobundle.cc:315-361 ZnccPatch_<2, float>
+struct ZnccPatch {
+  static constexpr int R = 2, N = 25;
+  float data[N];
+  float norm = 0.f;
+  template <class Image>
+  void set(const Image& I, double u, double v) {
+    const float x = (float)u, y = (float)v;
+    int k = 0;
+    for (int r = -R; r <= R; ++r) for (int c = -R; c <= R; ++c) data[k++] = interp2(I, c + x, r + y, 0.0f);
+    float sum = 0.f;
+    for (int i = 0; i < N; ++i) sum += data[i];
+    const float mean = sum / (float)N;
+    float n2 = 0.f;
+    for (int i = 0; i < N; ++i) { data[i] -= mean; n2 += data[i] * data[i]; }
+    norm = std::sqrt(n2);
+  }
+  float score(const ZnccPatch& o) const {
+    const float d = norm * o.norm;
+    if (!(d > 1e-6)) return -1.0f;
+    float dot = 0.f;
+    for (int i = 0; i < N; ++i) dot += data[i] * o.data[i];
+    return dot / d;
+  }
+};
+
+// view of the caller's u8 frame with the Eigen-map call syntax
+struct U8View {
+  const uint8_t* p; int rows_, cols_;
+  int rows() const { return rows_; }
+  int cols() const { return cols_; }
+  float operator()(int r, int c) const { return (float)p[(size_t)r * cols_ + c]; }
+};
+
+// reference photobundle.cc:617-644
+std::vector<double> MakePatchWeights(int radius, bool do_gaussian) {
+  const int n = PatchSizeFromRadius(radius);
+  std::vector<double> ret(n, 1.0);
+  if (!do_gaussian) return ret;
+  double sum = 0.0;
+  for (int r = -radius, i = 0; r <= radius; ++r)
+    for (int c = -radius; c <= radius; ++c, ++i) { ret[i] = std::exp(-0.5 * ((double)(r * r) + (double)(c * c))); sum += ret[i]; }
+  for (double& w : ret) w /= sum;
+  return ret;
+}
+
+// reference photobundle.cc:646-667 with the Ceres rotation.h conventions (matrix -> quaternion -> angle-axis)
+void PoseToParams(const Mat44& T, double* p) {
+  double q[4];
+  const double trace = T(0, 0) + T(1, 1) + T(2, 2);
+  if (trace >= 0.0) {
+    double t = std::sqrt(trace + 1.0);
+    q[0] = 0.5 * t; t = 0.5 / t;
+    q[1] = (T(2, 1) - T(1, 2)) * t; q[2] = (T(0, 2) - T(2, 0)) * t; q[3] = (T(1, 0) - T(0, 1)) * t;
+  } else {
+    int i = 0;
+    if (T(1, 1) > T(0, 0)) i = 1;
+    if (T(2, 2) > T(i, i)) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    double t = std::sqrt(T(i, i) - T(j, j) - T(k, k) + 1.0);
+    q[i + 1] = 0.5 * t; t = 0.5 / t;
+    q[0] = (T(k, j) - T(j, k)) * t; q[j + 1] = (T(j, i) + T(i, j)) * t; q[k + 1] = (T(k, i) + T(i, k)) * t;
+  }
+  const double s2 = q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+  double k = 2.0;
+  if (s2 > 0.0) {
+    const double s = std::sqrt(s2);
+    const double two_theta = 2.0 * ((q[0] < 0.0) ? std::atan2(-s, -q[0]) : std::atan2(s, q[0]));
+    k = two_theta / s;
+  }
+  p[0] = q[1] * k; p[1] = q[2] * k; p[2] = q[3] * k;
+  p[3] = T(0, 3); p[4] = T(1, 3); p[5] = T(2, 3);
+}
+
+Mat44 ParamsToPose(const double* p) {
+  Mat44 T = Mat44::Identity();
+  const double theta2 = p[0] * p[0] + p[1] * p[1] + p[2] * p[2];
+  if (theta2 > 2.220446049250313e-16) {
+    const double theta = std::sqrt(theta2);
+    const double wx = p[0] / theta, wy = p[1] / theta, wz = p[2] / theta;
+    const double c = std::cos(theta), s = std::sin(theta), oc = 1.0 - c;
+    T(0, 0) = c + wx * wx * oc;       T(1, 0) = wz * s + wx * wy * oc;  T(2, 0) = -wy * s + wx * wz * oc;
+    T(0, 1) = wx * wy * oc - wz * s;  T(1, 1) = c + wy * wy * oc;       T(2, 1) = wx * s + wy * wz * oc;
+    T(0, 2) = wy * s + wx * wz * oc;  T(1, 2) = -wx * s + wy * wz * oc; T(2, 2) = c + wz * wz * oc;
+  } else {
+    T(0, 0) = 1; T(1, 0) = p[2]; T(2, 0) = -p[1];
+    T(0, 1) = -p[2]; T(1, 1) = 1; T(2, 1) = p[0];
+    T(0, 2) = p[1]; T(1, 2) = -p[0]; T(2, 2) = 1;
+  }
+  T(0, 3) = p[3]; T(1, 3) = p[4]; T(2, 3) = p[5];
+  return T;
+}
+
+void check(pba_engine* e, int rc, const char* what) {
+  if (rc != PBA_OK)
+    throw std::runtime_error(std::string(what) + ": " + pba_status_string(rc) + " (" + (e ? pba_last_error(e) : "") + ")");
+}
+
+}  // namespace
+
+PhotometricBundleAdjustment::Options::Options(const utils::ConfigFile& cf)
+    : maxNumPoints(cf.get<int>("maxNumPoints", 4096)),
+      slidingWindowSize(cf.get<int>("slidingWindowSize", 5)),
+      patchRadius(cf.get<int>("patchRadius", 2)),
+      maskBlockRadius(cf.get<int>("maskBlockRadius", 1)),
+      maxFrameDistance(cf.get<int>("maxFrameDistance", 1)),
+      numThreads(cf.get<int>("numThreads", -1)),
+      doGaussianWeighting((bool)cf.get<int>("doGaussianWeighting", 0)),
+      verbose((bool)cf.get<int>("verbose", 1)),
+      minScore(cf.get<double>("minScore", 0.75)),
+      robustThreshold(cf.get<double>("robustThreshold", 0.05)),
+      minValidDepth(cf.get<double>("minValidDepth", 0.01)),
+      maxValidDepth(cf.get<double>("maxValidDepth", 1000.0)),
+      nonMaxSuppRadius(cf.get<int>("nonMaxSuppRadius", 1)),
+      descriptorType(DescriptorTypeFromString(cf.get<std::string>("descriptorType", "Intensity"))),
+      device(cf.get<int>("device", 0)) {}
+
+bool PhotometricBundleAdjustment::Result::Writer::add(const Result&) {
+  std::fprintf(stderr, "Result::Writer needs cereal (dead code in the reference's default build too)\n");
+  ++_counter;
+  return false;
+}
+PhotometricBundleAdjustment::Result PhotometricBundleAdjustment::Result::FromFile(std::string) {
+  throw std::runtime_error("Result::FromFile needs cereal (dead code in the reference's default build too)");
+}
+
+// reference photobundle.cc:151-257: one float channel (Intensity) + its gradient magnitude for the saliency map.
+struct PhotometricBundleAdjustment::DescriptorFrame {
+  uint32_t id;
+  Image_<float> I;
+  DescriptorFrame(uint32_t frame_id, const uint8_t* img, int rows, int cols) : id(frame_id), I(rows, cols) {
+    for (size_t i = 0; i < (size_t)rows * cols; ++i) I.d[i] = (float)img[i];
+  }
+  // computeSaliencyMap (:213-221) = |Ix| + |Iy| with imgradient semantics (imgproc.cc:27-95)
+  void computeSaliencyMap(Image_<float>& smap) const {
+    const int rows = I.rows(), cols = I.cols();
+    std::fill(smap.d.begin(), smap.d.end(), 0.0f);
+    for (int y = 1; y < rows - 1; ++y)
+      for (int x = 1; x < cols - 1; ++x) {
+        const float ix = 0.5f * (I(y, x + 1) - I(y, x - 1));
+        const float iy = 0.5f * (I(y + 1, x) - I(y - 1, x));
+        smap(y, x) = std::fabs(ix) + std::fabs(iy);
+      }
+  }
+};
+
+// reference photobundle.cc:366-446
+struct PhotometricBundleAdjustment::ScenePoint {
+  Vec3 X, X_original;
+  std::vector<uint32_t> f;
+  ZnccPatch patch;
+  std::vector<double> descriptor;
+  double saliency = 0.0;
+  bool was_refined = false;
+  int x0 = 0, y0 = 0;
+  ScenePoint(const Vec3& X_, uint32_t f_id) : X(X_), X_original(X_) { f.reserve(8); f.push_back(f_id); }
+  uint32_t refFrameId() const { return f.front(); }
+  uint32_t lastFrameId() const { return f.back(); }
+  size_t numFrames() const { return f.size(); }
+};
+
+PhotometricBundleAdjustment::PhotometricBundleAdjustment(const Calibration& calib, const ImageSize& image_size,
+                                                         const Options& options)
+    : _calib(calib), _image_size(image_size), _options(options) {
+  if (options.descriptorType != Options::DescriptorType::Intensity)
+    throw std::runtime_error("only DescriptorType::Intensity is implemented (the reference's multi-channel path asserts, "
+                             "photobundle.cc:684)");
+  _mask.resize(_image_size.rows, _image_size.cols);
+  _saliency_map.resize(_image_size.rows, _image_size.cols);
+  _K_inv = calib.K().inverse();
+  pba_config cfg;
+  std::memset(&cfg, 0, sizeof(cfg));
+  cfg.rows = image_size.rows; cfg.cols = image_size.cols;
+  cfg.max_frames = options.slidingWindowSize; cfg.radius = options.patchRadius;
+  cfg.fx = calib.fx(); cfg.fy = calib.fy(); cfg.cx = calib.cx(); cfg.cy = calib.cy();
+  cfg.huber = options.robustThreshold; cfg.device = options.device; cfg.flags = 0;
+  check(nullptr, pba_create(&cfg, &_engine), "pba_create");
+}
+
+PhotometricBundleAdjustment::~PhotometricBundleAdjustment() { pba_destroy(_engine); }
+
+void PhotometricBundleAdjustment::addFrame(const uint8_t* I_ptr, const float* Z_ptr, const Mat44& T, Result* result) {
+  _trajectory.push_back(T, _frame_id);
+  const Mat44 T_w = _trajectory.back();
+  const Mat44 T_c = T_w.inverse();
+  const int rows = _image_size.rows, cols = _image_size.cols;
+  const U8View I{I_ptr, rows, cols};
+
+  UniquePointer<DescriptorFrame> frame(new DescriptorFrame(_frame_id, I_ptr, rows, cols));
+  // the engine keeps its own device plane of this frame in the ring slot id % window
+  const int window = _options.slidingWindowSize;
+  check(_engine, pba_set_frame_u8(_engine, (int)(_frame_id % window), I_ptr), "pba_set_frame_u8");
+
+  const int B = std::max(_options.maskBlockRadius, std::max(2, _options.patchRadius));
+  const int max_rows = rows - B - 1, max_cols = cols - B - 1;
+  const int radius = _options.patchRadius, patch_length = PatchSizeFromRadius(radius);
+  const int mask_radius = _options.maskBlockRadius;
+
+  // ---- visibility list update (reference :505-542) ------------------------------------------------------------
+  std::fill(_mask.d.begin(), _mask.d.end(), (uint16_t)1);
+  int num_updated = 0, max_num_to_update = 0;
+  for (auto& pt : _scene_points) {
+    const int f_dist = (int)_frame_id - (int)pt->lastFrameId();
+    if (f_dist <= _options.maxFrameDistance) {
+      const Vec2 uv = _calib.project(TransformPoint(T_c, pt->X));
+      ++max_num_to_update;
+      const int r = (int)std::round(uv[1]), c = (int)std::round(uv[0]);
+      if (r >= B && r < max_rows && c >= B && c <= max_cols) {
+        ZnccPatch other;
+        other.set(I, uv[0], uv[1]);
+        if (pt->patch.score(other) > _options.minScore) {
+          ++num_updated;
+          pt->f.push_back(_frame_id);
+          for (int r_i = -mask_radius; r_i <= mask_radius; ++r_i)
+            for (int c_i = -mask_radius; c_i <= mask_radius; ++c_i) _mask(r + r_i, c + c_i) = 0;
+        }
+      }
+    }
+  }
+
+  // ---- new scene points (reference :545-585): valid depth AND strict local maximum of the saliency under the mask --
+  ScenePointPointerList new_points;
+  frame->computeSaliencyMap(_saliency_map);
+  const int nms = _options.nonMaxSuppRadius;
+  auto is_local_max = [&](int row, int col) {
+    if (nms > 0) {
+      const float v = _saliency_map(row, col);
+      if (!_mask(row, col) || v < 0.0f) return false;
+      for (int r = -nms; r <= nms; ++r)
+        for (int c = -nms; c <= nms; ++c)
+          if (!(!r && !c) && _saliency_map(r + row, c + col) >= v) return false;
+    }
+    return true;
+  };
+  for (int y = B; y < max_rows; ++y) {
+    for (int x = B; x < max_cols; ++x) {
+      const float z = Z_ptr[(size_t)y * cols + x];
+      if (z >= _options.minValidDepth && z <= _options.maxValidDepth && is_local_max(y, x)) {
+        const Vec3 ray = _K_inv * MakeVec3((double)x, (double)y, 1.0);
+        const Vec3 X = TransformPoint(T_w, MakeVec3((double)z * ray[0], (double)z * ray[1], (double)z * ray[2]));
+        ScenePointPointer p(new ScenePoint(X, _frame_id));
+        p->patch.set(I, (double)x, (double)y);
+        p->descriptor.resize(patch_length);
+        p->saliency = _saliency_map(y, x);
+        p->x0 = x; p->y0 = y;
+        new_points.push_back(std::move(p));
+      }
+    }
+  }
+  if (new_points.size() > (size_t)_options.maxNumPoints) {
+    auto nth = new_points.begin() + _options.maxNumPoints;
+    std::nth_element(new_points.begin(), nth, new_points.end(),
+                     [](const ScenePointPointer& a, const ScenePointPointer& b) { return a->saliency > b->saliency; });
+    new_points.erase(nth, new_points.end());
+  }
+  std::fprintf(stderr, "updated %d [%0.2f%%] max %d new %d\n", num_updated,
+               _scene_points.empty() ? 0.0 : 100.0 * num_updated / _scene_points.size(), max_num_to_update, (int)new_points.size());
+
+  // ---- descriptors (reference :466-479, :597-603): integer-pixel patch, indices clamped ------------------------
+  {
+    const int mc = cols - radius - 1, mr = rows - radius - 1;
+    for (auto& p : new_points) {
+      int i = 0;
+      for (int r = -radius; r <= radius; ++r) {
+        const int r_i = std::max(radius, std::min(p->y0 + r, mr));
+        for (int c = -radius; c <= radius; ++c, ++i) {
+          const int c_i = std::max(radius, std::min(p->x0 + c, mc));
+          p->descriptor[i] = (double)frame->I(r_i, c_i);
+        }
+      }
+    }
+  }
+  for (auto& p : new_points) _scene_points.push_back(std::move(p));
+
+  if ((int)_frame_buffer.size() == window) _frame_buffer.erase(_frame_buffer.begin());
+  _frame_buffer.push_back(std::move(frame));
+  if ((int)_frame_buffer.size() == window) optimize(result);
+  ++_frame_id;
+}
+
+void PhotometricBundleAdjustment::optimize(Result* result) {
+  const uint32_t frame_id_start = _frame_buffer.front()->id, frame_id_end = _frame_buffer.back()->id;
+  const int window = _options.slidingWindowSize;
+  const std::vector<double> patch_weights = MakePatchWeights(_options.patchRadius, _options.doGaussianWeighting);
+  const int P = (int)patch_weights.size();
+
+  // cameras: INVERTED world poses as angle-axis + t (reference :774-778), stored by ring slot id % window
+  std::vector<double> cams(6 * (size_t)window, 0.0);
+  for (uint32_t id = frame_id_start; id <= frame_id_end; ++id)
+    PoseToParams(_trajectory.atId((int)id).inverse(), &cams[6 * (id % window)]);
+
+  // points with >= 3 observations whose reference frame is inside the window; one block per visible frame (:786-806)
+  std::vector<ScenePoint*> selected;
+  std::vector<double> xyz, desc;
+  std::vector<int32_t> obs_point, obs_slot;
+  for (auto& pt : _scene_points) {
+    if (pt->numFrames() >= 3 && pt->refFrameId() >= frame_id_start) {
+      std::vector<int32_t> slots;
+      for (uint32_t id : pt->f) if (id >= frame_id_start && id <= frame_id_end) slots.push_back((int32_t)(id % window));
+      if (slots.empty()) continue;
+      std::sort(slots.begin(), slots.end());
+      pt->was_refined = true;
+      const int32_t idx = (int32_t)selected.size();
+      selected.push_back(pt.get());
+      for (int k = 0; k < 3; ++k) xyz.push_back(pt->X[k]);
+      desc.insert(desc.end(), pt->descriptor.begin(), pt->descriptor.end());
+      for (int32_t s : slots) { obs_point.push_back(idx); obs_slot.push_back(s); }
+    }
+  }
+  std::fprintf(stderr, "Using %d points (%d residual blocks) [id start %d]\n", (int)selected.size(), (int)obs_point.size(), (int)frame_id_start);
+
+  pba_solver_summary summary;
+  std::memset(&summary, 0, sizeof(summary));
+  std::vector<pba_iteration_summary> its(512);
+  if (!selected.empty()) {
+    check(_engine, pba_set_problem(_engine, (int32_t)selected.size(), xyz.data(), desc.data(), (int32_t)obs_point.size(),
+                                  obs_point.data(), obs_slot.data(), patch_weights.data()), "pba_set_problem");
+    check(_engine, pba_set_cameras(_engine, cams.data(), window, (int32_t)(frame_id_start % window)), "pba_set_cameras");
+    pba_solver_options so;
+    pba_default_solver_options(&so);     // GetSolverOptions (:738-761)
+    so.verbose = _options.verbose ? 1 : 0;
+    check(_engine, pba_solve(_engine, &so, &summary, its.data(), (int32_t)its.size()), "pba_solve");
+    if (_options.verbose)
+      std::printf("pba_solve: %s  initial %.6e  final %.6e  iterations %d (successful %d)  %.3f s\n", summary.message,
+                  summary.initial_cost, summary.final_cost, summary.num_iterations, summary.num_successful_steps,
+                  summary.total_time_in_seconds);
+    check(_engine, pba_get_state(_engine, cams.data(), xyz.data()), "pba_get_state");
+    for (size_t i = 0; i < selected.size(); ++i) for (int k = 0; k < 3; ++k) selected[i]->X[k] = xyz[3 * i + k];
+    // put back the refined camera poses (:841-844)
+    for (uint32_t id = frame_id_start; id <= frame_id_end; ++id)
+      _trajectory.atId((int)id) = ParamsToPose(&cams[6 * (id % window)]).inverse();
+  } else {
+    std::fprintf(stderr, "first camera is not in bundle\n");
+  }
+  (void)P;
+
+  auto points_to_remove = removePointsAtFrame(frame_id_start);
+  std::printf("removing %zu old points\n", points_to_remove.size());
+
+  if (result) {
+    result->poses = _trajectory.poses();
+    const size_t npts = points_to_remove.size();
+    result->refinedPoints.resize(npts);
+    result->originalPoints.resize(npts);
+    for (size_t i = 0; i < npts; ++i) { result->refinedPoints[i] = points_to_remove[i]->X; result->originalPoints[i] = points_to_remove[i]->X_original; }
+    result->initialCost = summary.initial_cost;
+    result->finalCost = summary.final_cost;
+    result->fixedCost = summary.fixed_cost;
+    result->numSuccessfulStep = summary.num_successful_steps;
+    result->totalTime = summary.total_time_in_seconds;
+    result->numResiduals = summary.num_residuals;
+    result->message = summary.message;
+    result->iterationSummary.clear();
+    for (int i = 0; i < summary.num_iterations; ++i) {
+      const pba_iteration_summary& s = its[i];
+      ceres::IterationSummary o;
+      o.iteration = s.iteration; o.step_is_valid = s.step_is_valid; o.step_is_nonmonotonic = s.step_is_nonmonotonic;
+      o.step_is_successful = s.step_is_successful; o.cost = s.cost; o.cost_change = s.cost_change;
+      o.gradient_max_norm = s.gradient_max_norm; o.gradient_norm = s.gradient_norm; o.step_norm = s.step_norm;
+      o.relative_decrease = s.relative_decrease; o.trust_region_radius = s.trust_region_radius; o.eta = s.eta;
+      o.step_size = s.step_size; o.linear_solver_iterations = s.linear_solver_iterations;
+      o.iteration_time_in_seconds = s.iteration_time_in_seconds; o.step_solver_time_in_seconds = s.step_solver_time_in_seconds;
+      o.cumulative_time_in_seconds = s.cumulative_time_in_seconds;
+      result->iterationSummary.push_back(o);
+    }
+  }
+}
+
+const PhotometricBundleAdjustment::DescriptorFrame* PhotometricBundleAdjustment::getFrameAtId(uint32_t id) const {
+  for (const auto& f : _frame_buffer) if (f->id == id) return f.get();
+  throw std::runtime_error("could not find frame id!");
+}
+
+// reference :888-905: everything whose reference frame is <= id leaves the system
+PhotometricBundleAdjustment::ScenePointPointerList PhotometricBundleAdjustment::removePointsAtFrame(uint32_t id) {
+  ScenePointPointerList keep, remove;
+  for (auto& p : _scene_points) (p->refFrameId() <= id ? remove : keep).push_back(std::move(p));
+  _scene_points.swap(keep);
+  return remove;
+}
