@@ -306,7 +306,7 @@ struct SampleParams {
 //                (SchurEliminator::BackSubstitute), samples at the candidate it just formed, and the last workgroup
 //                to finish reduces the per-block partials in a fixed order and publishes the step's scalar block.
 template <int R, bool JAC, int WAVES, bool FUSED>
-__global__ __launch_bounds__(WAVES * 64, (R <= 2 ? 4 : 1)) void k_sample(SampleParams p) {
+__global__ __launch_bounds__(WAVES * 64, (R <= 2 ? (JAC ? 3 : 2) : 1)) void k_sample(SampleParams p) {
   static_assert(!FUSED || (WAVES * 64) % 128 == 0, "fused tiles are 128 observations");
   constexpr int W = 2 * R + 1;      // patch side
   constexpr int F = 2 * R + 2;      // footprint side
