@@ -71,6 +71,8 @@ struct pba_engine {
   int schur_grid = 0, sample_grid = 0, backsub_grid = 0, sample_waves = 4, fused_grid = 0;
   bool fuse = true;                 // back-substitution + finalisation fused into the candidate pass (radius <= 3)
   unsigned int* d_ticket = nullptr;
+  unsigned long long* d_dbg = nullptr;   // PBA_SCHUR_TIMING diagnostics
+  int dbg_left = 0;
   int n_pairs = 0, part_stride = 0;
   static constexpr int kChunks = 32;
 
@@ -135,7 +137,7 @@ bool fused_capable(const pba_engine* e) { return e->cfg.radius <= 3 && e->fuse; 
 int sample_waves_for_radius(int R) { return (R <= 2) ? 4 : (R == 3 ? 2 : 1); }
 
 size_t schur_smem_bytes() {
-  return sizeof(double) * (kTile * kObsStride + kTile * 9 + kTile) + kTile * kMaxFrames;
+  return sizeof(double) * (kTile * kObsStride + kTile) + kTile * kMaxFrames;
 }
 
 template <int NF>
@@ -274,6 +276,7 @@ int pba_create(const pba_config* cfg, pba_engine** out) {
   if (hipHostGetDevicePointer(reinterpret_cast<void**>(&e->h_scal_dev), e->h_scal, 0) != hipSuccess) return bail(PBA_ERR_HIP);
   if (const char* sv = getenv("PBA_SPECULATE")) e->speculate = atoi(sv) != 0;
   if (const char* sv = getenv("PBA_FUSE")) e->fuse = atoi(sv) != 0;
+  if (const char* sv = getenv("PBA_SCHUR_TIMING")) e->dbg_left = atoi(sv);
   if ((rc = dev_alloc(e, &e->d_ticket, (size_t)1))) return bail(rc);
   if (hipMemsetAsync(e->d_ticket, 0, sizeof(unsigned int), e->stream) != hipSuccess) return bail(PBA_ERR_HIP);
   for (int k = 0; k < 6; ++k)
@@ -408,7 +411,7 @@ int pba_set_problem(pba_engine* e, int32_t n_points, const double* xyz, const do
   }
   e->backsub_grid = (n_points + 255) / 256;
   if ((rc = dev_alloc(e, &e->d_bs_out, (size_t)3 * std::max(e->backsub_grid, e->fused_grid)))) return rc;
-  e->schur_grid = std::min(e->n_tiles, 256 * 3);
+  e->schur_grid = std::min(e->n_tiles, 256 * 4);
 
   HIP_TRY(e, hipMemcpyAsync(e->d_xyz[0], xyz, sizeof(double) * 3 * n_points, hipMemcpyHostToDevice, e->stream));
   HIP_TRY(e, hipMemcpyAsync(e->d_desc, descf.data(), sizeof(float) * descf.size(), hipMemcpyHostToDevice, e->stream));
@@ -437,7 +440,7 @@ int pba_set_cameras(pba_engine* e, const double* cams6, int32_t n_frames, int32_
   e->part_stride = 36 * e->n_pairs + 3 * 6 * e->n_free + 3;
   if (e->n_pairs > kTile) return fail(e, PBA_ERR_INVALID, "too many free cameras for the Schur tile (%d pairs)", e->n_pairs);
   int rc;
-  if ((rc = dev_alloc(e, &e->d_partial, (size_t)std::max(1, 256 * 3) * e->part_stride))) return rc;
+  if ((rc = dev_alloc(e, &e->d_partial, (size_t)(256 * 4) * e->part_stride))) return rc;
   if ((rc = dev_alloc(e, &e->d_red, (size_t)pba_engine::kChunks * e->part_stride))) return rc;
   if ((rc = dev_alloc(e, &e->d_packed, (size_t)e->part_stride))) return rc;
   HIP_TRY(e, hipMemcpyAsync(e->d_cams[e->cur], cams6, sizeof(double) * 6 * n_frames, hipMemcpyHostToDevice, e->stream));
@@ -511,9 +514,24 @@ int pba_internal_step(pba_engine* e, double radius, int32_t init_scale, const pb
   sc.n_free = e->n_free; sc.n_pairs = e->n_pairs; sc.part_stride = e->part_stride; sc.init_scale = init_scale;
   sc.jacobi = o->jacobi_scaling; sc.fx = e->cfg.fx; sc.fy = e->cfg.fy; sc.radius = radius; sc.inv_radius = 1.0 / radius;
   sc.min_diag = o->min_lm_diagonal; sc.max_diag = o->max_lm_diagonal;
+  sc.dbg = nullptr;
+  if (e->dbg_left > 0) {
+    if (!e->d_dbg) { (void)hipMalloc(reinterpret_cast<void**>(&e->d_dbg), sizeof(unsigned long long) * 8 * 1024); }
+    sc.dbg = e->d_dbg;
+  }
   ev_begin(e, 2);
   launch_schur(e, sc);
   ev_end(e, 2);
+  if (sc.dbg) {
+    std::vector<unsigned long long> h(8 * (size_t)e->schur_grid);
+    (void)hipMemcpyAsync(h.data(), e->d_dbg, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost, e->stream);
+    (void)hipStreamSynchronize(e->stream);
+    double avg[8] = {0};
+    for (int b = 0; b < e->schur_grid; ++b) for (int k = 0; k < 8; ++k) avg[k] += (double)h[8 * b + k] / e->schur_grid;
+    std::fprintf(stderr, "k_schur phase cycles/block (stage, P1, P2sum, P2, P3a, P3b-write, P3b-acc): %.0f %.0f %.0f %.0f %.0f %.0f %.0f  tiles/block %.2f\n",
+                 avg[0], avg[1], avg[2], avg[3], avg[4], avg[5], avg[6], (double)e->n_tiles / e->schur_grid);
+    --e->dbg_left;
+  }
   hipLaunchKernelGGL(k_reduce_final, dim3((e->part_stride + 31) / 32 + 1), dim3(1024), 0, e->stream, e->d_partial,
                      e->schur_grid, e->part_stride, e->d_block_cost[cur], e->d_block_fail[cur], e->cost_blocks[cur], e->d_packed,
                      e->d_scal);

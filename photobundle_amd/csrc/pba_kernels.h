@@ -659,6 +659,7 @@ struct SchurParams {
   int32_t jacobi;
   double fx, fy;
   double radius, inv_radius, min_diag, max_diag;
+  unsigned long long* dbg;     // optional [gridDim.x][8] per-phase cycle sums of thread 0 (diagnostics)
 };
 
 __device__ __forceinline__ int sym6(int i, int j) {  // packed upper triangle of a symmetric 6x6 (21 entries)
@@ -670,12 +671,15 @@ __device__ __forceinline__ int sym6(int i, int j) {  // packed upper triangle of
 //   [0, 36 n_pairs)           T: pair (a <= b, enumerated row by row) -> row-major 6x6 block (a, b)
 //   [.., +n) rhs   [.., +n) g_c   [.., +n) diag(U)
 //   partial only: +0 gmax_pts, +1 gnorm2_pts, +2 schur_fail
-__global__ __launch_bounds__(kTile) void k_schur(SchurParams p) {
+__global__ __launch_bounds__(kTile, 2) void k_schur(SchurParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* s_obs = reinterpret_cast<double*>(smem);                       // [kTile][kObsStride]
-  double* s_vg = s_obs + kTile * kObsStride;                             // [kTile][9]  V_l (6) g_l (3)
-  double* s_red = s_vg + kTile * 9;                                      // [kTile]
-  int8_t* s_lane_of = reinterpret_cast<int8_t*>(s_red + kTile);          // [points in tile][kMaxFrames] by FREE index
+  // V_l (6) g_l (3) per lane live INSIDE the s_obs region (after the staged camera table, before W | Y are
+  // written): 40 KB per workgroup => 4 workgroups per CU instead of 3
+  static_assert(1024 + kTile * 9 <= kTile * kObsStride && kMaxFrames * sizeof(CamGeom) <= 1024 * sizeof(double), "aliasing fits");
+  double* s_vg = s_obs + 1024;                                           // [kTile][9]
+  double* s_red = s_obs + kTile * kObsStride;                            // [kTile]
+  int8_t* s_lane_of = reinterpret_cast<int8_t*>(s_red + kTile);          // [kMaxFrames (FREE index)][kTile points]: a camera's lanes are contiguous bytes
 
   const int tid = threadIdx.x;
   const int nf = p.n_free;
@@ -699,6 +703,9 @@ __global__ __launch_bounds__(kTile) void k_schur(SchurParams p) {
   double gmax = 0.0, gn2 = 0.0;
   int fail = 0;
 
+  unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tlast = p.dbg ? __builtin_amdgcn_s_memtime() : 0;
+#define PBA_TICK(k) do { if (p.dbg) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); tph[k] += tn - tlast; tlast = tn; } } while (0)
   int4 ti_next = p.tile_info[min((int)blockIdx.x, p.n_tiles - 1)];
   for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
     const int4 ti = ti_next;
@@ -707,10 +714,11 @@ __global__ __launch_bounds__(kTile) void k_schur(SchurParams p) {
     const bool active = tid < n_here;
     const int obs = o0 + tid;
 
-    for (int k = tid; k < n_pts * kMaxFrames; k += kTile) s_lane_of[k] = -1;
+    for (int k = tid; k < kMaxFrames * kTile / 4; k += kTile) reinterpret_cast<int32_t*>(s_lane_of)[k] = -1;
     CamGeom* s_geom = reinterpret_cast<CamGeom*>(s_obs);   // P1 only; P2 overwrites the region with W | Y
     stage_geom<kTile>(p.geom, s_geom, p.n_frames, tid);
     lds_barrier();
+    PBA_TICK(0);
 
     // ---- P1: per observation geometry and point-side contributions -----------------------------------
     int pt = 0, fa = -1, l0 = 0, l1 = 0;
@@ -742,14 +750,15 @@ __global__ __launch_bounds__(kTile) void k_schur(SchurParams p) {
       vg[5] = Ap[0][2] * MAp[0][2] + Ap[1][2] * MAp[1][2];
 #pragma unroll
       for (int k = 0; k < 3; ++k) vg[6 + k] = -(Ap[0][k] * b[0] + Ap[1][k] * b[1]);
-      if (fa >= 0) s_lane_of[(pt - pt0) * kMaxFrames + fa] = (int8_t)tid;
+      if (fa >= 0) s_lane_of[fa * kTile + (pt - pt0)] = (int8_t)tid;
     }
     lds_barrier();
+    PBA_TICK(1);
 
     // ---- P2: point totals, damping, effective inverse, per-observation Schur factors -------------------
     double rl[6] = {0, 0, 0, 0, 0, 0}, gcl[6] = {0, 0, 0, 0, 0, 0};
+    double V[6] = {0, 0, 0, 0, 0, 0}, gp[3] = {0, 0, 0};
     if (active) {
-      double V[6] = {0, 0, 0, 0, 0, 0}, gp[3] = {0, 0, 0};
       for (int l = l0; l < l1; ++l) {
         const double* vg = s_vg + l * 9;
 #pragma unroll
@@ -757,6 +766,10 @@ __global__ __launch_bounds__(kTile) void k_schur(SchurParams p) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) gp[k] += vg[6 + k];
       }
+    }
+    lds_barrier();     // every lane has its point totals: the region may now be overwritten with W | Y
+    PBA_TICK(2);
+    if (active) {
       const bool head = (tid == l0);
       double s[3];
       const double vd[3] = {V[0], V[3], V[5]};
@@ -829,27 +842,30 @@ __global__ __launch_bounds__(kTile) void k_schur(SchurParams p) {
       }
     }
     lds_barrier();
+    PBA_TICK(3);
 
     // ---- P3a: block owners: T(a, b) -= Y_la W_lb^T over this group's points ----------------------------------
     if (owner) {
+      const int8_t* la_row = s_lane_of + pa * kTile;
+      const int8_t* lb_row = s_lane_of + pb * kTile;
       for (int q = grp; q < n_pts; q += n_groups) {
-        const int8_t* lo = s_lane_of + q * kMaxFrames;
-        const int la = lo[pa], lb = lo[pb];
+        const int la = la_row[q], lb = lb_row[q];
         if (la < 0 || lb < 0) continue;
         const double* Y = s_obs + la * kObsStride + 18;
         const double* Wb = s_obs + lb * kObsStride;
-        double wb[18];
+        double wb[18], yy[18];
 #pragma unroll
-        for (int k = 0; k < 18; ++k) wb[k] = Wb[k];
+        for (int k = 0; k < 18; ++k) { wb[k] = Wb[k]; yy[k] = Y[k]; }
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-          const double y0 = Y[3 * i], y1 = Y[3 * i + 1], y2 = Y[3 * i + 2];
 #pragma unroll
-          for (int j = 0; j < 6; ++j) acc[6 * i + j] -= y0 * wb[3 * j] + y1 * wb[3 * j + 1] + y2 * wb[3 * j + 2];
+          for (int j = 0; j < 6; ++j)
+            acc[6 * i + j] -= yy[3 * i] * wb[3 * j] + yy[3 * i + 1] * wb[3 * j + 1] + yy[3 * i + 2] * wb[3 * j + 2];
         }
       }
     }
     lds_barrier();
+    PBA_TICK(4);
 
     // ---- P3b: camera-side sums: U_l = Ac^T M Ac into the diagonal blocks, rhs, g_c, diag(U) ---------------
     if (active && fa >= 0) {
@@ -865,30 +881,47 @@ __global__ __launch_bounds__(kTile) void k_schur(SchurParams p) {
       for (int j = 0; j < 6; ++j) { so[21 + j] = rl[j]; so[27 + j] = gcl[j]; }
     }
     lds_barrier();
+    PBA_TICK(5);
     if (owner && pa == pb) {
+      const int8_t* la_row = s_lane_of + pa * kTile;
       for (int q = grp; q < n_pts; q += n_groups) {
-        const int la = s_lane_of[q * kMaxFrames + pa];
+        const int la = la_row[q];
         if (la < 0) continue;
         const double* U = s_obs + la * kObsStride;
+        double u[21];
+#pragma unroll
+        for (int k = 0; k < 21; ++k) u[k] = U[k];
 #pragma unroll
         for (int i = 0; i < 6; ++i)
 #pragma unroll
-          for (int j = 0; j < 6; ++j) acc[6 * i + j] += U[sym6(i, j)];
+          for (int j = 0; j < 6; ++j) acc[6 * i + j] += u[sym6(i, j)];
       }
     }
     if (va >= 0) {
-      for (int q = 0; q < n_pts; ++q) {
-        const int la = s_lane_of[q * kMaxFrames + va];
-        if (la >= 0) {
-          const double* so = s_obs + la * kObsStride;
-          acc_rhs += so[21 + vi];
-          acc_gc += so[27 + vi];
-          acc_du += so[sym6(vi, vi)];
+      const int du_idx = sym6(vi, vi);
+      for (int q0 = 0; q0 < n_pts; q0 += 8) {
+        // 8 lane indices of camera va in one 64-bit read, then independent loads, then the adds in point order
+        const int2 l2 = *reinterpret_cast<const int2*>(s_lane_of + va * kTile + q0);
+        const int lw[2] = {l2.x, l2.y};
+        double r[8], g[8], d[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int la = (int)(int8_t)((lw[k >> 2] >> (8 * (k & 3))) & 0xff);
+          const bool ok = (q0 + k < n_pts) && la >= 0;
+          const double* so = s_obs + (ok ? la : 0) * kObsStride;
+          r[k] = ok ? so[21 + vi] : 0.0;
+          g[k] = ok ? so[27 + vi] : 0.0;
+          d[k] = ok ? so[du_idx] : 0.0;
         }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { acc_rhs += r[k]; acc_gc += g[k]; acc_du += d[k]; }
       }
     }
     lds_barrier();
+    PBA_TICK(6);
   }
+  if (p.dbg && tid == 0) for (int k = 0; k < 8; ++k) p.dbg[blockIdx.x * 8 + k] = tph[k];
+#undef PBA_TICK
 
   // ---- combine the point groups (fixed order), then per-block partials -----------------------------------
   double* out = p.partial + (size_t)blockIdx.x * p.part_stride;
@@ -948,7 +981,16 @@ __global__ __launch_bounds__(1024) void k_reduce_final(const double* __restrict_
     const bool is_max = (e == stride - 3) || (e == stride - 1);
     double acc = 0.0;
     if (valid) {
-      for (int b = sub; b < n_blocks; b += 32) {
+      // 8 loads in flight per thread, summed in block order (fixed)
+      int b = sub;
+      for (; b + 7 * 32 < n_blocks; b += 8 * 32) {
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = partial[(size_t)(b + 32 * k) * stride + e];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc = is_max ? fmax(acc, v[k]) : acc + v[k];
+      }
+      for (; b < n_blocks; b += 32) {
         const double v = partial[(size_t)b * stride + e];
         acc = is_max ? fmax(acc, v) : acc + v;
       }
