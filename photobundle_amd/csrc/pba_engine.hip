@@ -69,6 +69,7 @@ struct pba_engine {
   unsigned long long seq = 0;
   int64_t jac_passes = 0, cost_passes = 0;
   int schur_grid = 0, sample_grid = 0, backsub_grid = 0, sample_waves = 4, fused_grid = 0;
+  bool unit_weights = false;        // all patch weights are exactly 1 (MakePatchWeights without the Gaussian)
   bool fuse = true;                 // back-substitution + finalisation fused into the candidate pass (radius <= 3)
   unsigned int* d_ticket = nullptr;
   unsigned long long* d_dbg = nullptr;   // PBA_SCHUR_TIMING diagnostics
@@ -120,7 +121,8 @@ void launch_sample_r(pba_engine* e, const SampleParams& sp) {
     (void)e; (void)sp;   // unreachable: fused_capable() is false for these radii
   } else {
     const int grid = FUSED ? e->fused_grid : e->sample_grid;
-    hipLaunchKernelGGL((k_sample<R, JAC, WAVES, FUSED>), dim3(grid), dim3(WAVES * 64), 0, e->stream, sp);
+    if (e->unit_weights) hipLaunchKernelGGL((k_sample<R, JAC, WAVES, FUSED, true>), dim3(grid), dim3(WAVES * 64), 0, e->stream, sp);
+    else hipLaunchKernelGGL((k_sample<R, JAC, WAVES, FUSED, false>), dim3(grid), dim3(WAVES * 64), 0, e->stream, sp);
   }
 }
 template <bool JAC, bool FUSED = false>
@@ -382,7 +384,8 @@ int pba_set_problem(pba_engine* e, int32_t n_points, const double* xyz, const do
   std::vector<float> descf((size_t)n_points * P);
   for (size_t i = 0; i < descf.size(); ++i) descf[i] = (float)desc[i];
   std::vector<double> w2(P);
-  for (int i = 0; i < P; ++i) w2[i] = weights[i] * weights[i];
+  e->unit_weights = true;
+  for (int i = 0; i < P; ++i) { w2[i] = weights[i] * weights[i]; if (weights[i] != 1.0) e->unit_weights = false; }
 
   int rc;
   for (int k = 0; k < 2; ++k) if ((rc = dev_alloc(e, &e->d_xyz[k], (size_t)3 * n_points))) return rc;

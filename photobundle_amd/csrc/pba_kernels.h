@@ -234,8 +234,10 @@ __device__ __forceinline__ void linear_init_axis(float x, int size, int& x1, int
 }
 
 // sample_eigen.h:82-83: dx*a11 is a float product; (1.0 - dx) and everything downstream is double.
+// (1.0 - dx) * a2 is EXACT in double (dx: 24-bit significand, a2: integer of <= 9 bits), so one fma gives the same
+// bits as the reference's separate multiply and add.
 __device__ __forceinline__ double hlerp_exact(float dx, double omdx, float a1, float a2) {
-  return __dadd_rn((double)__fmul_rn(dx, a1), __dmul_rn(omdx, (double)a2));
+  return __fma_rn(omdx, (double)a2, (double)__fmul_rn(dx, a1));
 }
 __device__ __forceinline__ float vlerp_exact(float dy, float omdy, double top, double bot) {
   return __double2float_rn(__dadd_rn(__dmul_rn((double)dy, top), __dmul_rn((double)omdy, bot)));
@@ -305,7 +307,7 @@ struct SampleParams {
 //   FUSED      : the workgroup first back-substitutes the step for its own (whole) points
 //                (SchurEliminator::BackSubstitute), samples at the candidate it just formed, and the last workgroup
 //                to finish reduces the per-block partials in a fixed order and publishes the step's scalar block.
-template <int R, bool JAC, int WAVES, bool FUSED>
+template <int R, bool JAC, int WAVES, bool FUSED, bool UNITW>
 __global__ __launch_bounds__(WAVES * 64, (R <= 2 ? (JAC ? 3 : 2) : 1)) void k_sample(SampleParams p) {
   static_assert(!FUSED || (WAVES * 64) % 128 == 0, "fused tiles are 128 observations");
   constexpr int W = 2 * R + 1;      // patch side
@@ -492,14 +494,25 @@ __global__ __launch_bounds__(WAVES * 64, (R <= 2 ? (JAC ? 3 : 2) : 1)) void k_sa
           for (int j = 0; j < W; ++j) {
             const float sI = vlerp_exact(dy, omdy, Hp[0][j], Hc[0][j]);
             const double e = (double)p0[i * W + j] - (double)sI;   // photobundle.cc:720 (i0 - i1)
-            const double w2 = p.w2[i * W + j];
-            cc += w2 * e * e;
-            if (JAC) {
-              const double gx = (double)(0.5f * vlerp_exact(dy, omdy, Hp[1][j], Hc[1][j]));
-              const double gy = (double)(0.5f * vlerp_exact(dy, omdy, Hp[2][j], Hc[2][j]));
-              const double wgx = w2 * gx, wgy = w2 * gy;
-              m11 += wgx * gx; m12 += wgx * gy; m22 += wgy * gy;
-              b1 += wgx * e; b2 += wgy * e;
+            if (UNITW) {
+              cc = fma(e, e, cc);
+              if (JAC) {
+                // gradients stay in "2G" units here; the exact power-of-two scales are applied to the sums below
+                const double gx = (double)vlerp_exact(dy, omdy, Hp[1][j], Hc[1][j]);
+                const double gy = (double)vlerp_exact(dy, omdy, Hp[2][j], Hc[2][j]);
+                m11 = fma(gx, gx, m11); m12 = fma(gx, gy, m12); m22 = fma(gy, gy, m22);
+                b1 = fma(gx, e, b1); b2 = fma(gy, e, b2);
+              }
+            } else {
+              const double w2 = p.w2[i * W + j];
+              cc += w2 * e * e;
+              if (JAC) {
+                const double gx = (double)vlerp_exact(dy, omdy, Hp[1][j], Hc[1][j]);
+                const double gy = (double)vlerp_exact(dy, omdy, Hp[2][j], Hc[2][j]);
+                const double wgx = w2 * gx, wgy = w2 * gy;
+                m11 += wgx * gx; m12 += wgx * gy; m22 += wgy * gy;
+                b1 += wgx * e; b2 += wgy * e;
+              }
             }
           }
         }
@@ -508,6 +521,7 @@ __global__ __launch_bounds__(WAVES * 64, (R <= 2 ? (JAC ? 3 : 2) : 1)) void k_sa
 #pragma unroll
           for (int j = 0; j < W; ++j) Hp[pl][j] = Hc[pl][j];
       }
+      if (JAC) { m11 *= 0.25; m12 *= 0.25; m22 *= 0.25; b1 *= 0.5; b2 *= 0.5; }   // (2G)^2 / 4, (2G) e / 2: exact
     } else {
       // border / clamped / rounding-irregular observation: per-pixel generic rule from global memory
       const uint32_t* frame = p.frames + (size_t)slot * p.rows * p.cols;
