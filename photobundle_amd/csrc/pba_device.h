@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "../../include/pba.h"
+
 namespace pba {
 
 constexpr int kMaxFrames = 16;
@@ -59,6 +61,30 @@ enum Scal {
   kCostLin,         // GLOBAL cost at the linearisation point (copied out of the reduced packed buffer)
   kGnorm2Pts,       // GLOBAL sum g_p^2
   kNumScal = 32
+};
+
+// ---- device-resident Levenberg-Marquardt state (asynchronous driver) -------------------------------------------
+// The trust-region decisions of pba_lm.cpp (Ceres TrustRegionMinimizer / LevenbergMarquardtStrategy) evaluated by
+// the LAST workgroup of the candidate pass, so that the host can enqueue iterations back to back without a round
+// trip per step.  The host still owns the loop: it enqueues, watches `done`, and reads the iteration log.
+enum LmTermination { kLmRunning = 0, kLmMaxIterations, kLmGradientTolerance, kLmMinRadius, kLmParameterTolerance,
+                     kLmFunctionTolerance, kLmInvalidSteps, kLmEvalFailure };
+
+struct LmState {
+  double radius, decrease_factor, x_cost, minimum_cost, initial_cost;
+  double last_value[2];        // termination detail (e.g. step norm ratio)
+  int32_t cur;                 // parity of the current point
+  int32_t iteration;           // iterations completed (log entries written = n_log)
+  int32_t done;                // LmTermination
+  int32_t num_invalid, num_successful, num_unsuccessful;
+  int32_t pending_grad;        // log index still waiting for the gradient norms of its (accepted) point, -1 none
+  int32_t n_log;
+  int32_t first;               // 1 until iteration 0 has been logged
+  int32_t pad;
+  // options
+  double function_tolerance, gradient_tolerance, parameter_tolerance;
+  double max_radius, min_radius, min_relative_decrease;
+  int32_t max_num_iterations, max_invalid;
 };
 
 }  // namespace pba

@@ -72,6 +72,16 @@ struct pba_engine {
   bool unit_weights = false;        // all patch weights are exactly 1 (MakePatchWeights without the Gaussian)
   bool fuse = true;                 // back-substitution + finalisation fused into the candidate pass (radius <= 3)
   unsigned int* d_ticket = nullptr;
+  // asynchronous driver (device-side trust-region decisions)
+  LmState* d_lm = nullptr;          // device state
+  LmState* h_lm = nullptr;          // host-mapped mirror, written at every publish
+  LmState* h_lm_dev = nullptr;
+  pba_iteration_summary* h_log = nullptr;      // host-mapped iteration log
+  pba_iteration_summary* h_log_dev = nullptr;
+  static constexpr int kMaxLog = 1024;
+  bool async_on = false;
+  int async_cur = 0;                // parity assumed at enqueue time
+  bool use_async = true;            // PBA_ASYNC=0 disables
   unsigned long long* d_dbg = nullptr;   // PBA_SCHUR_TIMING diagnostics
   int dbg_left = 0;
   int n_pairs = 0, part_stride = 0;
@@ -278,6 +288,12 @@ int pba_create(const pba_config* cfg, pba_engine** out) {
   if (hipHostGetDevicePointer(reinterpret_cast<void**>(&e->h_scal_dev), e->h_scal, 0) != hipSuccess) return bail(PBA_ERR_HIP);
   if (const char* sv = getenv("PBA_SPECULATE")) e->speculate = atoi(sv) != 0;
   if (const char* sv = getenv("PBA_FUSE")) e->fuse = atoi(sv) != 0;
+  if (const char* sv = getenv("PBA_ASYNC")) e->use_async = atoi(sv) != 0;
+  if ((rc = dev_alloc(e, &e->d_lm, (size_t)1))) return bail(rc);
+  if (hipHostMalloc(reinterpret_cast<void**>(&e->h_lm), sizeof(LmState), hipHostMallocMapped) != hipSuccess) return bail(PBA_ERR_HIP);
+  if (hipHostGetDevicePointer(reinterpret_cast<void**>(&e->h_lm_dev), e->h_lm, 0) != hipSuccess) return bail(PBA_ERR_HIP);
+  if (hipHostMalloc(reinterpret_cast<void**>(&e->h_log), sizeof(pba_iteration_summary) * pba_engine::kMaxLog, hipHostMallocMapped) != hipSuccess) return bail(PBA_ERR_HIP);
+  if (hipHostGetDevicePointer(reinterpret_cast<void**>(&e->h_log_dev), e->h_log, 0) != hipSuccess) return bail(PBA_ERR_HIP);
   if (const char* sv = getenv("PBA_SCHUR_TIMING")) e->dbg_left = atoi(sv);
   if ((rc = dev_alloc(e, &e->d_ticket, (size_t)1))) return bail(rc);
   if (hipMemsetAsync(e->d_ticket, 0, sizeof(unsigned int), e->stream) != hipSuccess) return bail(PBA_ERR_HIP);
@@ -301,6 +317,9 @@ void pba_destroy(pba_engine* e) {
   dev_free(&e->d_delta_c); dev_free(&e->d_partial); dev_free(&e->d_red); dev_free(&e->d_packed); dev_free(&e->d_S);
   dev_free(&e->d_rhs); dev_free(&e->d_bs_out); dev_free(&e->d_scal); dev_free(&e->d_ticket);
   if (e->h_scal) (void)hipHostFree(e->h_scal);
+  if (e->h_lm) (void)hipHostFree(e->h_lm);
+  if (e->h_log) (void)hipHostFree(e->h_log);
+  dev_free(&e->d_lm);
   for (int k = 0; k < 6; ++k) if (e->ev[k]) (void)hipEventDestroy(e->ev[k]);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
@@ -517,7 +536,7 @@ int pba_internal_step(pba_engine* e, double radius, int32_t init_scale, const pb
   sc.n_free = e->n_free; sc.n_pairs = e->n_pairs; sc.part_stride = e->part_stride; sc.init_scale = init_scale;
   sc.jacobi = o->jacobi_scaling; sc.fx = e->cfg.fx; sc.fy = e->cfg.fy; sc.radius = radius; sc.inv_radius = 1.0 / radius;
   sc.min_diag = o->min_lm_diagonal; sc.max_diag = o->max_lm_diagonal;
-  sc.dbg = nullptr;
+  sc.dbg = nullptr; sc.lm = nullptr;
   if (e->dbg_left > 0) {
     if (!e->d_dbg) { (void)hipMalloc(reinterpret_cast<void**>(&e->d_dbg), sizeof(unsigned long long) * 8 * 1024); }
     sc.dbg = e->d_dbg;
@@ -537,7 +556,7 @@ int pba_internal_step(pba_engine* e, double radius, int32_t init_scale, const pb
   }
   hipLaunchKernelGGL(k_reduce_final, dim3((e->part_stride + 31) / 32 + 1), dim3(1024), 0, e->stream, e->d_partial,
                      e->schur_grid, e->part_stride, e->d_block_cost[cur], e->d_block_fail[cur], e->cost_blocks[cur], e->d_packed,
-                     e->d_scal);
+                     e->d_scal, (const LmState*)nullptr, 0, (const double*)nullptr, (const int32_t*)nullptr, 0);
   HIP_TRY(e, hipGetLastError());
   if (multi) {
     if (e->comm.allreduce_device(e->d_packed, (size_t)e->part_stride - 1, 0, e->stream))
@@ -552,6 +571,7 @@ int pba_internal_step(pba_engine* e, double radius, int32_t init_scale, const pb
   so.geom_cand = (!grad_only && fused_capable(e)) ? e->d_geom[cand] : nullptr;
   so.init_scale = init_scale; so.jacobi = o->jacobi_scaling; so.radius = radius; so.min_diag = o->min_lm_diagonal;
   so.max_diag = o->max_lm_diagonal;
+  so.lm = nullptr;
   launch_solve(e, so, n);
   const unsigned long long seq = ++e->seq;
   unsigned long long* h_seq_dev = reinterpret_cast<unsigned long long*>(e->h_scal_dev + kNumScal);
@@ -712,6 +732,145 @@ int pba_internal_world(const pba_engine* e) { return e->comm.world; }
 int pba_internal_rank(const pba_engine* e) { return e->comm.rank; }
 int64_t pba_internal_local_blocks(const pba_engine* e) { return e->n_obs; }
 int pba_internal_patch_len(const pba_engine* e) { return (2 * e->cfg.radius + 1) * (2 * e->cfg.radius + 1); }
+// ---- asynchronous driver ----------------------------------------------------------------------------------------
+int pba_internal_async_capable(const pba_engine* e, const pba_solver_options* o) {
+  return e->use_async && fused_capable(e) && e->comm.kind != 2 && o->max_num_iterations < pba_engine::kMaxLog - 2 && !e->profile;
+}
+
+int pba_internal_async_begin(pba_engine* e, const pba_solver_options* o) {
+  HIP_TRY(e, hipSetDevice(e->cfg.device));
+  LmState st;
+  std::memset(&st, 0, sizeof(st));
+  st.radius = o->initial_trust_region_radius; st.decrease_factor = 2.0;
+  st.cur = e->cur; st.pending_grad = -1; st.first = 1;
+  st.function_tolerance = o->function_tolerance; st.gradient_tolerance = o->gradient_tolerance;
+  st.parameter_tolerance = o->parameter_tolerance; st.max_radius = o->max_trust_region_radius;
+  st.min_radius = o->min_trust_region_radius; st.min_relative_decrease = o->min_relative_decrease;
+  st.max_num_iterations = o->max_num_iterations; st.max_invalid = o->max_num_consecutive_invalid_steps;
+  *e->h_lm = st;
+  // device copy of the initial state straight from the host-mapped mirror (stream ordered, no host sync)
+  HIP_TRY(e, hipMemcpyAsync(e->d_lm, e->h_lm_dev, sizeof(st), hipMemcpyDeviceToDevice, e->stream));
+  e->async_on = true;
+  e->async_cur = e->cur;
+  return PBA_OK;
+}
+
+// kind 0: first linearisation; 1: full iteration; 2: gradient norms of the final point.  Returns the sequence number
+// the device publishes when the enqueued work completes (0 for kind 0, which publishes nothing).
+int pba_internal_async_enqueue(pba_engine* e, int kind, int init_scale, const pba_solver_options* o, unsigned long long* seq_out) {
+  const int cur = e->async_cur, cand = 1 - cur;
+  const int n = 6 * e->n_free;
+  const bool multi = e->comm.world > 1;
+  unsigned long long* h_seq_dev = reinterpret_cast<unsigned long long*>(e->h_scal_dev + kNumScal);
+  *seq_out = 0;
+  auto sample_params = [&](bool skip) {
+    SampleParams sp = make_sample_params(e, skip ? cur : cand);
+    sp.tile_info = e->d_tile_info; sp.obs_l0 = e->d_obs_l0; sp.obs_cnt = e->d_obs_cnt;
+    sp.geom_prev = e->d_geom[skip ? cand : cur]; sp.xyz_prev = e->d_xyz[skip ? cand : cur]; sp.rec_prev = e->d_rec[skip ? cand : cur];
+    sp.sp = e->d_sp; sp.ptrec = e->d_ptrec; sp.delta_c = e->d_delta_c; sp.block_bs = e->d_bs_out; sp.ticket = e->d_ticket;
+    sp.scal = e->d_scal; sp.n_tiles = e->n_tiles; sp.skip_backsub = skip ? 1 : 0;
+    sp.block_cost_alt = e->d_block_cost[skip ? cand : cur]; sp.block_fail_alt = e->d_block_fail[skip ? cand : cur];
+    sp.host_state = e->h_lm_dev; sp.log = e->h_log_dev; sp.max_log = pba_engine::kMaxLog;
+    return sp;
+  };
+  if (kind == 0) {
+    // plain Jacobian pass at the current point, on the fused (tile) grid so that both parities share one block count
+    SampleParams sp = sample_params(true);
+    sp.lm = nullptr; sp.host_scal = nullptr; sp.host_seq = h_seq_dev; sp.seq = 0; sp.decide = 0; sp.enq_cur = cur;
+    launch_sample<true, true>(e, sp);
+    e->jac_passes++;
+    e->cost_blocks[0] = e->cost_blocks[1] = e->fused_grid;
+    HIP_TRY(e, hipGetLastError());
+    return PBA_OK;
+  }
+  SchurParams sc{};
+  sc.xyz = e->d_xyz[cur]; sc.geom = e->d_geom[cur]; sc.rec = e->d_rec[cur]; sc.obs_point = e->d_obs_point;
+  sc.obs_slot = e->d_obs_slot; sc.tile_info = e->d_tile_info; sc.obs_l0 = e->d_obs_l0; sc.obs_cnt = e->d_obs_cnt; sc.sp = e->d_sp;
+  sc.ptrec = e->d_ptrec; sc.partial = e->d_partial; sc.rec_stride = e->rec_stride; sc.n_tiles = e->n_tiles; sc.n_frames = e->n_frames;
+  sc.n_free = e->n_free; sc.n_pairs = e->n_pairs; sc.part_stride = e->part_stride; sc.init_scale = init_scale;
+  sc.jacobi = o->jacobi_scaling; sc.fx = e->cfg.fx; sc.fy = e->cfg.fy; sc.radius = 1.0; sc.inv_radius = 1.0;
+  sc.min_diag = o->min_lm_diagonal; sc.max_diag = o->max_lm_diagonal; sc.dbg = nullptr;
+  sc.lm = e->d_lm; sc.enq_cur = cur; sc.final_pass = (kind == 2) ? 1 : 0; sc.xyz_alt = e->d_xyz[cand]; sc.geom_alt = e->d_geom[cand]; sc.rec_alt = e->d_rec[cand];
+  launch_schur(e, sc);
+  hipLaunchKernelGGL(k_reduce_final, dim3((e->part_stride + 31) / 32 + 1), dim3(1024), 0, e->stream, e->d_partial,
+                     e->schur_grid, e->part_stride, e->d_block_cost[cur], e->d_block_fail[cur], e->fused_grid, e->d_packed,
+                     e->d_scal, (const LmState*)e->d_lm, cur, (const double*)e->d_block_cost[cand], (const int32_t*)e->d_block_fail[cand], kind == 2 ? 1 : 0);
+  HIP_TRY(e, hipGetLastError());
+  if (multi) {
+    if (e->comm.allreduce_device(e->d_packed, (size_t)e->part_stride - 1, 0, e->stream))
+      return fail(e, PBA_ERR_COMM, "allreduce(reduced system) failed: %s", e->comm.err.c_str());
+  }
+  SolveParams so{};
+  so.packed = e->d_packed; so.cams = e->d_cams[cur]; so.cams_cand = e->d_cams[cand]; so.delta_c = e->d_delta_c;
+  so.sc = e->d_sc; so.S_dbg = (e->cfg.flags & 1) ? e->d_S : nullptr; so.rhs_dbg = e->d_rhs; so.scal = e->d_scal; so.geom = e->d_geom[cur];
+  so.n_frames = e->n_frames; so.n_free = e->n_free; so.n_pairs = e->n_pairs; so.stride = e->part_stride; so.fixed_slot = e->fixed_slot;
+  so.geom_cand = (kind == 1) ? e->d_geom[cand] : nullptr;
+  so.init_scale = init_scale; so.jacobi = o->jacobi_scaling; so.radius = 1.0; so.min_diag = o->min_lm_diagonal; so.max_diag = o->max_lm_diagonal;
+  so.lm = e->d_lm; so.enq_cur = cur; so.final_pass = (kind == 2) ? 1 : 0; so.cams_alt = e->d_cams[cand]; so.cams_cand_alt = e->d_cams[cur]; so.geom_alt = e->d_geom[cand];
+  so.geom_cand_alt = e->d_geom[cur];
+  launch_solve(e, so, n);
+  const unsigned long long seq = ++e->seq;
+  if (kind == 1) {
+    SampleParams sp = sample_params(false);
+    sp.lm = e->d_lm; sp.enq_cur = cur; sp.decide = multi ? 0 : 1;
+    sp.host_scal = multi ? nullptr : e->h_scal_dev; sp.host_seq = h_seq_dev; sp.seq = seq;
+    launch_sample<true, true>(e, sp);
+    e->jac_passes++;
+    HIP_TRY(e, hipGetLastError());
+    if (multi) {
+      if (e->comm.allreduce_device(e->d_scal + kCandCost, kSumBCount, 0, e->stream) ||
+          e->comm.allreduce_device(e->d_scal + kGmaxPts, kMaxCount, 1, e->stream))
+        return fail(e, PBA_ERR_COMM, "allreduce(step scalars) failed: %s", e->comm.err.c_str());
+    }
+  } else if (multi) {
+    if (e->comm.allreduce_device(e->d_scal + kGmaxPts, kMaxCount, 1, e->stream))
+      return fail(e, PBA_ERR_COMM, "allreduce(step scalars) failed: %s", e->comm.err.c_str());
+  }
+  if (multi || kind == 2) {
+    DecideParams dp{};
+    dp.lm = e->d_lm; dp.host_state = e->h_lm_dev; dp.scal = e->d_scal; dp.host_scal = e->h_scal_dev; dp.log = e->h_log_dev;
+    dp.max_log = pba_engine::kMaxLog; dp.grad_only = (kind == 2) ? 1 : 0; dp.host_seq = h_seq_dev; dp.seq = seq;
+    hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, e->stream, dp);
+  }
+  HIP_TRY(e, hipGetLastError());
+  *seq_out = seq;
+  return PBA_OK;
+}
+
+int pba_internal_async_wait(pba_engine* e, unsigned long long seq) {
+  volatile unsigned long long* h_seq = reinterpret_cast<volatile unsigned long long*>(e->h_scal + kNumScal);
+  unsigned long spins = 0;
+  while (*h_seq < seq) {
+    if ((++spins & 0x3fff) == 0) {
+      const hipError_t q = hipStreamQuery(e->stream);
+      if (q != hipSuccess && q != hipErrorNotReady) return fail(e, PBA_ERR_HIP, "stream error while waiting: %s", hipGetErrorString(q));
+      if (q == hipSuccess && *h_seq < seq) {
+        // a terminated solve turns the remaining kernels into no-ops that publish nothing
+        if (reinterpret_cast<volatile LmState*>(e->h_lm)->done) return PBA_OK;
+        return fail(e, PBA_ERR_HIP, "step finished without publishing");
+      }
+    }
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  return PBA_OK;
+}
+
+const void* pba_internal_async_state(const pba_engine* e) { return e->h_lm; }
+const pba_iteration_summary* pba_internal_async_log(const pba_engine* e) { return e->h_log; }
+
+// Leaves the engine in the state a synchronous solve would: current parity, valid linearisation.
+int pba_internal_async_end(pba_engine* e) {
+  // the host mirror was written by the last publishing kernel the caller waited for; kernels enqueued after a
+  // termination are no-ops, so nothing behind it touches the state
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  const LmState st = *e->h_lm;
+  e->cur = st.cur;
+  e->lin_valid[e->cur] = true; e->lin_valid[1 - e->cur] = false;
+  e->have_lin = true;
+  e->async_on = false;
+  return PBA_OK;
+}
+
 void pba_internal_set_speculate(pba_engine* e, int on) {
   static const bool forced_off = [] { const char* sv = getenv("PBA_SPECULATE"); return sv && atoi(sv) == 0; }();
   e->speculate = on != 0 && !forced_off;

@@ -15,4 +15,12 @@ int pba_internal_allreduce_host(pba_engine* e, double* v, int n, int op);
 void pba_internal_set_speculate(pba_engine* e, int on);
 void pba_internal_pass_counts(const pba_engine* e, int64_t* jac, int64_t* cost);
 void pba_internal_reset_pass_counts(pba_engine* e);
+// asynchronous driver (device-side trust-region decisions)
+int pba_internal_async_capable(const pba_engine* e, const pba_solver_options* o);
+int pba_internal_async_begin(pba_engine* e, const pba_solver_options* o);
+int pba_internal_async_enqueue(pba_engine* e, int kind, int init_scale, const pba_solver_options* o, unsigned long long* seq_out);
+int pba_internal_async_wait(pba_engine* e, unsigned long long seq);
+const void* pba_internal_async_state(const pba_engine* e);
+const pba_iteration_summary* pba_internal_async_log(const pba_engine* e);
+int pba_internal_async_end(pba_engine* e);
 }

@@ -217,6 +217,150 @@ __device__ __forceinline__ void projection_jacobians(const CamGeom& g, const dou
   Ac[1][3] = 0.0; Ac[1][4] = jv1; Ac[1][5] = jv2;
 }
 
+
+// =====================================================================================================
+// device-side trust-region bookkeeping (asynchronous driver): the decisions of pba_lm.cpp for ONE step
+// =====================================================================================================
+__device__ __forceinline__ void lm_step_rejected(LmState* st) {   // LevenbergMarquardtStrategy::StepRejected
+  st->radius = st->radius / st->decrease_factor;
+  st->decrease_factor *= 2.0;
+}
+
+__device__ inline void lm_log(LmState* st, pba_iteration_summary* log, int max_log, const pba_iteration_summary& it) {
+  if (st->n_log < max_log) log[st->n_log] = it;
+  st->n_log++;
+}
+
+// `s` = the step's (fully reduced) scalar block.  grad_only: only the gradient norms of the current point are valid.
+__device__ inline void lm_decide(LmState* st, const double* s, pba_iteration_summary* log, int max_log, int grad_only) {
+  const double gmax = fmax(s[kGmaxPts], s[kGmaxCams]);
+  const double gnorm = sqrt(s[kGnorm2Pts] + s[kGnorm2Cams]);
+  if (st->done) {
+    // final pass after the iteration limit: only report the gradient norms of the last accepted point
+    if (grad_only && st->done == kLmMaxIterations && st->pending_grad >= 0 && !st->first) {
+      if (st->pending_grad < max_log) { log[st->pending_grad].gradient_max_norm = gmax; log[st->pending_grad].gradient_norm = gnorm; }
+      st->pending_grad = -1;
+    }
+    return;
+  }
+  pba_iteration_summary it;
+  memset(&it, 0, sizeof(it));
+  it.eta = 1e-1;
+  if (st->first) {
+    // IterationZero
+    if (s[kEvalFailLin] > 0.5) { st->done = kLmEvalFailure; return; }
+    st->first = 0;
+    st->x_cost = s[kCostLin];
+    st->initial_cost = st->x_cost;
+    st->minimum_cost = st->x_cost;
+    it.iteration = 0; it.cost = st->x_cost; it.gradient_max_norm = gmax; it.gradient_norm = gnorm;
+    it.step_is_valid = 1; it.step_is_successful = 1; it.trust_region_radius = st->radius;
+    st->num_successful = 1;
+    lm_log(st, log, max_log, it);
+    if (0 >= st->max_num_iterations) st->done = kLmMaxIterations;
+    else if (gmax <= st->gradient_tolerance) { st->done = kLmGradientTolerance; st->last_value[0] = gmax; }
+    else if (st->radius <= st->min_radius) st->done = kLmMinRadius;
+    if (st->done) return;
+  } else if (st->pending_grad >= 0) {
+    // gradient norms of the point accepted by the previous iteration + its deferred termination checks
+    if (st->pending_grad < max_log) { log[st->pending_grad].gradient_max_norm = gmax; log[st->pending_grad].gradient_norm = gnorm; }
+    st->pending_grad = -1;
+    if (s[kEvalFailLin] > 0.5) { st->done = kLmEvalFailure; return; }
+    if (gmax <= st->gradient_tolerance) { st->done = kLmGradientTolerance; st->last_value[0] = gmax; return; }
+    if (st->radius <= st->min_radius) { st->done = kLmMinRadius; return; }
+  }
+  if (grad_only) return;
+
+  const int iteration = st->iteration + 1;
+  it.iteration = iteration;
+  it.gradient_max_norm = gmax; it.gradient_norm = gnorm;
+  it.linear_solver_iterations = 1;
+  it.model_cost_change = s[kMccPts] + s[kMccCams];
+  const bool solver_ok = s[kSolveOk] > 0.5 && s[kSchurFail] < 0.5;
+  const bool step_is_valid = solver_ok && it.model_cost_change > 0.0;
+  bool successful = false;
+  if (!step_is_valid) {
+    // HandleInvalidStep
+    st->num_invalid++;
+    it.cost = st->x_cost;
+    if (st->num_invalid >= st->max_invalid) {
+      it.trust_region_radius = st->radius;
+      lm_log(st, log, max_log, it);
+      st->iteration = iteration;
+      st->done = kLmInvalidSteps;
+      return;
+    }
+    lm_step_rejected(st);
+  } else {
+    it.step_is_valid = 1;
+    st->num_invalid = 0;
+    const bool eval_ok = s[kEvalFailCand] < 0.5 && isfinite(s[kCandCost]);
+    const double candidate_cost = eval_ok ? s[kCandCost] : DBL_MAX;
+    it.candidate_cost = candidate_cost;
+    it.step_norm = sqrt(s[kStep2Pts] + s[kStep2Cams]);
+    const double x_norm = sqrt(s[kX2Pts] + s[kX2Cams]);
+    if (it.step_norm <= st->parameter_tolerance * (x_norm + st->parameter_tolerance)) {   // ParameterToleranceReached
+      st->done = kLmParameterTolerance;
+      st->last_value[0] = it.step_norm / (x_norm + st->parameter_tolerance);
+      return;
+    }
+    it.cost_change = st->x_cost - candidate_cost;
+    if (fabs(it.cost_change) <= st->function_tolerance * st->x_cost) {                    // FunctionToleranceReached
+      st->done = kLmFunctionTolerance;
+      st->last_value[0] = fabs(it.cost_change) / st->x_cost;
+      return;
+    }
+    it.relative_decrease = it.cost_change / it.model_cost_change;
+    if (it.relative_decrease > st->min_relative_decrease) {
+      // HandleSuccessfulStep + LevenbergMarquardtStrategy::StepAccepted
+      successful = true;
+      st->cur ^= 1;
+      st->x_cost = candidate_cost;
+      const double t = 2.0 * it.relative_decrease - 1.0;
+      st->radius = st->radius / fmax(1.0 / 3.0, 1.0 - t * t * t);
+      st->radius = fmin(st->max_radius, st->radius);
+      st->decrease_factor = 2.0;
+      it.step_is_successful = 1;
+      it.cost = st->x_cost;
+      st->pending_grad = st->n_log;
+    } else {
+      lm_step_rejected(st);
+      it.cost = candidate_cost;
+    }
+  }
+  // FinalizeIterationAndCheckIfMinimizerCanContinue (gradient tolerance deferred to the next decision)
+  if (successful) { st->num_successful++; st->minimum_cost = st->x_cost; }
+  else st->num_unsuccessful++;
+  it.trust_region_radius = st->radius;
+  lm_log(st, log, max_log, it);
+  st->iteration = iteration;
+  if (iteration >= st->max_num_iterations) st->done = kLmMaxIterations;
+  else if (!successful && st->radius <= st->min_radius) st->done = kLmMinRadius;
+}
+
+// Publishes state + scalars to the host mirror, then the sequence number.
+__device__ inline void lm_publish(const LmState* st, LmState* host_state, const double* scal, double* host_scal,
+                                  unsigned long long* host_seq, unsigned long long seq, int tid, int nthreads) {
+  if (host_scal) for (int k = tid; k < kNumScal; k += nthreads) host_scal[k] = scal[k];
+  if (host_state && tid == 0) *host_state = *st;
+  __threadfence_system();
+  __syncthreads();
+  if (tid == 0) { *reinterpret_cast<volatile unsigned long long*>(host_seq) = seq; __threadfence_system(); }
+}
+
+struct DecideParams {
+  LmState* lm; LmState* host_state;
+  const double* scal; double* host_scal;
+  pba_iteration_summary* log; int32_t max_log; int32_t grad_only;
+  unsigned long long* host_seq; unsigned long long seq;
+};
+
+__global__ void k_decide(DecideParams p) {
+  if (threadIdx.x == 0) lm_decide(p.lm, p.scal, p.log, p.max_log, p.grad_only);
+  __syncthreads();
+  lm_publish(p.lm, p.host_state, p.scal, p.host_scal, p.host_seq, p.seq, threadIdx.x, blockDim.x);
+}
+
 // =====================================================================================================
 // sampling (sample_eigen.h) -- exact mixed fp32/fp64 arithmetic of the reference
 // =====================================================================================================
@@ -295,6 +439,16 @@ struct SampleParams {
   unsigned long long* host_seq;
   unsigned long long seq;
   int32_t n_tiles;
+  int32_t skip_backsub;       // FUSED kernel used as a plain (first) linearisation: no step to back-substitute
+  // ---- asynchronous driver (lm != null): parity resolved on the device, decisions by the last workgroup ----
+  LmState* lm;
+  LmState* host_state;
+  pba_iteration_summary* log;
+  int32_t max_log;
+  int32_t enq_cur;            // parity the host assumed when it filled xyz/xyz_prev, rec/rec_prev, geom/geom_prev
+  double* block_cost_alt;     // the other parity's block arrays
+  int32_t* block_fail_alt;
+  int32_t decide;             // run lm_decide in the last workgroup (single rank)
 };
 
 // One LANE per observation (residual block); each wave stages the (2R+2)^2 texel footprints of its 64
@@ -308,8 +462,19 @@ struct SampleParams {
 //                (SchurEliminator::BackSubstitute), samples at the candidate it just formed, and the last workgroup
 //                to finish reduces the per-block partials in a fixed order and publishes the step's scalar block.
 template <int R, bool JAC, int WAVES, bool FUSED, bool UNITW>
-__global__ __launch_bounds__(WAVES * 64, (R <= 2 ? (JAC ? 3 : 2) : 1)) void k_sample(SampleParams p) {
+__global__ __launch_bounds__(WAVES * 64, (R <= 2 ? (JAC ? 3 : 2) : 1)) void k_sample(SampleParams p_in) {
   static_assert(!FUSED || (WAVES * 64) % 128 == 0, "fused tiles are 128 observations");
+  SampleParams p = p_in;
+  if (FUSED && p.lm) {
+    if (p.lm->done) return;
+    if (p.lm->cur != p.enq_cur) {     // the host's parity guess was off by an odd number of accepted steps
+      const double* tx = p.xyz; p.xyz = p.xyz_prev; p.xyz_prev = tx;
+      double* tr = p.rec; p.rec = const_cast<double*>(p.rec_prev); p.rec_prev = tr;
+      const CamGeom* tg = p.geom; p.geom = p.geom_prev; p.geom_prev = tg;
+      double* tc = p.block_cost; p.block_cost = p.block_cost_alt; p.block_cost_alt = tc;
+      int32_t* tf = p.block_fail; p.block_fail = p.block_fail_alt; p.block_fail_alt = tf;
+    }
+  }
   constexpr int W = 2 * R + 1;      // patch side
   constexpr int F = 2 * R + 2;      // footprint side
   constexpr int FF = F * F;
@@ -332,7 +497,7 @@ __global__ __launch_bounds__(WAVES * 64, (R <= 2 ? (JAC ? 3 : 2) : 1)) void k_sa
   CamGeom* s_geom = reinterpret_cast<CamGeom*>(s_raw + sizeof(double) * 3 * WAVES * 64);
   CamGeom* s_geom_prev = s_geom + kMaxFrames;
   stage_geom<WAVES * 64>(p.geom, s_geom, p.n_frames, threadIdx.x);
-  if (FUSED) stage_geom<WAVES * 64>(p.geom_prev, s_geom_prev, p.n_frames, threadIdx.x);
+  if (FUSED && !p.skip_backsub) stage_geom<WAVES * 64>(p.geom_prev, s_geom_prev, p.n_frames, threadIdx.x);
   lds_barrier();
 
   int pt = 0, slot = 0;
@@ -357,14 +522,17 @@ __global__ __launch_bounds__(WAVES * 64, (R <= 2 ? (JAC ? 3 : 2) : 1)) void k_sa
       pt = p.obs_point[obs];
       slot = p.obs_slot[obs];
       l0 = p.obs_l0[obs]; cnt = p.obs_cnt[obs];
-      X[0] = p.xyz_prev[3 * (size_t)pt]; X[1] = p.xyz_prev[3 * (size_t)pt + 1]; X[2] = p.xyz_prev[3 * (size_t)pt + 2];
+      const double* xsrc = p.skip_backsub ? p.xyz : p.xyz_prev;
+      X[0] = xsrc[3 * (size_t)pt]; X[1] = xsrc[3 * (size_t)pt + 1]; X[2] = xsrc[3 * (size_t)pt + 2];
       // issued here (same dependency level as X) so that they are in flight across the barrier below
+      if (!p.skip_backsub) {
 #pragma unroll
       for (int k = 0; k < 12; ++k) pr[k] = p.ptrec[12 * (size_t)pt + k];
 #pragma unroll
       for (int k = 0; k < 3; ++k) spk[k] = p.sp[3 * (size_t)pt + k];
+      }
       const CamGeom& g = s_geom_prev[slot];
-      if (g.free_index >= 0) {
+      if (!p.skip_backsub && g.free_index >= 0) {
         double xw[3], Ac[2][6], Ap[2][3];
         transform_point(g, X, xw);
         projection_jacobians(g, X, xw, p.fx, p.fy, Ac, Ap);
@@ -380,7 +548,7 @@ __global__ __launch_bounds__(WAVES * 64, (R <= 2 ? (JAC ? 3 : 2) : 1)) void k_sa
     }
     s_bs[threadIdx.x * 3 + 0] = c3[0]; s_bs[threadIdx.x * 3 + 1] = c3[1]; s_bs[threadIdx.x * 3 + 2] = c3[2];
     lds_barrier();
-    if (active) {
+    if (active && !p.skip_backsub) {
       double acc[3] = {0.0, 0.0, 0.0};
       const double* src = s_bs + (half * 128 + l0) * 3;
       for (int l = 0; l < cnt; ++l) { acc[0] += src[3 * l]; acc[1] += src[3 * l + 1]; acc[2] += src[3 * l + 2]; }
@@ -630,13 +798,11 @@ __global__ __launch_bounds__(WAVES * 64, (R <= 2 ? (JAC ? 3 : 2) : 1)) void k_sa
         p.scal[kMccPts] = s_r4[0]; p.scal[kStep2Pts] = s_r4[WAVES]; p.scal[kX2Pts] = s_r4[2 * WAVES];
         p.scal[kCandCost] = s_r4[3 * WAVES]; p.scal[kEvalFailCand] = (double)s_f[0];
         *p.ticket = 0;
+        if (p.lm && p.decide) lm_decide(p.lm, p.scal, p.log, p.max_log, 0);
       }
       if (p.host_scal) {
         __syncthreads();
-        if (threadIdx.x < kNumScal) p.host_scal[threadIdx.x] = p.scal[threadIdx.x];
-        __threadfence_system();
-        __syncthreads();
-        if (threadIdx.x == 0) { *reinterpret_cast<volatile unsigned long long*>(p.host_seq) = p.seq; __threadfence_system(); }
+        lm_publish(p.lm, (p.lm && p.decide) ? p.host_state : nullptr, p.scal, p.host_scal, p.host_seq, p.seq, threadIdx.x, NTH);
       }
     }
   }
@@ -674,6 +840,11 @@ struct SchurParams {
   double fx, fy;
   double radius, inv_radius, min_diag, max_diag;
   unsigned long long* dbg;     // optional [gridDim.x][8] per-phase cycle sums of thread 0 (diagnostics)
+  // asynchronous driver: parity / radius resolved from the device state
+  const LmState* lm;
+  int32_t enq_cur;
+  int32_t final_pass;          // run although the solve has terminated (gradient norms of the final point)
+  const double* xyz_alt; const CamGeom* geom_alt; const double* rec_alt;
 };
 
 __device__ __forceinline__ int sym6(int i, int j) {  // packed upper triangle of a symmetric 6x6 (21 entries)
@@ -685,7 +856,14 @@ __device__ __forceinline__ int sym6(int i, int j) {  // packed upper triangle of
 //   [0, 36 n_pairs)           T: pair (a <= b, enumerated row by row) -> row-major 6x6 block (a, b)
 //   [.., +n) rhs   [.., +n) g_c   [.., +n) diag(U)
 //   partial only: +0 gmax_pts, +1 gnorm2_pts, +2 schur_fail
-__global__ __launch_bounds__(kTile, 2) void k_schur(SchurParams p) {
+__global__ __launch_bounds__(kTile, 2) void k_schur(SchurParams p_in) {
+  SchurParams p = p_in;
+  if (p.lm) {
+    if (p.lm->done && !p.final_pass) return;
+    if (p.lm->cur != p.enq_cur) { p.xyz = p.xyz_alt; p.geom = p.geom_alt; p.rec = p.rec_alt; }
+    p.radius = p.lm->radius;
+    p.inv_radius = 1.0 / p.radius;
+  }
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* s_obs = reinterpret_cast<double*>(smem);                       // [kTile][kObsStride]
   // V_l (6) g_l (3) per lane live INSIDE the s_obs region (after the staged camera table, before W | Y are
@@ -984,7 +1162,13 @@ __global__ __launch_bounds__(kTile, 2) void k_schur(SchurParams p) {
 __global__ __launch_bounds__(1024) void k_reduce_final(const double* __restrict__ partial, int n_blocks, int stride,
                                                         const double* __restrict__ block_cost,
                                                         const int32_t* __restrict__ block_fail, int n_cost_blocks,
-                                                        double* __restrict__ packed, double* __restrict__ scal) {
+                                                        double* __restrict__ packed, double* __restrict__ scal,
+                                                        const LmState* lm, int enq_cur, const double* block_cost_alt,
+                                                        const int32_t* block_fail_alt, int final_pass) {
+  if (lm) {
+    if (lm->done && !final_pass) return;
+    if (lm->cur != enq_cur) { block_cost = block_cost_alt; block_fail = block_fail_alt; }
+  }
   __shared__ double s_red[32][33];
   __shared__ int s_f[1024];
   const int tid = threadIdx.x;
@@ -1052,7 +1236,22 @@ struct SolveParams {
   int32_t n_frames, n_free, n_pairs, stride, fixed_slot;
   int32_t init_scale, jacobi;
   double radius, min_diag, max_diag;
+  // asynchronous driver
+  const LmState* lm;
+  int32_t enq_cur, final_pass;
+  const double* cams_alt; double* cams_cand_alt; const CamGeom* geom_alt; CamGeom* geom_cand_alt;
 };
+
+__device__ __forceinline__ bool solve_resolve(SolveParams& p) {
+  if (!p.lm) return true;
+  if (p.lm->done && !p.final_pass) return false;
+  if (p.lm->cur != p.enq_cur) {
+    p.cams = p.cams_alt; p.cams_cand = p.cams_cand_alt; p.geom = p.geom_alt;
+    if (p.geom_cand) p.geom_cand = p.geom_cand_alt;
+  }
+  p.radius = p.lm->radius;
+  return true;
+}
 
 __device__ __forceinline__ double readlane_f64(double v, int src_lane) {
   const unsigned lo = __builtin_amdgcn_readlane((unsigned)__double2loint(v), src_lane);
@@ -1156,7 +1355,9 @@ __device__ __forceinline__ void solve_epilogue(const SolveParams& p, int n, cons
 // a[c] -= t_r * v_c and the factor entry is L_rj = v_r * rsqrt(v_j): no second broadcast, no barriers (one wave).
 // The other three waves only help with the prologue / epilogue.
 template <int NF>
-__global__ __launch_bounds__(256) void k_solve_wave(SolveParams p) {
+__global__ __launch_bounds__(256) void k_solve_wave(SolveParams p_in) {
+  SolveParams p = p_in;
+  if (!solve_resolve(p)) return;
   constexpr int N = 6 * NF;
   constexpr int LD = N + 1;
   __shared__ double S[N * LD];
@@ -1222,7 +1423,9 @@ __global__ __launch_bounds__(256) void k_solve_wave(SolveParams p) {
 // Generic path (any n <= 96): matrix in LDS, 256 threads, 2-D trailing update, one barrier pair per column.
 constexpr int kSolveThreads = 256;
 
-__global__ __launch_bounds__(kSolveThreads) void k_solve_generic(SolveParams p) {
+__global__ __launch_bounds__(kSolveThreads) void k_solve_generic(SolveParams p_in) {
+  SolveParams p = p_in;
+  if (!solve_resolve(p)) return;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int n = 6 * p.n_free;
   const int ld = n + 1;

@@ -17,9 +17,93 @@
 #include "../../include/pba.h"
 
 #include "pba_internal.h"
+#include "pba_device.h"
 
 namespace {
 double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+}
+
+// Asynchronous variant: the same trust-region rules are evaluated on the device by the last workgroup of every
+// candidate pass (pba_kernels.h: lm_decide), so the host enqueues iterations back to back (at most kAhead in flight
+// beyond the last one it has seen finish) instead of paying a launch + completion round trip per step.
+static int solve_async(pba_engine* e, const pba_solver_options* o, pba_solver_summary* sum, pba_iteration_summary* its,
+                       int32_t max_out, double t_start, bool verbose) {
+  using pba::LmState;
+  constexpr int kAhead = 3;
+  int rc = pba_internal_async_begin(e, o);
+  if (rc) return rc;
+  const volatile LmState* st = static_cast<const volatile LmState*>(pba_internal_async_state(e));
+  unsigned long long seq = 0, seqs[kAhead + 1] = {0};
+  if ((rc = pba_internal_async_enqueue(e, 0, 0, o, &seq))) return rc;
+  int enq = 0;
+  unsigned long long last_seq = 0;
+  while (enq < o->max_num_iterations && !st->done) {
+    if ((rc = pba_internal_async_enqueue(e, 1, enq == 0 ? 1 : 0, o, &seq))) return rc;
+    seqs[enq % (kAhead + 1)] = seq;
+    last_seq = seq;
+    ++enq;
+    if (enq > kAhead) { if ((rc = pba_internal_async_wait(e, seqs[(enq - kAhead) % (kAhead + 1)]))) return rc; }
+  }
+  if (last_seq && (rc = pba_internal_async_wait(e, last_seq))) return rc;
+  if (o->max_num_iterations <= 0 || (st->pending_grad >= 0 && (st->done == pba::kLmRunning || st->done == pba::kLmMaxIterations))) {
+    // gradient norms of the final point (iteration limit reached right after an accepted step, or max_it == 0)
+    if ((rc = pba_internal_async_enqueue(e, 2, o->max_num_iterations <= 0 ? 1 : 0, o, &seq))) return rc;
+    if ((rc = pba_internal_async_wait(e, seq))) return rc;
+  }
+  if ((rc = pba_internal_async_end(e))) return rc;
+  LmState fin;
+  std::memcpy(&fin, const_cast<const LmState*>(static_cast<const LmState*>(pba_internal_async_state(e))), sizeof(fin));
+  const pba_iteration_summary* log = pba_internal_async_log(e);
+  const double total = now() - t_start;
+  const int n_log = fin.n_log;
+  for (int i = 0; i < n_log && i < max_out && its; ++i) {
+    its[i] = log[i];
+    its[i].iteration_time_in_seconds = total / (n_log > 0 ? n_log : 1);
+    its[i].cumulative_time_in_seconds = total * (i + 1) / (n_log > 0 ? n_log : 1);
+    if (verbose)
+      std::printf("%4d  cost % .6e  change % .3e  |grad| %.3e  |step| %.3e  rho % .3e  radius %.3e  %s\n", its[i].iteration, its[i].cost,
+                  its[i].cost_change, its[i].gradient_max_norm, its[i].step_norm, its[i].relative_decrease, its[i].trust_region_radius,
+                  its[i].step_is_successful ? "ok" : (its[i].step_is_valid ? "rejected" : "invalid"));
+  }
+  sum->initial_cost = fin.initial_cost;
+  sum->final_cost = fin.minimum_cost;
+  sum->num_successful_steps = fin.num_successful;
+  sum->num_unsuccessful_steps = fin.num_unsuccessful;
+  sum->num_iterations = n_log < max_out ? n_log : max_out;
+  sum->num_resolve_passes = fin.num_unsuccessful;
+  pba_internal_pass_counts(e, &sum->num_jacobian_passes, &sum->num_cost_passes);
+  switch (fin.done) {
+    case pba::kLmGradientTolerance:
+      sum->termination_type = 0;
+      std::snprintf(sum->message, sizeof(sum->message), "Gradient tolerance reached. Gradient max norm: %e <= %e", fin.last_value[0], o->gradient_tolerance);
+      break;
+    case pba::kLmMinRadius:
+      sum->termination_type = 0;
+      std::snprintf(sum->message, sizeof(sum->message), "Minimum trust region radius reached. Trust region radius: %e <= %e", fin.radius, o->min_trust_region_radius);
+      break;
+    case pba::kLmParameterTolerance:
+      sum->termination_type = 0;
+      std::snprintf(sum->message, sizeof(sum->message), "Parameter tolerance reached. Relative step_norm: %e <= %e.", fin.last_value[0], o->parameter_tolerance);
+      break;
+    case pba::kLmFunctionTolerance:
+      sum->termination_type = 0;
+      std::snprintf(sum->message, sizeof(sum->message), "Function tolerance reached. |cost_change|/cost: %e <= %e", fin.last_value[0], o->function_tolerance);
+      break;
+    case pba::kLmInvalidSteps:
+      sum->termination_type = 2;
+      std::snprintf(sum->message, sizeof(sum->message), "Number of consecutive invalid steps more than Solver::Options::max_num_consecutive_invalid_steps: %d", o->max_num_consecutive_invalid_steps);
+      break;
+    case pba::kLmEvalFailure:
+      sum->termination_type = 2;
+      std::snprintf(sum->message, sizeof(sum->message), fin.n_log == 0 ? "Initial residual and Jacobian evaluation failed." : "Residual and Jacobian evaluation failed.");
+      break;
+    default:
+      sum->termination_type = 1;
+      std::snprintf(sum->message, sizeof(sum->message), "Maximum number of iterations reached. Number of iterations: %d.", fin.iteration);
+      break;
+  }
+  sum->total_time_in_seconds = now() - t_start;
+  return PBA_OK;
 }
 
 extern "C" int pba_solve(pba_engine* e, const pba_solver_options* o, pba_solver_summary* sum, pba_iteration_summary* its,
@@ -35,6 +119,10 @@ extern "C" int pba_solve(pba_engine* e, const pba_solver_options* o, pba_solver_
   sum->num_residuals = (int32_t)(blocks * pba_internal_patch_len(e));
   sum->fixed_cost = 0.0;   // every residual block has a free point
   const bool verbose = o->verbose && pba_internal_rank(e) == 0;
+  if (pba_internal_async_capable(e, o)) {
+    pba_internal_reset_pass_counts(e);
+    return solve_async(e, o, sum, its, max_out, t_start, verbose);
+  }
 
   int n_it = 0;
   auto push = [&](const pba_iteration_summary& s) {

@@ -141,7 +141,7 @@ class Engine:
         return rec
 
     # ---- the LM loop ---------------------------------------------------------------------------------------
-    def solve(self, options=None, max_iterations_out=512):
+    def solve(self, options=None, max_iterations_out=512, fetch_state=True):
         o = options or default_solver_options()
         s = _lib.SolverSummary()
         its = (_lib.IterationSummary * max_iterations_out)()
@@ -150,7 +150,8 @@ class Engine:
         res["message"] = s.message.decode()
         res["iterations"] = [{f: getattr(its[i], f) for f, _ in _lib.IterationSummary._fields_}
                              for i in range(s.num_iterations)]
-        res["cams"], res["xyz"] = self.get_state()
+        if fetch_state:
+            res["cams"], res["xyz"] = self.get_state()
         return res
 
     # ---- multi-GPU -------------------------------------------------------------------------------------------
