@@ -10,10 +10,12 @@
 #include <csignal>
 #include <cstdio>
 #include <fstream>
+#include <memory>
 #include <string>
 #include <vector>
 
 #include "../host/photobundle.h"
+#include "../host/photobundle_pyramid.h"
 #include "../host/pose_utils.h"
 #include "../host/utils.h"
 
@@ -66,7 +68,11 @@ int main(int argc, char** argv) {
     if (!readPgm(data + name, img, rows, cols)) throw std::runtime_error("cannot read the first frame");
 
     PhotometricBundleAdjustment::Result result;
-    PhotometricBundleAdjustment photoba(calib, ImageSize(rows, cols), {cf});
+    const int num_levels = cf.get<int>("numLevels", 1);   // > 1: coarse-to-fine (photobundle_pyramid path)
+    std::unique_ptr<PhotometricBundleAdjustment> photoba;
+    std::unique_ptr<PhotometricBundleAdjustmentPyr> photoba_pyr;
+    if (num_levels > 1) photoba_pyr.reset(new PhotometricBundleAdjustmentPyr(num_levels, calib, ImageSize(rows, cols), {cf}));
+    else photoba.reset(new PhotometricBundleAdjustment(calib, ImageSize(rows, cols), {cf}));
     for (int f_i = 0; f_i < (int)T_init.size() && !gStop; ++f_i) {
       std::snprintf(name, sizeof(name), "/image_%06d.pgm", f_i);
       int r2, c2;
@@ -77,7 +83,8 @@ int main(int argc, char** argv) {
       std::ifstream dfs(data + name, std::ios::binary);
       if (!dfs.read(reinterpret_cast<char*>(depth.data()), depth.size() * sizeof(float))) throw std::runtime_error("bad depth file");
       std::printf("Frame %05d\n", f_i);
-      photoba.addFrame(img.data(), depth.data(), T_init[f_i], &result);
+      if (photoba_pyr) photoba_pyr->addFrame(img.data(), depth.data(), T_init[f_i], &result);
+      else photoba->addFrame(img.data(), depth.data(), T_init[f_i], &result);
     }
     std::fprintf(stderr, "Writing refined poses to %s\n", output.c_str());
     writePosesKittiFormat(output, result.poses);

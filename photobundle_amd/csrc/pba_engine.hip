@@ -572,6 +572,7 @@ int pba_internal_step(pba_engine* e, double radius, int32_t init_scale, const pb
   so.init_scale = init_scale; so.jacobi = o->jacobi_scaling; so.radius = radius; so.min_diag = o->min_lm_diagonal;
   so.max_diag = o->max_lm_diagonal;
   so.lm = nullptr;
+  so.dbg = (e->dbg_left > 0) ? 1 : 0;
   launch_solve(e, so, n);
   const unsigned long long seq = ++e->seq;
   unsigned long long* h_seq_dev = reinterpret_cast<unsigned long long*>(e->h_scal_dev + kNumScal);

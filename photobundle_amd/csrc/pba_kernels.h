@@ -1239,6 +1239,7 @@ struct SolveParams {
   // asynchronous driver
   const LmState* lm;
   int32_t enq_cur, final_pass;
+  int32_t dbg;
   const double* cams_alt; double* cams_cand_alt; const CamGeom* geom_alt; CamGeom* geom_cand_alt;
 };
 
@@ -1361,11 +1362,13 @@ __global__ __launch_bounds__(256) void k_solve_wave(SolveParams p_in) {
   constexpr int N = 6 * NF;
   constexpr int LD = N + 1;
   __shared__ double S[N * LD];
-  __shared__ __attribute__((aligned(16))) double s_col[64];
+  __shared__ __attribute__((aligned(16))) double s_col[128];
   __shared__ double y_s[N], sc[N], D2[N], gcs[N], gc[N];
   __shared__ int s_ok;
   const int tid = threadIdx.x;
+  unsigned long long t0 = __builtin_amdgcn_s_memtime(), t1 = 0, t2 = 0, t3 = 0, t4 = 0;
   solve_prologue<256>(p, N, LD, S, y_s, sc, D2, gcs, gc, tid);
+  t1 = __builtin_amdgcn_s_memtime();
   if (tid < 64) {
     const int lane = tid;
     const int r = lane < N ? lane : N - 1;
@@ -1375,23 +1378,34 @@ __global__ __launch_bounds__(256) void k_solve_wave(SolveParams p_in) {
     double y = lane < N ? y_s[r] : 0.0;
     double d_own = 1.0;      // 1 / L_rr of this lane's row
     bool ok = true;
+    // look-ahead: column j+1 is finished and broadcast (double-buffered) BEFORE the rest of column j's trailing
+    // update, so the LDS round trip and the rsqrt chain of the next pivot overlap the FMAs of this one
+    s_col[lane] = a[0];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
     for (int j = 0; j < N; ++j) {
-      s_col[lane] = a[j];
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      const double piv = s_col[j];
+      const double* col = s_col + (j & 1) * 64;
+      double* col_next = s_col + ((j + 1) & 1) * 64;
+      const double piv = col[j];
       ok = ok && (piv > 0.0) && isfinite(piv);
       const double pv = (piv > 0.0) ? piv : 1.0;
       const double inv = fast_rsqrt(pv);
-      const double t = a[j] * fast_rcp(pv);
+      const double t = a[j] * (inv * inv);
       if (lane == j) d_own = inv;
       a[j] = a[j] * inv;                 // L_rj (lane j: sqrt(piv))
+      if (j + 1 < N) {
+        a[j + 1] = fma(-t, col[j + 1], a[j + 1]);
+        col_next[lane] = a[j + 1];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      }
 #pragma unroll
-      for (int c = j + 1; c < N; ++c) a[c] = fma(-t, s_col[c], a[c]);   // meaningful for lanes >= c
+      for (int c = j + 2; c < N; ++c) a[c] = fma(-t, col[c], a[c]);   // meaningful for lanes >= c
       __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
+    t2 = __builtin_amdgcn_s_memtime();
     // L to LDS (row-major) for the transposed access of the backward sweep
 #pragma unroll
     for (int c = 0; c < N; ++c) if (lane < N && c <= lane) S[r * LD + c] = a[c];
@@ -1415,9 +1429,12 @@ __global__ __launch_bounds__(256) void k_solve_wave(SolveParams p_in) {
     }
     if (lane < N) y_s[lane] = y;
     if (lane == 0) s_ok = ok ? 1 : 0;
+    t3 = __builtin_amdgcn_s_memtime();
   }
   __syncthreads();
   solve_epilogue<256>(p, N, y_s, sc, D2, gcs, gc, s_ok != 0, tid);
+  t4 = __builtin_amdgcn_s_memtime();
+  if (p.dbg && tid == 0) printf("k_solve_wave cycles: prologue %llu cholesky %llu substitution %llu epilogue %llu\n", t1 - t0, t2 - t1, t3 - t2, t4 - t3);
 }
 
 // Generic path (any n <= 96): matrix in LDS, 256 threads, 2-D trailing update, one barrier pair per column.

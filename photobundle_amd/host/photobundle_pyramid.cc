@@ -1,0 +1,124 @@
+// photobundle_pyramid.cc -- see photobundle_pyramid.h
+#include "photobundle_pyramid.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <stdexcept>
+
+namespace {
+inline int reflect101(int i, int n) {
+  if (n == 1) return 0;
+  while (i < 0 || i >= n) i = (i < 0) ? -i : 2 * n - 2 - i;
+  return i;
+}
+}  // namespace
+
+void pyrDownU8(const uint8_t* src, int rows, int cols, std::vector<uint8_t>& dst) {
+  const int drows = (rows + 1) / 2, dcols = (cols + 1) / 2;
+  dst.assign((size_t)drows * dcols, 0);
+  static const int w[5] = {1, 4, 6, 4, 1};
+  std::vector<int> hrow((size_t)dcols);
+  std::vector<int> hbuf((size_t)rows * dcols);
+  for (int y = 0; y < rows; ++y) {           // horizontal pass at the even columns, integer sums
+    const uint8_t* s = src + (size_t)y * cols;
+    for (int x = 0; x < dcols; ++x) {
+      int acc = 0;
+      for (int k = 0; k < 5; ++k) acc += w[k] * (int)s[reflect101(2 * x + k - 2, cols)];
+      hbuf[(size_t)y * dcols + x] = acc;
+    }
+  }
+  for (int y = 0; y < drows; ++y) {
+    for (int x = 0; x < dcols; ++x) {
+      int acc = 0;
+      for (int k = 0; k < 5; ++k) acc += w[k] * hbuf[(size_t)reflect101(2 * y + k - 2, rows) * dcols + x];
+      dst[(size_t)y * dcols + x] = (uint8_t)((acc + 128) >> 8);
+    }
+  }
+}
+
+void resizeBilinearF32(const float* src, int rows, int cols, int drows, int dcols, std::vector<float>& dst) {
+  dst.assign((size_t)drows * dcols, 0.0f);
+  const double scale_x = (double)cols / dcols, scale_y = (double)rows / drows;
+  std::vector<int> sx(dcols);
+  std::vector<float> ax(dcols);
+  for (int dx = 0; dx < dcols; ++dx) {
+    float fx = (float)((dx + 0.5) * scale_x - 0.5);
+    int ix = (int)std::floor(fx);
+    fx -= ix;
+    if (ix < 0) { fx = 0.f; ix = 0; }
+    if (ix >= cols - 1) { fx = 0.f; ix = cols - 1; }
+    sx[dx] = ix; ax[dx] = fx;
+  }
+  for (int dy = 0; dy < drows; ++dy) {
+    float fy = (float)((dy + 0.5) * scale_y - 0.5);
+    int iy = (int)std::floor(fy);
+    fy -= iy;
+    if (iy < 0) { fy = 0.f; iy = 0; }
+    if (iy >= rows - 1) { fy = 0.f; iy = rows - 1; }
+    const float* r0 = src + (size_t)iy * cols;
+    const float* r1 = src + (size_t)std::min(iy + 1, rows - 1) * cols;
+    for (int dx = 0; dx < dcols; ++dx) {
+      const int x0 = sx[dx], x1 = std::min(x0 + 1, cols - 1);
+      const float a1 = ax[dx], a0 = 1.f - a1;
+      const float h0 = r0[x0] * a0 + r0[x1] * a1;
+      const float h1 = r1[x0] * a0 + r1[x1] * a1;
+      dst[(size_t)dy * dcols + dx] = h0 * (1.f - fy) + h1 * fy;
+    }
+  }
+}
+
+PhotometricBundleAdjustmentPyr::PhotometricBundleAdjustmentPyr(int num_levels, const Calibration& calib,
+                                                               const ImageSize& im_size, const Options& options)
+    : _rows(im_size.rows), _cols(im_size.cols) {
+  if (num_levels <= 0) throw std::runtime_error("num_levels must be > 0");
+  Calibration calib_pyr(calib);
+  ImageSize size_pyr(im_size);
+  for (int i = 0; i < num_levels; ++i) {
+    _pyr.emplace_back(new PhotometricBundleAdjustment(calib_pyr, size_pyr, options));
+    _sizes.push_back(size_pyr);
+    calib_pyr = calib_pyr.pyrDown();
+    size_pyr = size_pyr.pyrDown();
+  }
+  _im_pyr.resize(num_levels);
+  _z_pyr.resize(num_levels);
+}
+
+PhotometricBundleAdjustmentPyr::~PhotometricBundleAdjustmentPyr() {}
+
+void PhotometricBundleAdjustmentPyr::addFrame(const uint8_t* image, const float* depth, const Mat44& T, Result* result) {
+  const int n = (int)_pyr.size();
+  _im_pyr[0].assign(image, image + (size_t)_rows * _cols);
+  _z_pyr[0].assign(depth, depth + (size_t)_rows * _cols);
+  for (int i = 1; i < n; ++i) {
+    pyrDownU8(_im_pyr[i - 1].data(), _sizes[i - 1].rows, _sizes[i - 1].cols, _im_pyr[i]);
+    resizeBilinearF32(_z_pyr[i - 1].data(), _sizes[i - 1].rows, _sizes[i - 1].cols, _sizes[i].rows, _sizes[i].cols, _z_pyr[i]);
+  }
+  Mat44 T_init(T);
+  Result last;
+  for (int i = n - 1; i >= 0; --i) {
+    std::fprintf(stderr, "Pyramid level %d\n", i);
+    Result tmp;
+    _pyr[i]->addFrame(_im_pyr[i].data(), _z_pyr[i].data(), T_init, &tmp);
+    const size_t m = tmp.poses.size();
+    if (m >= 2) {
+      // an optimisation ran at this level: hand its refined frame-to-frame pose to the next finer level
+      // (T_w_i = T_w_(i-1) * inv(T_i)  =>  T_i = inv(T_w_i) * T_w_(i-1), reference src/trajectory.cc:7-16)
+      T_init = tmp.poses[m - 1].inverse() * tmp.poses[m - 2];
+    }
+    if (i == 0) last = tmp;
+  }
+  if (result) *result = last;
+}
+
+// C hooks (tests bind them through ctypes)
+extern "C" void pb_pyr_down_u8(const uint8_t* src, int rows, int cols, uint8_t* dst) {
+  std::vector<uint8_t> d;
+  pyrDownU8(src, rows, cols, d);
+  std::copy(d.begin(), d.end(), dst);
+}
+extern "C" void pb_resize_bilinear_f32(const float* src, int rows, int cols, int drows, int dcols, float* dst) {
+  std::vector<float> d;
+  resizeBilinearF32(src, rows, cols, drows, dcols, d);
+  std::copy(d.begin(), d.end(), dst);
+}

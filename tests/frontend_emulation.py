@@ -174,3 +174,78 @@ class Emulator:
             self.results.append(dict(n_points=len(sel), n_obs=len(obs_p), initial_cost=res["initial_cost"],
                                      final_cost=res["final_cost"], iterations=len(res["iterations"])))
         self.points = [p for p in self.points if p.f[0] > start]
+
+
+# ---- coarse-to-fine wrapper (intended behaviour of reference src/photobundle_pyramid.cc, see host/photobundle_pyramid.h) --
+def _reflect101(i, n):
+    i = np.asarray(i)
+    if n == 1:
+        return np.zeros_like(i)
+    i = np.abs(i)
+    return np.where(i >= n, 2 * n - 2 - i, i)
+
+
+def pyr_down_u8(img):
+    """cv::pyrDown for u8: 5x5 binomial, BORDER_REFLECT_101, (sum + 128) >> 8, size ((cols+1)/2, (rows+1)/2)."""
+    rows, cols = img.shape
+    w = np.array([1, 4, 6, 4, 1], np.int64)
+    drows, dcols = (rows + 1) // 2, (cols + 1) // 2
+    xs = 2 * np.arange(dcols)[:, None] + np.arange(-2, 3)[None, :]
+    h = (img.astype(np.int64)[:, _reflect101(xs, cols)] * w).sum(-1)                 # [rows, dcols]
+    ys = 2 * np.arange(drows)[:, None] + np.arange(-2, 3)[None, :]
+    v = (h[_reflect101(ys, rows), :] * w[None, :, None]).sum(1)                      # [drows, dcols]
+    return ((v + 128) >> 8).astype(np.uint8)
+
+
+def resize_bilinear_f32(src, drows, dcols):
+    """cv::resize INTER_LINEAR for float32 (horizontal pass then vertical, float arithmetic)."""
+    rows, cols = src.shape
+    f32 = np.float32
+
+    def axis(n_src, n_dst):
+        f = ((np.arange(n_dst) + 0.5) * (n_src / n_dst) - 0.5).astype(f32)
+        i = np.floor(f).astype(np.int64)
+        a = (f - i.astype(f32)).astype(f32)
+        lo = i < 0
+        a[lo] = 0
+        i[lo] = 0
+        hi = i >= n_src - 1
+        a[hi] = 0
+        i[hi] = n_src - 1
+        return i, a
+    ix, ax = axis(cols, dcols)
+    iy, ay = axis(rows, drows)
+    x1 = np.minimum(ix + 1, cols - 1)
+    y1 = np.minimum(iy + 1, rows - 1)
+    s = src.astype(f32)
+    a0 = (f32(1) - ax).astype(f32)
+    h0 = (s[iy][:, ix] * a0 + s[iy][:, x1] * ax).astype(f32)
+    h1 = (s[y1][:, ix] * a0 + s[y1][:, x1] * ax).astype(f32)
+    b1 = ay[:, None]
+    return (h0 * (f32(1) - b1) + h1 * b1).astype(f32)
+
+
+class PyramidEmulator:
+    def __init__(self, levels, K, size, **kw):
+        self.levels = levels
+        self.emus = []
+        fx, fy, cx, cy = K
+        rows, cols = size
+        for _ in range(levels):
+            self.emus.append(Emulator((fx, fy, cx, cy), (rows, cols), **kw))
+            fx, fy, cx, cy = 0.5 * fx, 0.5 * fy, 0.5 * cx, 0.5 * cy      # Calibration::pyrDown: K * 0.5, K(2,2) = 1
+            rows, cols = (rows + 1) // 2, (cols + 1) // 2
+
+    def add_frame(self, img, depth, T_local):
+        ims, zs = [img], [depth.astype(np.float32)]
+        for l in range(1, self.levels):
+            ims.append(pyr_down_u8(ims[-1]))
+            zs.append(resize_bilinear_f32(zs[-1], *ims[-1].shape))
+        T = T_local
+        for l in range(self.levels - 1, -1, -1):
+            emu = self.emus[l]
+            n_before = len(emu.results)
+            emu.add_frame(ims[l], zs[l], T)
+            if len(emu.results) > n_before and len(emu.T_w) >= 2:
+                T = np.linalg.inv(emu.T_w[-1]) @ emu.T_w[-2]
+        return self.emus[0]

@@ -68,3 +68,29 @@ def test_run_kitti_matches_emulated_reference_pipeline(tmp_path):
     from photobundle_amd import se3
     chained = np.stack([T[:3, :] for T in se3.chain_local_poses(local)])
     assert np.abs(refined - chained).max() > 1e-6
+
+
+@pytest.mark.timeout(1500)
+def test_pyramid_path_matches_emulation(tmp_path):
+    """configs[2] (photobundle_pyramid path): 2-level coarse-to-fine through run_kitti (numLevels = 2)."""
+    from frontend_emulation import PyramidEmulator
+    size, K = (160, 224), (280.0, 280.0, 112.0, 80.0)
+    n_frames, window, radius, max_points = 5, 3, 1, 100000
+    tmp = str(tmp_path)
+    imgs, depths, local = _write_sequence(tmp, n_frames, size, K)
+    cfg = os.path.join(tmp, "pyr.cfg")
+    with open(cfg, "w") as f:
+        f.write("DataDirectory = %s\nTrajectory = %s/init.txt\n" % (tmp, tmp))
+        f.write("numLevels = 2\nmaxNumPoints = %d\nslidingWindowSize = %d\npatchRadius = %d\nminScore = 0.65\nrobustThreshold = 0.05\nverbose = 0\n"
+                % (max_points, window, radius))
+    out = os.path.join(tmp, "refined.txt")
+    r = subprocess.run([RUN, "-c", cfg, "-o", out], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stderr.count("Pyramid level 1") == n_frames and r.stderr.count("Pyramid level 0") == n_frames
+    refined = np.loadtxt(out).reshape(-1, 3, 4)
+    emu = PyramidEmulator(2, K, size, window=window, radius=radius, max_points=max_points, min_score=0.65, huber=0.05)
+    for im, z, T in zip(imgs, depths, local):
+        fine = emu.add_frame(im, z, T)
+    assert len(fine.results) == n_frames - window + 1
+    ref = np.stack([T[:3, :] for T in fine.T_w])
+    assert np.abs(refined - ref).max() <= 1e-5, np.abs(refined - ref).max()
