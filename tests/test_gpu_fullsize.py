@@ -85,3 +85,35 @@ def test_sixteen_frame_window_large():
         assert a["step_is_successful"] == b["step_is_successful"]
         assert np.isclose(a["cost"], b["cost"], rtol=1e-9)
     assert np.abs(res["cams"] - ref["cams"]).max() <= 1e-5
+
+
+@pytest.mark.timeout(1500)
+def test_configs4_shape_huber_11x11():
+    """configs[4] shape: 8 frames, 50k points, 11x11 patches, Huber a = 0.05 (48.4 M residuals).  The oracle still does
+    the cost and ONE LM iteration at this size; beyond that the check is the size-independent monotone-cost property."""
+    from oracle import oracle
+    from photobundle_amd import synthetic
+    from photobundle_amd.engine import default_solver_options
+    from gpu_util import make_engine
+    p = synthetic.make_window(n_frames=8, n_points=50000, radius=5, huber=0.05)
+    assert p.n_obs == 400000 and p.patch_len == 121
+    c_ref, sq = oracle.cost(p, threads=8)
+    with make_engine(p, keep_reduced_system=False) as e:
+        c = e.linearize()
+        assert np.isclose(c, c_ref, rtol=1e-12)
+        rec = e.obs_records()
+        a = p.huber
+        rho = np.where(sq > a * a, 2 * a * np.sqrt(sq) - a * a, sq)
+        assert np.allclose(rec[:, 5], 0.5 * rho, rtol=1e-12)
+    ref = oracle.solve(p, oracle.default_options(max_num_iterations=1, num_threads=8, use_autodiff=0))
+    with make_engine(p, keep_reduced_system=False) as e:
+        res = e.solve(default_solver_options(max_num_iterations=6))
+    for a_, b_ in zip(ref["iterations"], res["iterations"][:2]):
+        assert a_["step_is_successful"] == b_["step_is_successful"]
+        assert np.isclose(a_["cost"], b_["cost"], rtol=1e-9)
+    cost = res["iterations"][0]["cost"]
+    for it in res["iterations"][1:]:
+        if it["step_is_successful"]:
+            assert it["cost"] < cost
+            cost = it["cost"]
+    assert res["num_residuals"] == 400000 * 121
