@@ -4,6 +4,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <cstdlib>
 #include <cstring>
 
 namespace pba {
@@ -55,17 +56,19 @@ int Comm::init_rccl(const void* id128, int rank_, int world_) {
   if (rc != ncclSuccess) { err = std::string("ncclCommInitRank: ") + r.GetErrorString(rc); return 1; }
   if (hipMalloc(reinterpret_cast<void**>(&d_small), 64 * sizeof(double)) != hipSuccess) { err = "hipMalloc(d_small)"; return 1; }
   nccl_comm = c; world = world_; rank = rank_; kind = 1;
+  if (const char* f = getenv("PBA_FORCE_MULTI")) force = atoi(f) != 0;
   return 0;
 }
 
 int Comm::init_callback(pba_allreduce_fn f, void* c, int rank_, int world_) {
   shutdown();
   fn = f; ctx = c; world = world_; rank = rank_; kind = 2;
+  if (const char* fm = getenv("PBA_FORCE_MULTI")) force = atoi(fm) != 0;
   return 0;
 }
 
 int Comm::allreduce_device(double* d, size_t n, int op, hipStream_t s) {
-  if (world <= 1 || n == 0) return 0;
+  if (!multi() || n == 0) return 0;
   if (kind == 1) {
     Rccl& r = rccl();
     const ncclResult_t rc = r.AllReduce(d, d, n, ncclDouble, op == 0 ? ncclSum : ncclMax, static_cast<ncclComm_t>(nccl_comm), s);
@@ -89,7 +92,7 @@ int Comm::allreduce_device(double* d, size_t n, int op, hipStream_t s) {
 }
 
 int Comm::allreduce_host(double* h, int n, int op) {
-  if (world <= 1 || n <= 0) return 0;
+  if (!multi() || n <= 0) return 0;
   if (n > 64) { err = "allreduce_host: n > 64"; return 1; }
   if (kind == 2) {
     if (fn(h, n, op, ctx) != 0) { err = "all-reduce callback failed"; return 1; }
@@ -109,7 +112,7 @@ void Comm::shutdown() {
   if (kind == 1 && nccl_comm) { rccl().CommDestroy(static_cast<ncclComm_t>(nccl_comm)); nccl_comm = nullptr; }
   if (h_stage) { (void)hipHostFree(h_stage); h_stage = nullptr; stage_cap = 0; }
   if (d_small) { (void)hipFree(d_small); d_small = nullptr; }
-  kind = 0; world = 1; rank = 0; fn = nullptr; ctx = nullptr;
+  kind = 0; world = 1; rank = 0; fn = nullptr; ctx = nullptr; force = false;
 }
 
 }  // namespace pba

@@ -15,6 +15,7 @@ namespace pba {
 struct Comm {
   int world = 1, rank = 0;
   int kind = 0;   // 0 none, 1 rccl, 2 callback
+  bool force = false;   // PBA_FORCE_MULTI=1: run the multi-rank code path (and the collectives) even at world == 1
   std::string err;
   hipStream_t stream = nullptr;
 
@@ -34,6 +35,7 @@ struct Comm {
   int allreduce_device(double* d, size_t n, int op, hipStream_t s);
   // in-place all-reduce of n (<= 64) host doubles
   int allreduce_host(double* h, int n, int op);
+  bool multi() const { return world > 1 || (force && kind != 0); }
   void shutdown();
 };
 

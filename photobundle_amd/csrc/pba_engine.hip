@@ -64,6 +64,7 @@ struct pba_engine {
   int cost_blocks[2] = {0, 0};      // valid entries in d_block_cost[k] (grid of the pass that wrote them)
   double* d_bs_out = nullptr;       // [backsub_grid][3]
   double* d_scal = nullptr;         // [kNumScal]
+  double* d_xchg = nullptr;         // [kSumBCount + kMaxCount * world] multi-rank exchange buffer
   double* h_scal = nullptr;         // pinned + mapped: [kNumScal] doubles then one u64 sequence number
   double* h_scal_dev = nullptr;     // device view of h_scal
   unsigned long long seq = 0;
@@ -201,6 +202,21 @@ SampleParams make_sample_params(pba_engine* e, int which_point) {
   return sp;
 }
 
+// ONE sum all-reduce for the step scalars of all ranks (sum group + rank-slotted max group, see k_xchg_pack)
+int exchange_step_scalars(pba_engine* e) {
+  const int world = e->comm.world;
+  const size_t n = (size_t)kSumBCount + (size_t)kMaxCount * world;
+  if (!e->d_xchg) {
+    int rc = dev_alloc(e, &e->d_xchg, n);
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(k_xchg_pack, dim3(1), dim3(64), 0, e->stream, e->d_scal, e->d_xchg, e->comm.rank, world);
+  HIP_TRY(e, hipGetLastError());
+  if (e->comm.allreduce_device(e->d_xchg, n, 0, e->stream))
+    return fail(e, PBA_ERR_COMM, "allreduce(step scalars) failed: %s", e->comm.err.c_str());
+  return PBA_OK;
+}
+
 void ev_begin(pba_engine* e, int k) { if (e->profile) { (void)hipEventRecord(e->ev[2 * k], e->stream); } }
 void ev_end(pba_engine* e, int k) { if (e->profile) { (void)hipEventRecord(e->ev[2 * k + 1], e->stream); e->ev_used[k] = true; } }
 void ev_collect(pba_engine* e) {
@@ -315,7 +331,7 @@ void pba_destroy(pba_engine* e) {
   dev_free(&e->d_desc); dev_free(&e->d_w2); dev_free(&e->d_obs_point); dev_free(&e->d_obs_slot); dev_free(&e->d_pt_begin);
   dev_free(&e->d_tile_info); dev_free(&e->d_obs_l0); dev_free(&e->d_obs_cnt); dev_free(&e->d_rec[0]); dev_free(&e->d_rec[1]); dev_free(&e->d_sp); dev_free(&e->d_ptrec); dev_free(&e->d_sc);
   dev_free(&e->d_delta_c); dev_free(&e->d_partial); dev_free(&e->d_red); dev_free(&e->d_packed); dev_free(&e->d_S);
-  dev_free(&e->d_rhs); dev_free(&e->d_bs_out); dev_free(&e->d_scal); dev_free(&e->d_ticket);
+  dev_free(&e->d_rhs); dev_free(&e->d_bs_out); dev_free(&e->d_scal); dev_free(&e->d_xchg); dev_free(&e->d_ticket);
   if (e->h_scal) (void)hipHostFree(e->h_scal);
   if (e->h_lm) (void)hipHostFree(e->h_lm);
   if (e->h_log) (void)hipHostFree(e->h_log);
@@ -507,7 +523,7 @@ int pba_linearize(pba_engine* e, double* cost) {
     ev_collect(e);
     double c = 0.0;
     for (double v : bc) c += v;
-    if (e->comm.world > 1) {
+    if (e->comm.multi()) {
       if (e->comm.allreduce_host(&c, 1, 0)) return fail(e, PBA_ERR_COMM, "allreduce(cost) failed: %s", e->comm.err.c_str());
     }
     *cost = c;
@@ -527,7 +543,7 @@ int pba_internal_step(pba_engine* e, double radius, int32_t init_scale, const pb
   HIP_TRY(e, hipSetDevice(e->cfg.device));
   const int cur = e->cur, cand = 1 - e->cur;
   const int n = 6 * e->n_free;
-  const bool multi = e->comm.world > 1;
+  const bool multi = e->comm.multi();
 
   SchurParams sc{};
   sc.xyz = e->d_xyz[cur]; sc.geom = e->d_geom[cur]; sc.rec = e->d_rec[cur]; sc.obs_point = e->d_obs_point;
@@ -624,12 +640,12 @@ int pba_internal_step(pba_engine* e, double radius, int32_t init_scale, const pb
   }
   HIP_TRY(e, hipGetLastError());
   if (multi) {
-    if ((!grad_only && e->comm.allreduce_device(e->d_scal + kCandCost, kSumBCount, 0, e->stream)) ||
-        e->comm.allreduce_device(e->d_scal + kGmaxPts, kMaxCount, 1, e->stream))
-      return fail(e, PBA_ERR_COMM, "allreduce(step scalars) failed: %s", e->comm.err.c_str());
+    int rc2 = exchange_step_scalars(e);
+    if (rc2) return rc2;
   }
   if (multi || grad_only) {
-    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, e->stream, e->d_scal, e->h_scal_dev, h_seq_dev, seq);
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, e->stream, e->d_scal, e->h_scal_dev, h_seq_dev, seq,
+                       (const double*)(multi ? e->d_xchg : nullptr), e->comm.world);
     HIP_TRY(e, hipGetLastError());
   }
   // wait for the device to publish this step's scalar block (host-mapped memory, no driver round trip)
@@ -761,7 +777,7 @@ int pba_internal_async_begin(pba_engine* e, const pba_solver_options* o) {
 int pba_internal_async_enqueue(pba_engine* e, int kind, int init_scale, const pba_solver_options* o, unsigned long long* seq_out) {
   const int cur = e->async_cur, cand = 1 - cur;
   const int n = 6 * e->n_free;
-  const bool multi = e->comm.world > 1;
+  const bool multi = e->comm.multi();
   unsigned long long* h_seq_dev = reinterpret_cast<unsigned long long*>(e->h_scal_dev + kNumScal);
   *seq_out = 0;
   auto sample_params = [&](bool skip) {
@@ -818,18 +834,15 @@ int pba_internal_async_enqueue(pba_engine* e, int kind, int init_scale, const pb
     launch_sample<true, true>(e, sp);
     e->jac_passes++;
     HIP_TRY(e, hipGetLastError());
-    if (multi) {
-      if (e->comm.allreduce_device(e->d_scal + kCandCost, kSumBCount, 0, e->stream) ||
-          e->comm.allreduce_device(e->d_scal + kGmaxPts, kMaxCount, 1, e->stream))
-        return fail(e, PBA_ERR_COMM, "allreduce(step scalars) failed: %s", e->comm.err.c_str());
-    }
-  } else if (multi) {
-    if (e->comm.allreduce_device(e->d_scal + kGmaxPts, kMaxCount, 1, e->stream))
-      return fail(e, PBA_ERR_COMM, "allreduce(step scalars) failed: %s", e->comm.err.c_str());
+  }
+  if (multi) {
+    int rc2 = exchange_step_scalars(e);
+    if (rc2) return rc2;
   }
   if (multi || kind == 2) {
     DecideParams dp{};
     dp.lm = e->d_lm; dp.host_state = e->h_lm_dev; dp.scal = e->d_scal; dp.host_scal = e->h_scal_dev; dp.log = e->h_log_dev;
+    dp.xchg = multi ? e->d_xchg : nullptr; dp.world = e->comm.world;
     dp.max_log = pba_engine::kMaxLog; dp.grad_only = (kind == 2) ? 1 : 0; dp.host_seq = h_seq_dev; dp.seq = seq;
     hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, e->stream, dp);
   }
@@ -879,7 +892,7 @@ void pba_internal_set_speculate(pba_engine* e, int on) {
 void pba_internal_pass_counts(const pba_engine* e, int64_t* jac, int64_t* cost) { *jac = e->jac_passes; *cost = e->cost_passes; }
 void pba_internal_reset_pass_counts(pba_engine* e) { e->jac_passes = 0; e->cost_passes = 0; }
 int pba_internal_allreduce_host(pba_engine* e, double* v, int n, int op) {
-  if (e->comm.world <= 1) return 0;
+  if (!e->comm.multi()) return 0;
   return e->comm.allreduce_host(v, n, op);
 }
 }  // extern "C"

@@ -348,15 +348,39 @@ __device__ inline void lm_publish(const LmState* st, LmState* host_state, const 
   if (tid == 0) { *reinterpret_cast<volatile unsigned long long*>(host_seq) = seq; __threadfence_system(); }
 }
 
+// ---- multi-rank exchange of the step scalars in ONE sum all-reduce -----------------------------------------------
+// xchg = [ sum group (kSumBCount) | world x max group (kMaxCount) ]: every rank writes its max-group values into its
+// own slot and zeros into the others, so the SUM all-reduce doubles as an all-gather; the max is taken afterwards.
+__global__ void k_xchg_pack(const double* __restrict__ scal, double* __restrict__ xchg, int rank, int world) {
+  const int i = threadIdx.x;
+  if (i < kSumBCount) xchg[i] = scal[kCandCost + i];
+  for (int k = i; k < kMaxCount * world; k += blockDim.x) {
+    const int r = k / kMaxCount, j = k - r * kMaxCount;
+    xchg[kSumBCount + k] = (r == rank) ? scal[kGmaxPts + j] : 0.0;
+  }
+}
+__device__ inline void xchg_unpack(const double* xchg, double* scal, int world) {   // one thread
+  for (int i = 0; i < kSumBCount; ++i) scal[kCandCost + i] = xchg[i];
+  for (int j = 0; j < kMaxCount; ++j) {
+    double m = xchg[kSumBCount + j];
+    for (int r = 1; r < world; ++r) m = fmax(m, xchg[kSumBCount + kMaxCount * r + j]);
+    scal[kGmaxPts + j] = m;
+  }
+}
+
 struct DecideParams {
   LmState* lm; LmState* host_state;
-  const double* scal; double* host_scal;
+  double* scal; double* host_scal;
+  const double* xchg; int32_t world;
   pba_iteration_summary* log; int32_t max_log; int32_t grad_only;
   unsigned long long* host_seq; unsigned long long seq;
 };
 
 __global__ void k_decide(DecideParams p) {
-  if (threadIdx.x == 0) lm_decide(p.lm, p.scal, p.log, p.max_log, p.grad_only);
+  if (threadIdx.x == 0) {
+    if (p.xchg) xchg_unpack(p.xchg, p.scal, p.world);
+    lm_decide(p.lm, p.scal, p.log, p.max_log, p.grad_only);
+  }
   __syncthreads();
   lm_publish(p.lm, p.host_state, p.scal, p.host_scal, p.host_seq, p.seq, threadIdx.x, blockDim.x);
 }
@@ -1595,9 +1619,13 @@ __global__ __launch_bounds__(256) void k_finalize_step(const double* __restrict_
 
 // Publishes the (already reduced) scalar block to host-mapped memory: used after the multi-rank all-reduces and
 // for gradient-only steps.
-__global__ void k_publish(const double* __restrict__ scal, double* host_scal, unsigned long long* host_seq,
-                          unsigned long long seq) {
+__global__ void k_publish(double* __restrict__ scal, double* host_scal, unsigned long long* host_seq,
+                          unsigned long long seq, const double* xchg, int world) {
   const int tid = threadIdx.x;
+  if (xchg) {
+    if (tid == 0) xchg_unpack(xchg, scal, world);
+    __syncthreads();
+  }
   if (tid < kNumScal) host_scal[tid] = scal[tid];
   __threadfence_system();
   __syncthreads();

@@ -86,3 +86,33 @@ def test_rccl_transport_initialises_single_rank():
         e.comm_init_rccl(Engine.comm_unique_id(), 0, 1)
         res = e.solve(default_solver_options(max_num_iterations=4))
     assert np.array_equal(res["cams"], ref["cams"]) and res["final_cost"] == ref["final_cost"]
+
+
+def test_rccl_collectives_on_the_device_stream(tmp_path):
+    """PBA_FORCE_MULTI=1 runs the multi-rank code path of both drivers (packed reduced system + one scalar exchange,
+    k_decide / k_publish after the collectives) with real ncclAllReduce calls on the engine's stream, world = 1."""
+    import subprocess
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from photobundle_amd.engine import Engine, default_solver_options\n"
+        "from gpu_util import make_engine\n"
+        "import test_gpu_multirank as t\n"
+        "p = t._make()\n"
+        "e = make_engine(p); e.comm_init_rccl(Engine.comm_unique_id(), 0, 1)\n"
+        "res = e.solve(default_solver_options(max_num_iterations=8)); e.close()\n"
+        "np.savez(%r + '/out_' + sys.argv[1] + '.npz', cams=res['cams'], xyz=res['xyz'], costs=np.array([i['cost'] for i in res['iterations']]),"
+        " g=np.array([i['gradient_max_norm'] for i in res['iterations']]))\n"
+    ) % (ROOT, os.path.join(ROOT, "tests"), str(tmp_path))
+    outs = {}
+    for tag, env in [("plain", {}), ("multi_async", {"PBA_FORCE_MULTI": "1"}), ("multi_sync", {"PBA_FORCE_MULTI": "1", "PBA_ASYNC": "0"})]:
+        r = subprocess.run([sys.executable, "-c", code, tag], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs[tag] = np.load(tmp_path / ("out_%s.npz" % tag))
+    # same driver, same kernels, collectives are identities at world = 1: bit-identical
+    assert np.array_equal(outs["multi_async"]["costs"], outs["plain"]["costs"])
+    assert np.array_equal(outs["multi_async"]["cams"], outs["plain"]["cams"]) and np.array_equal(outs["multi_async"]["xyz"], outs["plain"]["xyz"])
+    # the synchronous driver linearises the first point on a different workgroup grid (different summation order)
+    assert np.allclose(outs["multi_sync"]["costs"], outs["plain"]["costs"], rtol=1e-11)
+    assert np.abs(outs["multi_sync"]["cams"] - outs["plain"]["cams"]).max() <= 1e-9
+    for tag in ("multi_async", "multi_sync"):
+        assert np.allclose(outs[tag]["g"], outs["plain"]["g"], rtol=1e-9)
