@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define PBA_MAX_FRAMES 32
+#define PBA_MAX_FRAMES 16
 #define PBA_MAX_RADIUS 5
 
 typedef struct pba_engine pba_engine;
