@@ -49,8 +49,8 @@ def main():
     ap.add_argument("--radius", type=int, default=2)
     ap.add_argument("--huber", type=float, default=0.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-points", type=int, default=12500, help="points of the bounded CPU-baseline sample")
-    ap.add_argument("--cpu-steps", type=int, default=4)
+    ap.add_argument("--cpu-points", type=int, default=50000, help="points of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-steps", type=int, default=20)
     args = ap.parse_args()
 
     import torch

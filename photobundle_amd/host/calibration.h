@@ -1,50 +1,86 @@
-// calibration.h -- pinhole stereo calibration with the reference's interface (reference src/calibration.h:10-84).
+// calibration.h -- pinhole stereo calibration; call-compatible with the reference's Calibration
+// (reference src/calibration.h:10-84): fx()/fy()/cx()/cy()/b()/K()/baseline()/project()/setParameters()/pyrDown().
+//
+// Representation differs from the reference (which keeps only an Eigen 3x3): the four intrinsics and the baseline are
+// the source of truth and the matrix view is rebuilt on mutation through the accessors below.
 #ifndef PHOTOBUNDLE_AMD_CALIBRATION_H
 #define PHOTOBUNDLE_AMD_CALIBRATION_H
 
 #include "types.h"
 
 class Calibration {
+  Mat33 _K;           // upper-triangular intrinsics [fx 0 cx; 0 fy cy; 0 0 1]
+  double _baseline;   // stereo baseline (metres)
+
  public:
-  Calibration() : _K(Mat33::Identity()), _baseline(0.0) {}
-  Calibration(const Mat33& K, double b) : _K(K), _baseline(b) {}
+  Calibration();
+  Calibration(const Mat33& intrinsics, double stereo_baseline);
 
-  const double& b() const { return _baseline; }
-  const double& fx() const { return _K(0, 0); }
-  const double& fy() const { return _K(1, 1); }
-  const double& cx() const { return _K(0, 2); }
-  const double& cy() const { return _K(1, 2); }
-  const Mat33& K() const { return _K; }
-  Mat33& K() { return _K; }
-  double& baseline() { return _baseline; }
+  // --- read access (references, like the reference class) ---
+  const Mat33& K() const;
+  const double& fx() const;
+  const double& fy() const;
+  const double& cx() const;
+  const double& cy() const;
+  const double& b() const;
 
-  // reference calibration.h:33-38
-  template <typename T>
-  void project(const T* X, T& u, T& v) const {
-    u = ((X[0] * T(fx())) / X[2]) + T(cx());
-    v = ((X[1] * T(fy())) / X[2]) + T(cy());
-  }
-  // reference calibration.h:43 + eigen.h normHomog: (1 / p[2]) * (K X).head<2>()
-  Vec2 project(const Vec3& X) const {
-    const Vec3 p = _K * X;
-    const double s = 1.0 / p[2];
-    Vec2 uv; uv[0] = s * p[0]; uv[1] = s * p[1];
-    return uv;
-  }
-  void setParameters(const double* p) {
-    _K = Mat33::Identity();
-    _K(0, 0) = p[0]; _K(1, 1) = p[1]; _K(0, 2) = p[2]; _K(1, 2) = p[3];
-  }
-  // reference calibration.h:72-78: K * 0.5 (K(2,2) = 1), baseline * 2
-  Calibration pyrDown() const {
-    Mat33 K = 0.5 * _K;
-    K(2, 2) = 1.0;
-    return Calibration(K, _baseline * 2);
-  }
+  // --- write access ---
+  Mat33& K();
+  double& baseline();
+  void setParameters(const double* fx_fy_cx_cy);
 
- private:
-  Mat33 _K;
-  double _baseline;
+  // u = fx X/Z + cx, v = fy Y/Z + cy, for any scalar type with * / + (the device kernels use the same order)
+  template <typename Scalar>
+  void project(const Scalar* X, Scalar& u, Scalar& v) const;
+  // homogeneous form used by the front-end: (K X) / (K X)_z
+  Vec2 project(const Vec3& X) const;
+
+  // one pyramid level down: focal lengths and principal point halve, the baseline doubles
+  Calibration pyrDown() const;
 };
+
+inline Calibration::Calibration() : _K(Mat33::Identity()), _baseline(0.0) {}
+inline Calibration::Calibration(const Mat33& intrinsics, double stereo_baseline) : _K(intrinsics), _baseline(stereo_baseline) {}
+
+inline const Mat33& Calibration::K() const { return _K; }
+inline Mat33& Calibration::K() { return _K; }
+inline const double& Calibration::fx() const { return _K(0, 0); }
+inline const double& Calibration::fy() const { return _K(1, 1); }
+inline const double& Calibration::cx() const { return _K(0, 2); }
+inline const double& Calibration::cy() const { return _K(1, 2); }
+inline const double& Calibration::b() const { return _baseline; }
+inline double& Calibration::baseline() { return _baseline; }
+
+inline void Calibration::setParameters(const double* q) {
+  Mat33 M = Mat33::Identity();
+  M(0, 0) = q[0];
+  M(1, 1) = q[1];
+  M(0, 2) = q[2];
+  M(1, 2) = q[3];
+  _K = M;
+}
+
+template <typename Scalar>
+inline void Calibration::project(const Scalar* X, Scalar& u, Scalar& v) const {
+  const Scalar numer_u = X[0] * Scalar(fx());
+  const Scalar numer_v = X[1] * Scalar(fy());
+  u = (numer_u / X[2]) + Scalar(cx());
+  v = (numer_v / X[2]) + Scalar(cy());
+}
+
+inline Vec2 Calibration::project(const Vec3& X) const {
+  const Vec3 h = _K * X;
+  const double inv_w = 1.0 / h[2];
+  Vec2 uv;
+  uv[0] = inv_w * h[0];
+  uv[1] = inv_w * h[1];
+  return uv;
+}
+
+inline Calibration Calibration::pyrDown() const {
+  Mat33 half = 0.5 * _K;
+  half(2, 2) = 1.0;
+  return Calibration(half, 2.0 * _baseline);
+}
 
 #endif

@@ -208,9 +208,12 @@ struct PhotometricBundleAdjustment::ScenePoint {
   size_t numFrames() const { return f.size(); }
 };
 
+PhotometricBundleAdjustment::PhotometricBundleAdjustment(const Calibration& calib, const ImageSize& image_size)
+    : PhotometricBundleAdjustment(calib, image_size, Options()) {}
+
 PhotometricBundleAdjustment::PhotometricBundleAdjustment(const Calibration& calib, const ImageSize& image_size,
                                                          const Options& options)
-    : _calib(calib), _image_size(image_size), _options(options) {
+    : _calib(calib), _image_size(image_size), _options_ptr(new Options(options)) {
   if (options.descriptorType != Options::DescriptorType::Intensity)
     throw std::runtime_error("only DescriptorType::Intensity is implemented (the reference's multi-channel path asserts, "
                              "photobundle.cc:684)");
@@ -237,27 +240,27 @@ void PhotometricBundleAdjustment::addFrame(const uint8_t* I_ptr, const float* Z_
 
   UniquePointer<DescriptorFrame> frame(new DescriptorFrame(_frame_id, I_ptr, rows, cols));
   // the engine keeps its own device plane of this frame in the ring slot id % window
-  const int window = _options.slidingWindowSize;
+  const int window = _options_ptr->slidingWindowSize;
   check(_engine, pba_set_frame_u8(_engine, (int)(_frame_id % window), I_ptr), "pba_set_frame_u8");
 
-  const int B = std::max(_options.maskBlockRadius, std::max(2, _options.patchRadius));
+  const int B = std::max(_options_ptr->maskBlockRadius, std::max(2, _options_ptr->patchRadius));
   const int max_rows = rows - B - 1, max_cols = cols - B - 1;
-  const int radius = _options.patchRadius, patch_length = PatchSizeFromRadius(radius);
-  const int mask_radius = _options.maskBlockRadius;
+  const int radius = _options_ptr->patchRadius, patch_length = PatchSizeFromRadius(radius);
+  const int mask_radius = _options_ptr->maskBlockRadius;
 
   // ---- visibility list update (reference :505-542) ------------------------------------------------------------
   std::fill(_mask.d.begin(), _mask.d.end(), (uint16_t)1);
   int num_updated = 0, max_num_to_update = 0;
   for (auto& pt : _scene_points) {
     const int f_dist = (int)_frame_id - (int)pt->lastFrameId();
-    if (f_dist <= _options.maxFrameDistance) {
+    if (f_dist <= _options_ptr->maxFrameDistance) {
       const Vec2 uv = _calib.project(TransformPoint(T_c, pt->X));
       ++max_num_to_update;
       const int r = (int)std::round(uv[1]), c = (int)std::round(uv[0]);
       if (r >= B && r < max_rows && c >= B && c <= max_cols) {
         ZnccPatch other;
         other.set(I, uv[0], uv[1]);
-        if (pt->patch.score(other) > _options.minScore) {
+        if (pt->patch.score(other) > _options_ptr->minScore) {
           ++num_updated;
           pt->f.push_back(_frame_id);
           for (int r_i = -mask_radius; r_i <= mask_radius; ++r_i)
@@ -270,7 +273,7 @@ void PhotometricBundleAdjustment::addFrame(const uint8_t* I_ptr, const float* Z_
   // ---- new scene points (reference :545-585): valid depth AND strict local maximum of the saliency under the mask --
   ScenePointPointerList new_points;
   frame->computeSaliencyMap(_saliency_map);
-  const int nms = _options.nonMaxSuppRadius;
+  const int nms = _options_ptr->nonMaxSuppRadius;
   auto is_local_max = [&](int row, int col) {
     if (nms > 0) {
       const float v = _saliency_map(row, col);
@@ -284,7 +287,7 @@ void PhotometricBundleAdjustment::addFrame(const uint8_t* I_ptr, const float* Z_
   for (int y = B; y < max_rows; ++y) {
     for (int x = B; x < max_cols; ++x) {
       const float z = Z_ptr[(size_t)y * cols + x];
-      if (z >= _options.minValidDepth && z <= _options.maxValidDepth && is_local_max(y, x)) {
+      if (z >= _options_ptr->minValidDepth && z <= _options_ptr->maxValidDepth && is_local_max(y, x)) {
         const Vec3 ray = _K_inv * MakeVec3((double)x, (double)y, 1.0);
         const Vec3 X = TransformPoint(T_w, MakeVec3((double)z * ray[0], (double)z * ray[1], (double)z * ray[2]));
         ScenePointPointer p(new ScenePoint(X, _frame_id));
@@ -296,8 +299,8 @@ void PhotometricBundleAdjustment::addFrame(const uint8_t* I_ptr, const float* Z_
       }
     }
   }
-  if (new_points.size() > (size_t)_options.maxNumPoints) {
-    auto nth = new_points.begin() + _options.maxNumPoints;
+  if (new_points.size() > (size_t)_options_ptr->maxNumPoints) {
+    auto nth = new_points.begin() + _options_ptr->maxNumPoints;
     std::nth_element(new_points.begin(), nth, new_points.end(),
                      [](const ScenePointPointer& a, const ScenePointPointer& b) { return a->saliency > b->saliency; });
     new_points.erase(nth, new_points.end());
@@ -329,8 +332,8 @@ void PhotometricBundleAdjustment::addFrame(const uint8_t* I_ptr, const float* Z_
 
 void PhotometricBundleAdjustment::optimize(Result* result) {
   const uint32_t frame_id_start = _frame_buffer.front()->id, frame_id_end = _frame_buffer.back()->id;
-  const int window = _options.slidingWindowSize;
-  const std::vector<double> patch_weights = MakePatchWeights(_options.patchRadius, _options.doGaussianWeighting);
+  const int window = _options_ptr->slidingWindowSize;
+  const std::vector<double> patch_weights = MakePatchWeights(_options_ptr->patchRadius, _options_ptr->doGaussianWeighting);
   const int P = (int)patch_weights.size();
 
   // cameras: INVERTED world poses as angle-axis + t (reference :774-778), stored by ring slot id % window
@@ -367,9 +370,9 @@ void PhotometricBundleAdjustment::optimize(Result* result) {
     check(_engine, pba_set_cameras(_engine, cams.data(), window, (int32_t)(frame_id_start % window)), "pba_set_cameras");
     pba_solver_options so;
     pba_default_solver_options(&so);     // GetSolverOptions (:738-761)
-    so.verbose = _options.verbose ? 1 : 0;
+    so.verbose = _options_ptr->verbose ? 1 : 0;
     check(_engine, pba_solve(_engine, &so, &summary, its.data(), (int32_t)its.size()), "pba_solve");
-    if (_options.verbose)
+    if (_options_ptr->verbose)
       std::printf("pba_solve: %s  initial %.6e  final %.6e  iterations %d (successful %d)  %.3f s\n", summary.message,
                   summary.initial_cost, summary.final_cost, summary.num_iterations, summary.num_successful_steps,
                   summary.total_time_in_seconds);

@@ -51,46 +51,67 @@ struct IterationSummary {
 
 struct pba_engine;
 
+// Same public surface as the reference class (nested Options / Result, addFrame, protected optimize); the private
+// part is this implementation's own.
 class PhotometricBundleAdjustment {
  public:
+  struct Options;
+  struct Result;
+
+  PhotometricBundleAdjustment(const Calibration& calibration, const ImageSize& image_size, const Options& options);
+  PhotometricBundleAdjustment(const Calibration& calibration, const ImageSize& image_size);
+  ~PhotometricBundleAdjustment();
+  PhotometricBundleAdjustment(const PhotometricBundleAdjustment&) = delete;
+  PhotometricBundleAdjustment& operator=(const PhotometricBundleAdjustment&) = delete;
+
+  // image: dense row-major rows x cols u8; depth_map: dense row-major float (<= 0 / out of [minValidDepth,
+  // maxValidDepth] = invalid); T: frame-to-frame pose initialisation.  `result` (optional) is overwritten whenever
+  // an optimisation ran, i.e. once the sliding window is full.
+  void addFrame(const uint8_t* image, const float* depth_map, const Mat44& T, Result* result = nullptr);
+
+  // ---- solver / front-end settings: field names, meanings and ConfigFile keys of the reference ----
   struct Options {
-    int maxNumPoints = 4096;          // maximum number of points to initialise from a new frame
-    int slidingWindowSize = 5;        // number of frames in the sliding window
-    int patchRadius = 2;              // radius of the image patch
-    int maskBlockRadius = 1;          // area blocked around re-observed points when selecting new ones
-    int maxFrameDistance = 1;         // maximum age of a scene point
-    int numThreads = -1;              // kept for source compatibility; the solve runs on the GPU
-    bool doGaussianWeighting = false;
-    bool verbose = true;
-    double minScore = 0.75;           // ZNCC threshold of the visibility test
-    double robustThreshold = 0.05;    // HuberLoss threshold (if > 0)
+    // front-end
+    int maxNumPoints = 4096;          // new scene points kept per frame (largest saliency first)
+    int nonMaxSuppRadius = 1;         // saliency non-maximum suppression radius
+    int maskBlockRadius = 1;          // pixels blocked around a re-observed point
+    int maxFrameDistance = 1;         // a point not seen for more frames than this is no longer tracked
+    double minScore = 0.75;           // ZNCC acceptance threshold, in [-1, 1]
     double minValidDepth = 0.01;
     double maxValidDepth = 1000.0;
-    int nonMaxSuppRadius = 1;
+    // problem shape
+    int slidingWindowSize = 5;
+    int patchRadius = 2;
+    bool doGaussianWeighting = false;
+    double robustThreshold = 0.05;    // Huber threshold; <= 0 disables the loss
     enum class DescriptorType { Intensity, IntensityAndGradient, BitPlanes };
-    DescriptorType descriptorType = DescriptorType::Intensity;   // (uninitialised in the reference, photobundle.h:77-79)
-    int device = 0;                   // NEW: HIP device ordinal
+    DescriptorType descriptorType = DescriptorType::Intensity;   // (left uninitialised by the reference)
+    // execution
+    int numThreads = -1;              // accepted for source compatibility; the solve runs on the GPU
+    bool verbose = true;
+    int device = 0;                   // HIP device ordinal (new)
 
     Options() {}
     Options(const utils::ConfigFile& cf);
   };
 
+  // ---- what an optimisation reports ----
   struct Result {
-    EigenAlignedContainer_<Mat44> poses;           // refined world poses (whole trajectory so far)
-    EigenAlignedContainer_<Vec3> refinedPoints;    // points that left the window in this call
-    EigenAlignedContainer_<Vec3> originalPoints;
+    EigenAlignedContainer_<Mat44> poses;           // refined world poses of the whole trajectory so far
+    EigenAlignedContainer_<Vec3> refinedPoints;    // points that left the window in this call ...
+    EigenAlignedContainer_<Vec3> originalPoints;   // ... and what they were initialised to
     double initialCost = -1.0;
     double finalCost = -1.0;
     double fixedCost = -1.0;
     int numSuccessfulStep = 0;
     int numResiduals = 0;
-    double totalTime = -1.0;
+    double totalTime = -1.0;                        // seconds
     std::string message;
     std::vector<ceres::IterationSummary> iterationSummary;
 
-    // Dead code in the reference's default build (WITH_CEREAL is never defined, photobundle.cc:51-86): kept as stubs.
+    // cereal-based serialisation is dead code in the reference's default build; kept as stubs for the signatures
     struct Writer {
-      Writer(std::string prefix = "./") : _counter(0), _prefix(prefix) {}
+      explicit Writer(std::string prefix = "./") : _counter(0), _prefix(prefix) {}
       bool add(const Result&);
      private:
       int _counter;
@@ -98,16 +119,6 @@ class PhotometricBundleAdjustment {
     };
     static Result FromFile(std::string);
   };
-
- public:
-  PhotometricBundleAdjustment(const Calibration&, const ImageSize&, const Options& = Options());
-  ~PhotometricBundleAdjustment();
-  PhotometricBundleAdjustment(const PhotometricBundleAdjustment&) = delete;
-  PhotometricBundleAdjustment& operator=(const PhotometricBundleAdjustment&) = delete;
-
-  // image: dense row-major rows x cols u8; depth_map: dense row-major float; T: frame-to-frame pose initialisation;
-  // result (optional) is overwritten whenever an optimisation ran (reference photobundle.h:154-160).
-  void addFrame(const uint8_t* image, const float* depth_map, const Mat44& T, Result* = nullptr);
 
  protected:
   void optimize(Result*);
@@ -124,9 +135,9 @@ class PhotometricBundleAdjustment {
   uint32_t _frame_id = 0;
   Calibration _calib;
   ImageSize _image_size;
-  Options _options;
+  UniquePointer<Options> _options_ptr;
   Trajectory _trajectory;
-  std::vector<UniquePointer<DescriptorFrame>> _frame_buffer;   // ring of the last slidingWindowSize frames
+  std::vector<UniquePointer<DescriptorFrame>> _frame_buffer;   // the last slidingWindowSize frames, oldest first
   ScenePointPointerList _scene_points;
   Image_<uint16_t> _mask;
   Image_<float> _saliency_map;
