@@ -190,7 +190,7 @@ def main():
     }
 
     # ---- CPU baseline: the oracle ("restated Ceres-equivalent CPU path") on a bounded sample, rank 0, N = 1 ----
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.cpu_steps > 0:
         from oracle import oracle
         n_cpu = min(args.cpu_points, prob.n_points)
         sub = prob.shard(0, 1)

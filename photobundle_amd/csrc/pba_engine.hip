@@ -554,7 +554,7 @@ int pba_internal_step(pba_engine* e, double radius, int32_t init_scale, const pb
   sc.min_diag = o->min_lm_diagonal; sc.max_diag = o->max_lm_diagonal;
   sc.dbg = nullptr; sc.lm = nullptr;
   if (e->dbg_left > 0) {
-    if (!e->d_dbg) { (void)hipMalloc(reinterpret_cast<void**>(&e->d_dbg), sizeof(unsigned long long) * 8 * 1024); }
+    if (!e->d_dbg) { (void)hipMalloc(reinterpret_cast<void**>(&e->d_dbg), sizeof(unsigned long long) * 8 * (1024 + 4096)); }
     sc.dbg = e->d_dbg;
   }
   ev_begin(e, 2);
@@ -599,6 +599,7 @@ int pba_internal_step(pba_engine* e, double radius, int32_t init_scale, const pb
     sp.xyz_prev = e->d_xyz[cur]; sp.rec_prev = e->d_rec[cur]; sp.sp = e->d_sp; sp.ptrec = e->d_ptrec;
     sp.delta_c = e->d_delta_c; sp.block_bs = e->d_bs_out; sp.ticket = e->d_ticket; sp.scal = e->d_scal;
     sp.host_scal = multi ? nullptr : e->h_scal_dev; sp.host_seq = h_seq_dev; sp.seq = seq; sp.n_tiles = e->n_tiles;
+    sp.dbg = (e->dbg_left > 0 && e->d_dbg) ? e->d_dbg + 8 * 1024 : nullptr;
     if (e->speculate) {
       ev_begin(e, 0);
       launch_sample<true, true>(e, sp);
@@ -612,6 +613,15 @@ int pba_internal_step(pba_engine* e, double radius, int32_t init_scale, const pb
     }
     e->cost_blocks[cand] = e->fused_grid;
     e->lin_valid[cand] = e->speculate;
+    if (sp.dbg) {
+      std::vector<unsigned long long> h(8 * (size_t)e->fused_grid);
+      (void)hipMemcpyAsync(h.data(), sp.dbg, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost, e->stream);
+      (void)hipStreamSynchronize(e->stream);
+      double avg[8] = {0};
+      for (int b = 0; b < e->fused_grid; ++b) for (int k = 0; k < 8; ++k) avg[k] += (double)h[8 * b + k] / e->fused_grid;
+      std::fprintf(stderr, "k_sample(fused) phase cycles/block: geom-stage %.0f  backsub %.0f  geometry+base %.0f  staging %.0f  walk %.0f  loss+reduce %.0f\n",
+                   avg[0], avg[1], avg[2], avg[3], avg[4], avg[5]);
+    }
   } else if (!grad_only) {
     BacksubParams bs{};
     bs.xyz = e->d_xyz[cur]; bs.xyz_cand = e->d_xyz[cand]; bs.geom = e->d_geom[cur]; bs.rec = e->d_rec[cur];

@@ -49,6 +49,16 @@ __device__ __forceinline__ void stage_geom(const CamGeom* __restrict__ src, CamG
   for (int k = tid; k < n; k += NT) d[k] = s[k];
 }
 
+// XCD-aware workgroup order (MI355X: 8 XCDs with private 4 MiB L2s; the dispatcher places workgroup b on XCD b % 8).
+// Returns the LOGICAL workgroup index for physical index b so that each XCD works on one contiguous eighth of the
+// logical range: observations are point-major and points are spatially sorted, so an XCD's L2 then only has to hold
+// its own band of every frame instead of all of it.  Placement is a speed hint only; any mapping is correct.
+__device__ __forceinline__ int xcd_logical_block(int b, int grid) {
+  const int q = grid >> 3, r = grid & 7;
+  const int x = b & 7, i = b >> 3;
+  return x * q + (x < r ? x : r) + i;
+}
+
 // Workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, i.e. it waits for every
 // outstanding global STORE of the wave (~1 us round trip) although nothing after the barrier depends on it.
 // Global LOADS stay correct: the compiler still waits for a load's result before its first use.
@@ -473,6 +483,7 @@ struct SampleParams {
   double* block_cost_alt;     // the other parity's block arrays
   int32_t* block_fail_alt;
   int32_t decide;             // run lm_decide in the last workgroup (single rank)
+  unsigned long long* dbg;    // optional [gridDim.x][8] per-phase cycle stamps of thread 0 (diagnostics)
 };
 
 // One LANE per observation (residual block); each wave stages the (2R+2)^2 texel footprints of its 64
@@ -502,7 +513,9 @@ __global__ __launch_bounds__(WAVES * 64, (R <= 2 ? (JAC ? 3 : 2) : 1)) void k_sa
   constexpr int W = 2 * R + 1;      // patch side
   constexpr int F = 2 * R + 2;      // footprint side
   constexpr int FF = F * F;
-  constexpr int LSTRIDE = 65;       // texel-major LDS layout [t][lane], odd stride: conflict-free both ways
+  // texel-major LDS layout [t][lane]: the walk reads stride-1 across lanes for any stride; 72 (= 8 mod 32) also keeps
+  // the staging stores of the vector row segments at the 2-way minimum.  R >= 4 needs the tighter 65 to fit 160 KB.
+  constexpr int LSTRIDE = (R <= 3) ? 72 : 65;
   constexpr size_t kTexBytes = sizeof(uint32_t) * WAVES * FF * LSTRIDE;
   constexpr size_t kPreBytes = sizeof(double) * 3 * WAVES * 64 + 2 * kMaxFrames * sizeof(CamGeom);
   __shared__ __attribute__((aligned(16))) char s_raw[kTexBytes > kPreBytes ? kTexBytes : kPreBytes];
@@ -513,16 +526,21 @@ __global__ __launch_bounds__(WAVES * 64, (R <= 2 ? (JAC ? 3 : 2) : 1)) void k_sa
 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  int obs = blockIdx.x * (WAVES * 64) + threadIdx.x;
+  const int bid = xcd_logical_block(blockIdx.x, gridDim.x);
+  int obs = bid * (WAVES * 64) + threadIdx.x;
   bool active = obs < p.n_obs;
   if (threadIdx.x == 0) s_fail = 0;
 
   // camera geometry tables -> LDS (the texel region is free until the staging phase)
   CamGeom* s_geom = reinterpret_cast<CamGeom*>(s_raw + sizeof(double) * 3 * WAVES * 64);
   CamGeom* s_geom_prev = s_geom + kMaxFrames;
+  unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tl = p.dbg ? __builtin_amdgcn_s_memtime() : 0;
+#define PBA_STK(k) do { if (p.dbg) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); tk[k] += tn - tl; tl = tn; } } while (0)
   stage_geom<WAVES * 64>(p.geom, s_geom, p.n_frames, threadIdx.x);
   if (FUSED && !p.skip_backsub) stage_geom<WAVES * 64>(p.geom_prev, s_geom_prev, p.n_frames, threadIdx.x);
   lds_barrier();
+  PBA_STK(0);
 
   int pt = 0, slot = 0;
   double X[3] = {0.0, 0.0, 0.0};
@@ -532,7 +550,7 @@ __global__ __launch_bounds__(WAVES * 64, (R <= 2 ? (JAC ? 3 : 2) : 1)) void k_sa
     // delta_p = -P (g_p + sum_l W_l^T delta_c[slot_l]),  W_l^T delta_c = Ap^T M' (Ac delta_c)
     double* s_bs = reinterpret_cast<double*>(&s_tex[0][0]);       // [WAVES * 64][3], reused before the staging
     const int half = threadIdx.x >> 7, lt = threadIdx.x & 127;
-    const int tile = blockIdx.x * ((WAVES * 64) / 128) + half;
+    const int tile = bid * ((WAVES * 64) / 128) + half;
     int4 ti = make_int4(0, 0, 0, 0);
     if (tile < p.n_tiles) ti = p.tile_info[tile];
     active = lt < ti.y;
@@ -599,6 +617,7 @@ __global__ __launch_bounds__(WAVES * 64, (R <= 2 ? (JAC ? 3 : 2) : 1)) void k_sa
     X[0] = p.xyz[3 * (size_t)pt]; X[1] = p.xyz[3 * (size_t)pt + 1]; X[2] = p.xyz[3 * (size_t)pt + 2];
   }
 
+  PBA_STK(1);
   // ---- phase 1: geometry, one lane per observation (fp64) ------------------------------------------------
   double u = 0.0, v = 0.0;
   float xf[W], yf[W];
@@ -624,32 +643,55 @@ __global__ __launch_bounds__(WAVES * 64, (R <= 2 ? (JAC ? 3 : 2) : 1)) void k_sa
   }
   s_base[wave][lane] = (active && regular) ? (int32_t)(slot * (p.rows * p.cols) + by * p.cols + bx) : -1;
   lds_barrier();
+  PBA_STK(2);
 
   // ---- phase 2: cooperative footprint staging global -> LDS ----------------------------------------------
-  // all loads of a batch are issued before the first LDS store so that the L2 latency is paid once per batch
-  constexpr int BATCH = (FF <= 64) ? FF : (FF == 100 ? 25 : 36);
-  static_assert(FF % BATCH == 0, "footprint batches");
+  // NCH consecutive lanes fetch one footprint row of one observation as CW-texel vectors, so one load instruction
+  // covers row r of OPI observations; the row offset r * cols is wave-uniform and the LDS destination of texel
+  // (r, c) is a compile-time offset from a per-lane base, which leaves almost no address arithmetic per load.
+  // All loads of a batch are issued before the first LDS store so that the L2 latency is paid once per batch.
+  constexpr int CW = (F % 4 == 0) ? 4 : (F % 3 == 0 ? 3 : 2);
+  constexpr int NCH = F / CW;
+  constexpr int OPI = 64 / NCH;
+  constexpr int NG = (64 + OPI - 1) / OPI;
+  constexpr int GB0 = 40 / (F * CW);
+  constexpr int GB = GB0 < 1 ? 1 : (GB0 > NG ? NG : GB0);
+  static_assert(NG % GB == 0, "footprint batches");
+  {
+    const int ch = lane % NCH, oi = lane / NCH;
+    const char* fbytes = reinterpret_cast<const char*>(p.frames);
 #pragma unroll 1
-  for (int n0 = 0; n0 < FF; n0 += BATCH) {
-    uint32_t tx[BATCH];
+    for (int g0 = 0; g0 < NG; g0 += GB) {
+      uint32_t tx[GB][F][CW];
+      int32_t bs[GB];
 #pragma unroll
-    for (int k = 0; k < BATCH; ++k) {
-      const int g = (n0 + k) * 64 + lane;
-      const int o = g / FF;
-      const int t = g - o * FF;
-      const int base = s_base[wave][o];
-      tx[k] = 0;
-      if (base >= 0) tx[k] = p.frames[(size_t)base + (t / F) * p.cols + (t % F)];
-    }
+      for (int gg = 0; gg < GB; ++gg) {
+        const int o = (g0 + gg) * OPI + oi;
+        bs[gg] = (oi < OPI && o < 64) ? s_base[wave][o & 63] : -1;
+        const uint32_t boff = ((uint32_t)bs[gg] + (uint32_t)(ch * CW)) * 4u;
 #pragma unroll
-    for (int k = 0; k < BATCH; ++k) {
-      const int g = (n0 + k) * 64 + lane;
-      const int o = g / FF;
-      s_tex[wave][(g - o * FF) * LSTRIDE + o] = tx[k];
+        for (int r = 0; r < F; ++r) {
+#pragma unroll
+          for (int j = 0; j < CW; ++j) tx[gg][r][j] = 0;
+          if (bs[gg] >= 0) __builtin_memcpy(tx[gg][r], fbytes + (boff + (uint32_t)(r * p.cols) * 4u), sizeof(uint32_t) * CW);
+        }
+      }
+#pragma unroll
+      for (int gg = 0; gg < GB; ++gg) {
+        const int o = (g0 + gg) * OPI + oi;
+        if (bs[gg] >= 0) {
+          uint32_t* dst = &s_tex[wave][(ch * CW) * LSTRIDE + o];
+#pragma unroll
+          for (int r = 0; r < F; ++r)
+#pragma unroll
+            for (int j = 0; j < CW; ++j) dst[(r * F + j) * LSTRIDE] = tx[gg][r][j];
+        }
+      }
     }
   }
   lds_barrier();
 
+  PBA_STK(3);
   // ---- phase 3: per-lane patch walk ------------------------------------------------------------------------
   double m11 = 0, m12 = 0, m22 = 0, b1 = 0, b2 = 0, cc = 0;
   if (active) {
@@ -735,6 +777,7 @@ __global__ __launch_bounds__(WAVES * 64, (R <= 2 ? (JAC ? 3 : 2) : 1)) void k_sa
     }
   }
 
+  PBA_STK(4);
   // ---- phase 4: loss (HuberLoss::Evaluate + Corrector with rho'' <= 0), record, block cost ---------------
   double cost_obs = 0.0;
   if (active) {
@@ -779,16 +822,19 @@ __global__ __launch_bounds__(WAVES * 64, (R <= 2 ? (JAC ? 3 : 2) : 1)) void k_sa
   if (threadIdx.x == 0) {
     if (FUSED) {
       // consumed by the last workgroup of THIS launch: write-through stores; a non-finite block poisons its cost
-      store_agent(p.block_cost + blockIdx.x, s_fail ? __longlong_as_double(0x7ff8000000000000ll) : red_out[0]);
-      store_agent(p.block_bs + 3 * blockIdx.x, red_out[NQ > 1 ? 1 : 0]);
-      store_agent(p.block_bs + 3 * blockIdx.x + 1, red_out[NQ > 2 ? 2 : 0]);
-      store_agent(p.block_bs + 3 * blockIdx.x + 2, red_out[NQ > 3 ? 3 : 0]);
-      p.block_fail[blockIdx.x] = s_fail;
+      store_agent(p.block_cost + bid, s_fail ? __longlong_as_double(0x7ff8000000000000ll) : red_out[0]);
+      store_agent(p.block_bs + 3 * bid, red_out[NQ > 1 ? 1 : 0]);
+      store_agent(p.block_bs + 3 * bid + 1, red_out[NQ > 2 ? 2 : 0]);
+      store_agent(p.block_bs + 3 * bid + 2, red_out[NQ > 3 ? 3 : 0]);
+      p.block_fail[bid] = s_fail;
     } else {
-      p.block_cost[blockIdx.x] = red_out[0];
-      p.block_fail[blockIdx.x] = s_fail;
+      p.block_cost[bid] = red_out[0];
+      p.block_fail[bid] = s_fail;
     }
   }
+  PBA_STK(5);
+  if (p.dbg && threadIdx.x == 0) for (int k = 0; k < 8; ++k) p.dbg[blockIdx.x * 8 + k] = tk[k];
+#undef PBA_STK
   if (FUSED) {
     // ---- step finalisation by the last workgroup to arrive (agent-scope release / acquire around the ticket) ----
     __shared__ int s_last;
