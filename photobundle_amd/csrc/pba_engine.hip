@@ -568,9 +568,20 @@ int pba_internal_step(pba_engine* e, double radius, int32_t init_scale, const pb
     for (int b = 0; b < e->schur_grid; ++b) for (int k = 0; k < 8; ++k) avg[k] += (double)h[8 * b + k] / e->schur_grid;
     std::fprintf(stderr, "k_schur phase cycles/block (stage, P1, P2sum, P2, P3a, P3b-write, P3b-acc): %.0f %.0f %.0f %.0f %.0f %.0f %.0f  tiles/block %.2f\n",
                  avg[0], avg[1], avg[2], avg[3], avg[4], avg[5], avg[6], (double)e->n_tiles / e->schur_grid);
+    {
+      const int rem = e->n_tiles % e->schur_grid;   // blocks [0, rem) run one tile more than the others
+      double d_long = 0, d_short = 0, d_max = 0; int n_long = 0, n_short = 0;
+      for (int b = 0; b < e->schur_grid; ++b) {
+        const double d = 0.01 * (double)h[8 * b + 7];
+        d_max = std::max(d_max, d);
+        if (b < rem) { d_long += d; ++n_long; } else { d_short += d; ++n_short; }
+      }
+      std::fprintf(stderr, "  k_schur tile loop: %d blocks with the extra tile %.2f us, %d others %.2f us, max %.2f us\n", n_long,
+                   n_long ? d_long / n_long : 0.0, n_short, n_short ? d_short / n_short : 0.0, d_max);
+    }
     --e->dbg_left;
   }
-  hipLaunchKernelGGL(k_reduce_final, dim3((e->part_stride + 31) / 32 + 1), dim3(1024), 0, e->stream, e->d_partial,
+  hipLaunchKernelGGL(k_reduce_final, dim3((e->part_stride + kReduceEntries - 1) / kReduceEntries + 1), dim3(1024), 0, e->stream, e->d_partial,
                      e->schur_grid, e->part_stride, e->d_block_cost[cur], e->d_block_fail[cur], e->cost_blocks[cur], e->d_packed,
                      e->d_scal, (const LmState*)nullptr, 0, (const double*)nullptr, (const int32_t*)nullptr, 0);
   HIP_TRY(e, hipGetLastError());
@@ -614,11 +625,43 @@ int pba_internal_step(pba_engine* e, double radius, int32_t init_scale, const pb
     e->cost_blocks[cand] = e->fused_grid;
     e->lin_valid[cand] = e->speculate;
     if (sp.dbg) {
-      std::vector<unsigned long long> h(8 * (size_t)e->fused_grid);
+      std::vector<unsigned long long> h(8 * (size_t)e->fused_grid + 8);
       (void)hipMemcpyAsync(h.data(), sp.dbg, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost, e->stream);
       (void)hipStreamSynchronize(e->stream);
       double avg[8] = {0};
-      for (int b = 0; b < e->fused_grid; ++b) for (int k = 0; k < 8; ++k) avg[k] += (double)h[8 * b + k] / e->fused_grid;
+      for (int b = 0; b < e->fused_grid; ++b) for (int k = 0; k < 6; ++k) avg[k] += (double)(h[8 * b + k] & 0xffffffffffffffull) / e->fused_grid;
+      // per-XCD timeline (the counters of different XCDs are not assumed to be synchronised)
+      {
+        unsigned long long g0 = ~0ull, g1 = 0;
+        for (int b = 0; b < e->fused_grid; ++b) { g0 = std::min(g0, h[8 * b + 6]); g1 = std::max(g1, h[8 * b + 7]); }
+        double mean_dur = 0.0;
+        for (int b = 0; b < e->fused_grid; ++b) mean_dur += 0.01 * (double)(h[8 * b + 7] - h[8 * b + 6]) / e->fused_grid;
+        std::fprintf(stderr, "k_sample(fused) timeline: first start -> last end %.2f us, mean block duration %.2f us\n",
+                     0.01 * (double)(g1 - g0), mean_dur);
+        int hist[16] = {0};
+        for (int b = 0; b < e->fused_grid; ++b) { int k = (int)((h[8 * b + 6] - g0) / 400); hist[k > 15 ? 15 : k]++; }
+        const unsigned long long* hf = &h[8 * (size_t)e->fused_grid];
+        std::fprintf(stderr, "  last workgroup: own work %.2f us, finalisation %.2f us (loads %.2f, reduce %.2f, decide %.2f)\n",
+                     0.01 * (double)hf[1], 0.01 * (double)hf[0], 0.01 * (double)hf[2], 0.01 * (double)hf[3], 0.01 * (double)hf[4]);
+        std::fprintf(stderr, "  block starts per 4 us bin:");
+        for (int k = 0; k < 16; ++k) std::fprintf(stderr, " %d", hist[k]);
+        std::fprintf(stderr, "\n");
+      }
+      for (int x = 0; x < 8; ++x) {
+        unsigned long long t0 = ~0ull, t1 = 0; int n = 0; int late = 0;
+        int mism = 0;
+        for (int b = 0; b < e->fused_grid; ++b) {
+          if ((int)(h[8 * b] >> 56) != x) continue;
+          t0 = std::min(t0, h[8 * b + 6]); t1 = std::max(t1, h[8 * b + 7]); ++n;
+          if ((b & 7) != x) ++mism;
+        }
+        unsigned long long first_end = ~0ull;
+        for (int b = 0; b < e->fused_grid; ++b) if ((int)(h[8 * b] >> 56) == x) first_end = std::min(first_end, h[8 * b + 7]);
+        for (int b = 0; b < e->fused_grid; ++b) if ((int)(h[8 * b] >> 56) == x && h[8 * b + 6] >= first_end) ++late;
+        (void)mism;
+        std::fprintf(stderr, "  xcd %d: %d blocks, span %.2f us, first block done after %.2f us, %d blocks started later than that\n",
+                     x, n, 0.01 * (double)(t1 - t0), 0.01 * (double)(first_end - t0), late);
+      }
       std::fprintf(stderr, "k_sample(fused) phase cycles/block: geom-stage %.0f  backsub %.0f  geometry+base %.0f  staging %.0f  walk %.0f  loss+reduce %.0f\n",
                    avg[0], avg[1], avg[2], avg[3], avg[4], avg[5]);
     }
@@ -819,7 +862,7 @@ int pba_internal_async_enqueue(pba_engine* e, int kind, int init_scale, const pb
   sc.min_diag = o->min_lm_diagonal; sc.max_diag = o->max_lm_diagonal; sc.dbg = nullptr;
   sc.lm = e->d_lm; sc.enq_cur = cur; sc.final_pass = (kind == 2) ? 1 : 0; sc.xyz_alt = e->d_xyz[cand]; sc.geom_alt = e->d_geom[cand]; sc.rec_alt = e->d_rec[cand];
   launch_schur(e, sc);
-  hipLaunchKernelGGL(k_reduce_final, dim3((e->part_stride + 31) / 32 + 1), dim3(1024), 0, e->stream, e->d_partial,
+  hipLaunchKernelGGL(k_reduce_final, dim3((e->part_stride + kReduceEntries - 1) / kReduceEntries + 1), dim3(1024), 0, e->stream, e->d_partial,
                      e->schur_grid, e->part_stride, e->d_block_cost[cur], e->d_block_fail[cur], e->fused_grid, e->d_packed,
                      e->d_scal, (const LmState*)e->d_lm, cur, (const double*)e->d_block_cost[cand], (const int32_t*)e->d_block_fail[cand], kind == 2 ? 1 : 0);
   HIP_TRY(e, hipGetLastError());

@@ -349,13 +349,32 @@ __device__ inline void lm_decide(LmState* st, const double* s, pba_iteration_sum
 }
 
 // Publishes state + scalars to the host mirror, then the sequence number.
+// Host-mapped (fine-grained, uncached) destinations: the stores go straight to the host, so waiting for their
+// acknowledgement (vmcnt) orders them before the sequence number; a system-scope release fence would instead write
+// back every dirty line of this XCD's L2 (megabytes of Jacobian records) from a single workgroup.
+__device__ __forceinline__ void store_system_u32(void* dst, unsigned v) {
+  __hip_atomic_store(reinterpret_cast<unsigned*>(dst), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void publish_seq(unsigned long long* host_seq, unsigned long long seq, int tid) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    __hip_atomic_store(host_seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+__device__ inline void publish_scal(const double* scal, double* host_scal, int tid, int nthreads) {
+  const unsigned* src = reinterpret_cast<const unsigned*>(scal);
+  for (int k = tid; k < 2 * kNumScal; k += nthreads) store_system_u32(reinterpret_cast<unsigned*>(host_scal) + k, src[k]);
+}
 __device__ inline void lm_publish(const LmState* st, LmState* host_state, const double* scal, double* host_scal,
                                   unsigned long long* host_seq, unsigned long long seq, int tid, int nthreads) {
-  if (host_scal) for (int k = tid; k < kNumScal; k += nthreads) host_scal[k] = scal[k];
-  if (host_state && tid == 0) *host_state = *st;
-  __threadfence_system();
-  __syncthreads();
-  if (tid == 0) { *reinterpret_cast<volatile unsigned long long*>(host_seq) = seq; __threadfence_system(); }
+  if (host_scal) publish_scal(scal, host_scal, tid, nthreads);
+  if (host_state) {
+    static_assert(sizeof(LmState) % 4 == 0, "word copy");
+    const unsigned* src = reinterpret_cast<const unsigned*>(st);
+    for (int k = tid; k < (int)(sizeof(LmState) / 4); k += nthreads) store_system_u32(reinterpret_cast<unsigned*>(host_state) + k, src[k]);
+  }
+  publish_seq(host_seq, seq, tid);
 }
 
 // ---- multi-rank exchange of the step scalars in ONE sum all-reduce -----------------------------------------------
@@ -513,15 +532,15 @@ __global__ __launch_bounds__(WAVES * 64, (R <= 2 ? (JAC ? 3 : 2) : 1)) void k_sa
   constexpr int W = 2 * R + 1;      // patch side
   constexpr int F = 2 * R + 2;      // footprint side
   constexpr int FF = F * F;
-  // texel-major LDS layout [t][lane]: the walk reads stride-1 across lanes for any stride; 72 (= 8 mod 32) also keeps
-  // the staging stores of the vector row segments at the 2-way minimum.  R >= 4 needs the tighter 65 to fit 160 KB.
-  constexpr int LSTRIDE = (R <= 3) ? 72 : 65;
+  // texel-major LDS layout [t][lane]: the walk reads stride-1 across lanes; the odd stride keeps the staging stores of
+  // the vector row segments at the 2-way minimum (64 lanes on 32 banks) and four workgroups within 160 KB of LDS.
+  constexpr int LSTRIDE = 65;
   constexpr size_t kTexBytes = sizeof(uint32_t) * WAVES * FF * LSTRIDE;
   constexpr size_t kPreBytes = sizeof(double) * 3 * WAVES * 64 + 2 * kMaxFrames * sizeof(CamGeom);
   __shared__ __attribute__((aligned(16))) char s_raw[kTexBytes > kPreBytes ? kTexBytes : kPreBytes];
   uint32_t (*s_tex)[FF * LSTRIDE] = reinterpret_cast<uint32_t (*)[FF * LSTRIDE]>(s_raw);
   __shared__ int32_t s_base[WAVES][64];
-  __shared__ double s_red[WAVES * 64];
+  __shared__ double s_red[4 * WAVES];
   __shared__ int32_t s_fail;
 
   const int lane = threadIdx.x & 63;
@@ -536,6 +555,7 @@ __global__ __launch_bounds__(WAVES * 64, (R <= 2 ? (JAC ? 3 : 2) : 1)) void k_sa
   CamGeom* s_geom_prev = s_geom + kMaxFrames;
   unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tl = p.dbg ? __builtin_amdgcn_s_memtime() : 0;
+  const unsigned long long t_begin = p.dbg ? __builtin_amdgcn_s_memrealtime() : 0;   // 100 MHz, device-wide
 #define PBA_STK(k) do { if (p.dbg) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); tk[k] += tn - tl; tl = tn; } } while (0)
   stage_geom<WAVES * 64>(p.geom, s_geom, p.n_frames, threadIdx.x);
   if (FUSED && !p.skip_backsub) stage_geom<WAVES * 64>(p.geom_prev, s_geom_prev, p.n_frames, threadIdx.x);
@@ -833,6 +853,8 @@ __global__ __launch_bounds__(WAVES * 64, (R <= 2 ? (JAC ? 3 : 2) : 1)) void k_sa
     }
   }
   PBA_STK(5);
+  tk[6] = t_begin; tk[7] = p.dbg ? __builtin_amdgcn_s_memrealtime() : 0;
+  tk[0] |= (unsigned long long)(__builtin_amdgcn_s_getreg(6164) & 15u) << 56;   // HW_REG_XCC_ID[3:0]
   if (p.dbg && threadIdx.x == 0) for (int k = 0; k < 8; ++k) p.dbg[blockIdx.x * 8 + k] = tk[k];
 #undef PBA_STK
   if (FUSED) {
@@ -845,14 +867,26 @@ __global__ __launch_bounds__(WAVES * 64, (R <= 2 ? (JAC ? 3 : 2) : 1)) void k_sa
     }
     __syncthreads();
     if (s_last) {
+      const unsigned long long t_fin0 = p.dbg ? __builtin_amdgcn_s_memrealtime() : 0;
       int* s_f = &s_base[0][0];                              // [NTH] ints, free by now
       double* s_r4 = reinterpret_cast<double*>(&s_tex[0][0]);   // [4][NTH] doubles, free by now
       double a0 = 0, a1 = 0, a2 = 0, a3 = 0; int f = 0;
-      for (int b = threadIdx.x; b < (int)gridDim.x; b += NTH) {
-        a0 += load_agent(p.block_bs + 3 * b); a1 += load_agent(p.block_bs + 3 * b + 1); a2 += load_agent(p.block_bs + 3 * b + 2);
-        const double c = load_agent(p.block_cost + b);
-        a3 += c; f |= (c != c) ? 1 : 0;
+      // 8 blocks' partials in flight per thread (every load misses this XCD's L2), summed in block order
+      for (int b0 = threadIdx.x; b0 < (int)gridDim.x; b0 += 8 * NTH) {
+        double v0[8], v1[8], v2[8], v3[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int b = b0 + k * NTH;
+          const bool ok = b < (int)gridDim.x;
+          v0[k] = ok ? load_agent(p.block_bs + 3 * b) : 0.0;
+          v1[k] = ok ? load_agent(p.block_bs + 3 * b + 1) : 0.0;
+          v2[k] = ok ? load_agent(p.block_bs + 3 * b + 2) : 0.0;
+          v3[k] = ok ? load_agent(p.block_cost + b) : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { a0 += v0[k]; a1 += v1[k]; a2 += v2[k]; a3 += v3[k]; f |= (v3[k] != v3[k]) ? 1 : 0; }
       }
+      const unsigned long long t_fin1 = p.dbg ? __builtin_amdgcn_s_memrealtime() : 0;
       a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3);
       f = __any(f) ? 1 : 0;
       if (lane == 0) { s_r4[wave] = a0; s_r4[WAVES + wave] = a1; s_r4[2 * WAVES + wave] = a2; s_r4[3 * WAVES + wave] = a3; s_f[wave] = f; }
@@ -864,15 +898,25 @@ __global__ __launch_bounds__(WAVES * 64, (R <= 2 ? (JAC ? 3 : 2) : 1)) void k_sa
         }
       }
       __syncthreads();
+      unsigned long long t_fin2 = 0, t_fin3 = 0;
       if (threadIdx.x == 0) {
+        t_fin2 = p.dbg ? __builtin_amdgcn_s_memrealtime() : 0;
         p.scal[kMccPts] = s_r4[0]; p.scal[kStep2Pts] = s_r4[WAVES]; p.scal[kX2Pts] = s_r4[2 * WAVES];
         p.scal[kCandCost] = s_r4[3 * WAVES]; p.scal[kEvalFailCand] = (double)s_f[0];
         *p.ticket = 0;
         if (p.lm && p.decide) lm_decide(p.lm, p.scal, p.log, p.max_log, 0);
+        t_fin3 = p.dbg ? __builtin_amdgcn_s_memrealtime() : 0;
       }
       if (p.host_scal) {
         __syncthreads();
         lm_publish(p.lm, (p.lm && p.decide) ? p.host_state : nullptr, p.scal, p.host_scal, p.host_seq, p.seq, threadIdx.x, NTH);
+      }
+      if (p.dbg && threadIdx.x == 0) {
+        p.dbg[(size_t)gridDim.x * 8] = __builtin_amdgcn_s_memrealtime() - t_fin0;
+        p.dbg[(size_t)gridDim.x * 8 + 1] = t_fin0 - t_begin;
+        p.dbg[(size_t)gridDim.x * 8 + 2] = t_fin1 - t_fin0;      // partial loads
+        p.dbg[(size_t)gridDim.x * 8 + 3] = t_fin2 - t_fin1;      // block reduction
+        p.dbg[(size_t)gridDim.x * 8 + 4] = t_fin3 - t_fin2;      // decision
       }
     }
   }
@@ -967,6 +1011,7 @@ __global__ __launch_bounds__(kTile, 2) void k_schur(SchurParams p_in) {
 
   unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tlast = p.dbg ? __builtin_amdgcn_s_memtime() : 0;
+  const unsigned long long t_rt0 = p.dbg ? __builtin_amdgcn_s_memrealtime() : 0;
 #define PBA_TICK(k) do { if (p.dbg) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); tph[k] += tn - tlast; tlast = tn; } } while (0)
   int4 ti_next = p.tile_info[min((int)blockIdx.x, p.n_tiles - 1)];
   for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
@@ -1182,6 +1227,7 @@ __global__ __launch_bounds__(kTile, 2) void k_schur(SchurParams p_in) {
     lds_barrier();
     PBA_TICK(6);
   }
+  if (p.dbg) tph[7] = __builtin_amdgcn_s_memrealtime() - t_rt0;     // tile loop, 100 MHz
   if (p.dbg && tid == 0) for (int k = 0; k < 8; ++k) p.dbg[blockIdx.x * 8 + k] = tph[k];
 #undef PBA_TICK
 
@@ -1229,6 +1275,7 @@ __global__ __launch_bounds__(kTile, 2) void k_schur(SchurParams p_in) {
 // sub-sums are combined by a fixed LDS tree.
 //   packed[0, stride-3) = T | rhs | g_c | diag(U);  packed[stride-3] = cost at the linearisation point (sum of the
 //   Jacobian-pass block costs);  packed[stride-2] = sum g_p^2;  scal[kGmaxPts / kSchurFail / kEvalFailLin] = max group.
+constexpr int kReduceEntries = 16;      // packed entries per workgroup of k_reduce_final (x 64 sub-chunks of blocks)
 __global__ __launch_bounds__(1024) void k_reduce_final(const double* __restrict__ partial, int n_blocks, int stride,
                                                         const double* __restrict__ block_cost,
                                                         const int32_t* __restrict__ block_fail, int n_cost_blocks,
@@ -1239,33 +1286,32 @@ __global__ __launch_bounds__(1024) void k_reduce_final(const double* __restrict_
     if (lm->done && !final_pass) return;
     if (lm->cur != enq_cur) { block_cost = block_cost_alt; block_fail = block_fail_alt; }
   }
-  __shared__ double s_red[32][33];
+  constexpr int EX = kReduceEntries, SUB = 1024 / EX;
+  __shared__ double s_red[SUB][EX + 1];
   __shared__ int s_f[1024];
   const int tid = threadIdx.x;
-  const int ex = tid & 31, sub = tid >> 5;
+  const int ex = tid % EX, sub = tid / EX;
   if ((int)blockIdx.x < (int)gridDim.x - 1) {
-    const int e = blockIdx.x * 32 + ex;
+    const int e = blockIdx.x * EX + ex;
     const bool valid = e < stride;
     const bool is_max = (e == stride - 3) || (e == stride - 1);
     double acc = 0.0;
     if (valid) {
-      // 8 loads in flight per thread, summed in block order (fixed)
-      int b = sub;
-      for (; b + 7 * 32 < n_blocks; b += 8 * 32) {
-        double v[8];
+      // 16 loads in flight per thread (all of them for <= 1024 partials), summed in block order (fixed)
+      for (int b = sub; b < n_blocks; b += 16 * SUB) {
+        double v[16];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = partial[(size_t)(b + 32 * k) * stride + e];
+        for (int k = 0; k < 16; ++k) {
+          const int bb = b + SUB * k;
+          v[k] = (bb < n_blocks) ? partial[(size_t)bb * stride + e] : 0.0;
+        }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) acc = is_max ? fmax(acc, v[k]) : acc + v[k];
-      }
-      for (; b < n_blocks; b += 32) {
-        const double v = partial[(size_t)b * stride + e];
-        acc = is_max ? fmax(acc, v) : acc + v;
+        for (int k = 0; k < 16; ++k) acc = is_max ? fmax(acc, v[k]) : acc + v[k];
       }
     }
     s_red[sub][ex] = acc;
     __syncthreads();
-    for (int s = 16; s > 0; s >>= 1) {
+    for (int s = SUB / 2; s > 0; s >>= 1) {
       if (sub < s) s_red[sub][ex] = is_max ? fmax(s_red[sub][ex], s_red[sub + s][ex]) : s_red[sub][ex] + s_red[sub + s][ex];
       __syncthreads();
     }
@@ -1278,6 +1324,7 @@ __global__ __launch_bounds__(1024) void k_reduce_final(const double* __restrict_
     }
   } else {
     // last workgroup: cost of the linearisation point = fixed-order sum of the Jacobian-pass block partials
+    static_assert(SUB * (EX + 1) >= 1024, "flat view");
     double* flat = &s_red[0][0];
     double acc = 0.0; int f = 0;
     for (int b = tid; b < n_cost_blocks; b += 1024) { acc += block_cost[b]; f |= block_fail[b]; }
@@ -1656,10 +1703,8 @@ __global__ __launch_bounds__(256) void k_finalize_step(const double* __restrict_
   }
   if (host_scal) {
     __syncthreads();
-    if (tid < kNumScal) host_scal[tid] = scal[tid];
-    __threadfence_system();
-    __syncthreads();
-    if (tid == 0) { *reinterpret_cast<volatile unsigned long long*>(host_seq) = seq; __threadfence_system(); }
+    publish_scal(scal, host_scal, tid, blockDim.x);
+    publish_seq(host_seq, seq, tid);
   }
 }
 
@@ -1672,10 +1717,8 @@ __global__ void k_publish(double* __restrict__ scal, double* host_scal, unsigned
     if (tid == 0) xchg_unpack(xchg, scal, world);
     __syncthreads();
   }
-  if (tid < kNumScal) host_scal[tid] = scal[tid];
-  __threadfence_system();
-  __syncthreads();
-  if (tid == 0) { *reinterpret_cast<volatile unsigned long long*>(host_seq) = seq; __threadfence_system(); }
+  publish_scal(scal, host_scal, tid, blockDim.x);
+  publish_seq(host_seq, seq, tid);
 }
 
 }  // namespace pba
