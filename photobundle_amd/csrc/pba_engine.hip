@@ -79,6 +79,7 @@ struct pba_engine {
   LmState* h_lm_dev = nullptr;
   pba_iteration_summary* h_log = nullptr;      // host-mapped iteration log
   pba_iteration_summary* h_log_dev = nullptr;
+  pba_iteration_summary* d_log = nullptr;      // device iteration log of the asynchronous driver (flushed at the end)
   static constexpr int kMaxLog = 1024;
   bool async_on = false;
   int async_cur = 0;                // parity assumed at enqueue time
@@ -149,10 +150,6 @@ void launch_sample(pba_engine* e, const SampleParams& sp) {
 bool fused_capable(const pba_engine* e) { return e->cfg.radius <= 3 && e->fuse; }
 int sample_waves_for_radius(int R) { return (R <= 2) ? 4 : (R == 3 ? 2 : 1); }
 
-size_t schur_smem_bytes() {
-  return sizeof(double) * (kTile * kObsStride + kTile) + kTile * kMaxFrames;
-}
-
 template <int NF>
 void launch_solve_wave(pba_engine* e, const SolveParams& so) {
   hipLaunchKernelGGL((k_solve_wave<NF>), dim3(1), dim3(256), 0, e->stream, so);
@@ -176,7 +173,7 @@ void launch_solve(pba_engine* e, const SolveParams& so, int n) {
 }
 
 void launch_schur(pba_engine* e, const SchurParams& sp) {
-  hipLaunchKernelGGL(k_schur, dim3(e->schur_grid), dim3(kTile), schur_smem_bytes(), e->stream, sp);
+  hipLaunchKernelGGL(k_schur, dim3(e->schur_grid), dim3(kTile), 0, e->stream, sp);
 }
 
 SampleParams make_sample_params(pba_engine* e, int which_point) {
@@ -310,7 +307,11 @@ int pba_create(const pba_config* cfg, pba_engine** out) {
   if (hipHostGetDevicePointer(reinterpret_cast<void**>(&e->h_lm_dev), e->h_lm, 0) != hipSuccess) return bail(PBA_ERR_HIP);
   if (hipHostMalloc(reinterpret_cast<void**>(&e->h_log), sizeof(pba_iteration_summary) * pba_engine::kMaxLog, hipHostMallocMapped) != hipSuccess) return bail(PBA_ERR_HIP);
   if (hipHostGetDevicePointer(reinterpret_cast<void**>(&e->h_log_dev), e->h_log, 0) != hipSuccess) return bail(PBA_ERR_HIP);
-  if (const char* sv = getenv("PBA_SCHUR_TIMING")) e->dbg_left = atoi(sv);
+  if ((rc = dev_alloc(e, &e->d_log, (size_t)pba_engine::kMaxLog))) return bail(rc);
+  if (const char* sv = getenv("PBA_SCHUR_TIMING")) {
+    if (PBA_PHASE_TIMING) e->dbg_left = atoi(sv);
+    else std::fprintf(stderr, "PBA_SCHUR_TIMING ignored: libpba_hip.so was built without the phase stamps (make TIMING=1)\n");
+  }
   if ((rc = dev_alloc(e, &e->d_ticket, (size_t)1))) return bail(rc);
   if (hipMemsetAsync(e->d_ticket, 0, sizeof(unsigned int), e->stream) != hipSuccess) return bail(PBA_ERR_HIP);
   for (int k = 0; k < 6; ++k)
@@ -336,6 +337,7 @@ void pba_destroy(pba_engine* e) {
   if (e->h_lm) (void)hipHostFree(e->h_lm);
   if (e->h_log) (void)hipHostFree(e->h_log);
   dev_free(&e->d_lm);
+  dev_free(&e->d_log);
   for (int k = 0; k < 6; ++k) if (e->ev[k]) (void)hipEventDestroy(e->ev[k]);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
@@ -706,7 +708,9 @@ int pba_internal_step(pba_engine* e, double radius, int32_t init_scale, const pb
     volatile unsigned long long* h_seq = reinterpret_cast<volatile unsigned long long*>(e->h_scal + kNumScal);
     unsigned long spins = 0;
     while (*h_seq != seq) {
-      if ((++spins & 0x3fff) == 0) {
+      // hipStreamQuery is not free for the device (it showed up as a ~6 us bubble in front of the next kernel), so it only
+    // serves as a watchdog here: roughly every 50 ms of spinning
+    if ((++spins & 0x3ffffff) == 0) {
         const hipError_t q = hipStreamQuery(e->stream);
         if (q != hipSuccess && q != hipErrorNotReady) return fail(e, PBA_ERR_HIP, "stream error while waiting: %s", hipGetErrorString(q));
         if (q == hipSuccess && *h_seq != seq) return fail(e, PBA_ERR_HIP, "step finished without publishing its scalars");
@@ -825,8 +829,9 @@ int pba_internal_async_begin(pba_engine* e, const pba_solver_options* o) {
   return PBA_OK;
 }
 
-// kind 0: first linearisation; 1: full iteration; 2: gradient norms of the final point.  Returns the sequence number
-// the device publishes when the enqueued work completes (0 for kind 0, which publishes nothing).
+// kind 0: first linearisation; 1: full iteration; 2: gradient norms of the final point; 3: flush (log + state to the
+// host).  Returns the sequence number that marks the enqueued work as complete (0 for kind 0).  Single rank: a kind-1
+// sequence number is published by the NEXT kind-1 / kind-3 enqueue, so callers end every solve with a flush.
 int pba_internal_async_enqueue(pba_engine* e, int kind, int init_scale, const pba_solver_options* o, unsigned long long* seq_out) {
   const int cur = e->async_cur, cand = 1 - cur;
   const int n = 6 * e->n_free;
@@ -840,7 +845,7 @@ int pba_internal_async_enqueue(pba_engine* e, int kind, int init_scale, const pb
     sp.sp = e->d_sp; sp.ptrec = e->d_ptrec; sp.delta_c = e->d_delta_c; sp.block_bs = e->d_bs_out; sp.ticket = e->d_ticket;
     sp.scal = e->d_scal; sp.n_tiles = e->n_tiles; sp.skip_backsub = skip ? 1 : 0;
     sp.block_cost_alt = e->d_block_cost[skip ? cand : cur]; sp.block_fail_alt = e->d_block_fail[skip ? cand : cur];
-    sp.host_state = e->h_lm_dev; sp.log = e->h_log_dev; sp.max_log = pba_engine::kMaxLog;
+    sp.host_state = e->h_lm_dev; sp.log = e->d_log; sp.max_log = pba_engine::kMaxLog;
     return sp;
   };
   if (kind == 0) {
@@ -853,11 +858,24 @@ int pba_internal_async_enqueue(pba_engine* e, int kind, int init_scale, const pb
     HIP_TRY(e, hipGetLastError());
     return PBA_OK;
   }
+  if (kind == 3) {
+    // end of the solve: iteration log, final state and sequence number to the host mirror
+    const unsigned long long seq = ++e->seq;
+    hipLaunchKernelGGL(k_flush, dim3(1), dim3(256), 0, e->stream, (const LmState*)e->d_lm, e->h_lm_dev, (const double*)e->d_scal,
+                       e->h_scal_dev, (const pba_iteration_summary*)e->d_log, e->h_log_dev, (int)pba_engine::kMaxLog, h_seq_dev, seq);
+    HIP_TRY(e, hipGetLastError());
+    *seq_out = seq;
+    return PBA_OK;
+  }
   SchurParams sc{};
   sc.xyz = e->d_xyz[cur]; sc.geom = e->d_geom[cur]; sc.rec = e->d_rec[cur]; sc.obs_point = e->d_obs_point;
   sc.obs_slot = e->d_obs_slot; sc.tile_info = e->d_tile_info; sc.obs_l0 = e->d_obs_l0; sc.obs_cnt = e->d_obs_cnt; sc.sp = e->d_sp;
   sc.ptrec = e->d_ptrec; sc.partial = e->d_partial; sc.rec_stride = e->rec_stride; sc.n_tiles = e->n_tiles; sc.n_frames = e->n_frames;
   sc.n_free = e->n_free; sc.n_pairs = e->n_pairs; sc.part_stride = e->part_stride; sc.init_scale = init_scale;
+  if (!multi) {
+    // the fused sampling kernel of the previous enqueue decided on the device without publishing; this kernel does
+    sc.pub_state = e->h_lm_dev; sc.pub_scal = e->d_scal; sc.pub_host_scal = e->h_scal_dev; sc.pub_host_seq = h_seq_dev; sc.pub_seq = e->seq;
+  }
   sc.jacobi = o->jacobi_scaling; sc.fx = e->cfg.fx; sc.fy = e->cfg.fy; sc.radius = 1.0; sc.inv_radius = 1.0;
   sc.min_diag = o->min_lm_diagonal; sc.max_diag = o->max_lm_diagonal; sc.dbg = nullptr;
   sc.lm = e->d_lm; sc.enq_cur = cur; sc.final_pass = (kind == 2) ? 1 : 0; sc.xyz_alt = e->d_xyz[cand]; sc.geom_alt = e->d_geom[cand]; sc.rec_alt = e->d_rec[cand];
@@ -883,7 +901,8 @@ int pba_internal_async_enqueue(pba_engine* e, int kind, int init_scale, const pb
   if (kind == 1) {
     SampleParams sp = sample_params(false);
     sp.lm = e->d_lm; sp.enq_cur = cur; sp.decide = multi ? 0 : 1;
-    sp.host_scal = multi ? nullptr : e->h_scal_dev; sp.host_seq = h_seq_dev; sp.seq = seq;
+    sp.host_scal = nullptr;     // published by the next k_schur (or k_flush): see SchurParams::pub_*
+    sp.host_seq = h_seq_dev; sp.seq = seq;
     launch_sample<true, true>(e, sp);
     e->jac_passes++;
     HIP_TRY(e, hipGetLastError());
@@ -894,7 +913,7 @@ int pba_internal_async_enqueue(pba_engine* e, int kind, int init_scale, const pb
   }
   if (multi || kind == 2) {
     DecideParams dp{};
-    dp.lm = e->d_lm; dp.host_state = e->h_lm_dev; dp.scal = e->d_scal; dp.host_scal = e->h_scal_dev; dp.log = e->h_log_dev;
+    dp.lm = e->d_lm; dp.host_state = e->h_lm_dev; dp.scal = e->d_scal; dp.host_scal = e->h_scal_dev; dp.log = e->d_log;
     dp.xchg = multi ? e->d_xchg : nullptr; dp.world = e->comm.world;
     dp.max_log = pba_engine::kMaxLog; dp.grad_only = (kind == 2) ? 1 : 0; dp.host_seq = h_seq_dev; dp.seq = seq;
     hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, e->stream, dp);
@@ -908,7 +927,9 @@ int pba_internal_async_wait(pba_engine* e, unsigned long long seq) {
   volatile unsigned long long* h_seq = reinterpret_cast<volatile unsigned long long*>(e->h_scal + kNumScal);
   unsigned long spins = 0;
   while (*h_seq < seq) {
-    if ((++spins & 0x3fff) == 0) {
+    // hipStreamQuery is not free for the device (it showed up as a ~6 us bubble in front of the next kernel), so it only
+    // serves as a watchdog here: roughly every 50 ms of spinning
+    if ((++spins & 0x3ffffff) == 0) {
       const hipError_t q = hipStreamQuery(e->stream);
       if (q != hipSuccess && q != hipErrorNotReady) return fail(e, PBA_ERR_HIP, "stream error while waiting: %s", hipGetErrorString(q));
       if (q == hipSuccess && *h_seq < seq) {

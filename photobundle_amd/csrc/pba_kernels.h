@@ -12,6 +12,12 @@
 #include <cfloat>
 #include <climits>
 
+// Per-phase cycle stamps inside the kernels (PBA_SCHUR_TIMING=1|2 at run time) cost registers and a device printf, so
+// they are compiled in only on request: make TIMING=1.
+#ifndef PBA_PHASE_TIMING
+#define PBA_PHASE_TIMING 0
+#endif
+
 namespace pba {
 
 // Agent-scope relaxed 8-byte store / load (gfx950: write-through `sc1` store, L1-bypassing `sc1` load).  Used for the
@@ -519,6 +525,7 @@ template <int R, bool JAC, int WAVES, bool FUSED, bool UNITW>
 __global__ __launch_bounds__(WAVES * 64, (R <= 2 ? (JAC ? 3 : 2) : 1)) void k_sample(SampleParams p_in) {
   static_assert(!FUSED || (WAVES * 64) % 128 == 0, "fused tiles are 128 observations");
   SampleParams p = p_in;
+  if (!PBA_PHASE_TIMING) p.dbg = nullptr;
   if (FUSED && p.lm) {
     if (p.lm->done) return;
     if (p.lm->cur != p.enq_cur) {     // the host's parity guess was off by an odd number of accepted steps
@@ -810,12 +817,14 @@ __global__ __launch_bounds__(WAVES * 64, (R <= 2 ? (JAC ? 3 : 2) : 1)) void k_sa
     cost_obs = 0.5 * rho0;
     if (!isfinite(cc)) atomicOr(&s_fail, 1);
     if (JAC) {
-      p.rec[0 * p.rec_stride + obs] = rho1 * m11;
-      p.rec[1 * p.rec_stride + obs] = rho1 * m12;
-      p.rec[2 * p.rec_stride + obs] = rho1 * m22;
-      p.rec[3 * p.rec_stride + obs] = rho1 * b1;
-      p.rec[4 * p.rec_stride + obs] = rho1 * b2;
-      p.rec[5 * p.rec_stride + obs] = cost_obs;
+      // streamed: the records are next read by another kernel (and, the L2 being per XCD, from HBM anyway); keeping
+      // them out of the L2 as dirty lines also shortens the write-back at the end of the kernel
+      __builtin_nontemporal_store(rho1 * m11, p.rec + 0 * p.rec_stride + obs);
+      __builtin_nontemporal_store(rho1 * m12, p.rec + 1 * p.rec_stride + obs);
+      __builtin_nontemporal_store(rho1 * m22, p.rec + 2 * p.rec_stride + obs);
+      __builtin_nontemporal_store(rho1 * b1, p.rec + 3 * p.rec_stride + obs);
+      __builtin_nontemporal_store(rho1 * b2, p.rec + 4 * p.rec_stride + obs);
+      __builtin_nontemporal_store(cost_obs, p.rec + 5 * p.rec_stride + obs);
     }
   }
   // deterministic block reductions: butterfly inside each wave, then the waves in order
@@ -932,6 +941,8 @@ __global__ __launch_bounds__(WAVES * 64, (R <= 2 ? (JAC ? 3 : 2) : 1)) void k_sa
 constexpr int kTile = 128;              // observations (= threads) per tile
 constexpr int kObsStride = 37;          // doubles per observation in LDS (36 + 1 pad)
 
+constexpr size_t kSchurSmemBytes = sizeof(double) * (kTile * kObsStride + kTile) + kTile * kMaxFrames;
+
 struct SchurParams {
   const double* xyz;
   const CamGeom* geom;
@@ -959,6 +970,11 @@ struct SchurParams {
   int32_t enq_cur;
   int32_t final_pass;          // run although the solve has terminated (gradient norms of the final point)
   const double* xyz_alt; const CamGeom* geom_alt; const double* rec_alt;
+  // deferred publication of the PREVIOUS step's outcome (null: nothing to publish): host-mapped stores complete over
+  // PCIe, and a kernel does not retire before its stores have, so they are issued at the start of this long kernel
+  // rather than at the end of the sampling kernel that produced the outcome (measured: 6 us per iteration)
+  LmState* pub_state; const double* pub_scal; double* pub_host_scal;
+  unsigned long long* pub_host_seq; unsigned long long pub_seq;
 };
 
 __device__ __forceinline__ int sym6(int i, int j) {  // packed upper triangle of a symmetric 6x6 (21 entries)
@@ -972,13 +988,16 @@ __device__ __forceinline__ int sym6(int i, int j) {  // packed upper triangle of
 //   partial only: +0 gmax_pts, +1 gnorm2_pts, +2 schur_fail
 __global__ __launch_bounds__(kTile, 2) void k_schur(SchurParams p_in) {
   SchurParams p = p_in;
+  if (!PBA_PHASE_TIMING) p.dbg = nullptr;
+  if (p.pub_host_seq && blockIdx.x == 0)
+    lm_publish(p.lm, p.pub_state, p.pub_scal, p.pub_host_scal, p.pub_host_seq, p.pub_seq, threadIdx.x, kTile);
   if (p.lm) {
     if (p.lm->done && !p.final_pass) return;
     if (p.lm->cur != p.enq_cur) { p.xyz = p.xyz_alt; p.geom = p.geom_alt; p.rec = p.rec_alt; }
     p.radius = p.lm->radius;
     p.inv_radius = 1.0 / p.radius;
   }
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ __attribute__((aligned(16))) char smem[kSchurSmemBytes];
   double* s_obs = reinterpret_cast<double*>(smem);                       // [kTile][kObsStride]
   // V_l (6) g_l (3) per lane live INSIDE the s_obs region (after the staged camera table, before W | Y are
   // written): 40 KB per workgroup => 4 workgroups per CU instead of 3
@@ -1475,6 +1494,7 @@ __device__ __forceinline__ void solve_epilogue(const SolveParams& p, int n, cons
 template <int NF>
 __global__ __launch_bounds__(256) void k_solve_wave(SolveParams p_in) {
   SolveParams p = p_in;
+  if (!PBA_PHASE_TIMING) p.dbg = 0;
   if (!solve_resolve(p)) return;
   constexpr int N = 6 * NF;
   constexpr int LD = N + 1;
@@ -1483,9 +1503,9 @@ __global__ __launch_bounds__(256) void k_solve_wave(SolveParams p_in) {
   __shared__ double y_s[N], sc[N], D2[N], gcs[N], gc[N];
   __shared__ int s_ok;
   const int tid = threadIdx.x;
-  unsigned long long t0 = __builtin_amdgcn_s_memtime(), t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+  unsigned long long t0 = (PBA_PHASE_TIMING ? __builtin_amdgcn_s_memtime() : 0ull), t1 = 0, t2 = 0, t3 = 0, t4 = 0;
   solve_prologue<256>(p, N, LD, S, y_s, sc, D2, gcs, gc, tid);
-  t1 = __builtin_amdgcn_s_memtime();
+  t1 = (PBA_PHASE_TIMING ? __builtin_amdgcn_s_memtime() : 0ull);
   if (tid < 64) {
     const int lane = tid;
     const int r = lane < N ? lane : N - 1;
@@ -1522,7 +1542,7 @@ __global__ __launch_bounds__(256) void k_solve_wave(SolveParams p_in) {
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    t2 = __builtin_amdgcn_s_memtime();
+    t2 = (PBA_PHASE_TIMING ? __builtin_amdgcn_s_memtime() : 0ull);
     // L to LDS (row-major) for the transposed access of the backward sweep
 #pragma unroll
     for (int c = 0; c < N; ++c) if (lane < N && c <= lane) S[r * LD + c] = a[c];
@@ -1546,12 +1566,12 @@ __global__ __launch_bounds__(256) void k_solve_wave(SolveParams p_in) {
     }
     if (lane < N) y_s[lane] = y;
     if (lane == 0) s_ok = ok ? 1 : 0;
-    t3 = __builtin_amdgcn_s_memtime();
+    t3 = (PBA_PHASE_TIMING ? __builtin_amdgcn_s_memtime() : 0ull);
   }
   __syncthreads();
   solve_epilogue<256>(p, N, y_s, sc, D2, gcs, gc, s_ok != 0, tid);
-  t4 = __builtin_amdgcn_s_memtime();
-  if (p.dbg && tid == 0) printf("k_solve_wave cycles: prologue %llu cholesky %llu substitution %llu epilogue %llu\n", t1 - t0, t2 - t1, t3 - t2, t4 - t3);
+  t4 = (PBA_PHASE_TIMING ? __builtin_amdgcn_s_memtime() : 0ull);
+  if (PBA_PHASE_TIMING && p.dbg && tid == 0) printf("k_solve_wave cycles: prologue %llu cholesky %llu substitution %llu epilogue %llu\n", t1 - t0, t2 - t1, t3 - t2, t4 - t3);
 }
 
 // Generic path (any n <= 96): matrix in LDS, 256 threads, 2-D trailing update, one barrier pair per column.
@@ -1706,6 +1726,17 @@ __global__ __launch_bounds__(256) void k_finalize_step(const double* __restrict_
     publish_scal(scal, host_scal, tid, blockDim.x);
     publish_seq(host_seq, seq, tid);
   }
+}
+
+// End of an asynchronous solve: device iteration log -> host-mapped log, then state, scalars and sequence number.
+__global__ void k_flush(const LmState* lm, LmState* host_state, const double* scal, double* host_scal,
+                        const pba_iteration_summary* log, pba_iteration_summary* host_log, int max_log,
+                        unsigned long long* host_seq, unsigned long long seq) {
+  const int n_words = (lm->n_log < max_log ? lm->n_log : max_log) * (int)(sizeof(pba_iteration_summary) / 4);
+  static_assert(sizeof(pba_iteration_summary) % 4 == 0, "word copy");
+  const unsigned* src = reinterpret_cast<const unsigned*>(log);
+  for (int k = threadIdx.x; k < n_words; k += blockDim.x) store_system_u32(reinterpret_cast<unsigned*>(host_log) + k, src[k]);
+  lm_publish(lm, host_state, scal, host_scal, host_seq, seq, threadIdx.x, blockDim.x);
 }
 
 // Publishes the (already reduced) scalar block to host-mapped memory: used after the multi-rank all-reduces and

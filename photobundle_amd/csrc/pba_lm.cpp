@@ -44,12 +44,16 @@ static int solve_async(pba_engine* e, const pba_solver_options* o, pba_solver_su
     ++enq;
     if (enq > kAhead) { if ((rc = pba_internal_async_wait(e, seqs[(enq - kAhead) % (kAhead + 1)]))) return rc; }
   }
-  if (last_seq && (rc = pba_internal_async_wait(e, last_seq))) return rc;
+  // flush: the last step's outcome and the iteration log reach the host mirror
+  if ((rc = pba_internal_async_enqueue(e, 3, 0, o, &seq))) return rc;
+  if ((rc = pba_internal_async_wait(e, seq))) return rc;
   if (o->max_num_iterations <= 0 || (st->pending_grad >= 0 && (st->done == pba::kLmRunning || st->done == pba::kLmMaxIterations))) {
     // gradient norms of the final point (iteration limit reached right after an accepted step, or max_it == 0)
     if ((rc = pba_internal_async_enqueue(e, 2, o->max_num_iterations <= 0 ? 1 : 0, o, &seq))) return rc;
+    if ((rc = pba_internal_async_enqueue(e, 3, 0, o, &seq))) return rc;
     if ((rc = pba_internal_async_wait(e, seq))) return rc;
   }
+  (void)last_seq;
   if ((rc = pba_internal_async_end(e))) return rc;
   LmState fin;
   std::memcpy(&fin, const_cast<const LmState*>(static_cast<const LmState*>(pba_internal_async_state(e))), sizeof(fin));
