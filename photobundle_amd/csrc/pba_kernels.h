@@ -1490,6 +1490,7 @@ __device__ __forceinline__ void solve_epilogue(const SolveParams& p, int n, cons
 // Fast path, n = 6 NF <= 60: wave 0 keeps row r of the matrix in lane r's registers (compile-time indexed).  Per
 // column ONE LDS round trip broadcasts the unscaled column v = A[:, j]; with t_r = v_r / v_j the trailing update is
 // a[c] -= t_r * v_c and the factor entry is L_rj = v_r * rsqrt(v_j): no second broadcast, no barriers (one wave).
+// The right-hand side is carried as an extra column, which makes the forward substitution part of the factorisation.
 // The other three waves only help with the prologue / epilogue.
 template <int NF>
 __global__ __launch_bounds__(256) void k_solve_wave(SolveParams p_in) {
@@ -1518,6 +1519,7 @@ __global__ __launch_bounds__(256) void k_solve_wave(SolveParams p_in) {
     // look-ahead: column j+1 is finished and broadcast (double-buffered) BEFORE the rest of column j's trailing
     // update, so the LDS round trip and the rsqrt chain of the next pivot overlap the FMAs of this one
     s_col[lane] = a[0];
+    if (lane == 0) s_col[63] = y;     // the right-hand side rides along as one more column (slot 63: N <= 60)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1532,9 +1534,12 @@ __global__ __launch_bounds__(256) void k_solve_wave(SolveParams p_in) {
       const double t = a[j] * (inv * inv);
       if (lane == j) d_own = inv;
       a[j] = a[j] * inv;                 // L_rj (lane j: sqrt(piv))
+      // forward substitution folded in: z_j = y_j / L_jj, y_r -= (L_rj / L_jj) y_j for the rows below
+      y = (lane > j) ? fma(-t, col[63], y) : ((lane == j) ? y * inv : y);
       if (j + 1 < N) {
         a[j + 1] = fma(-t, col[j + 1], a[j + 1]);
         col_next[lane] = a[j + 1];
+        if (lane == j + 1) col_next[63] = y;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       }
 #pragma unroll
@@ -1546,13 +1551,6 @@ __global__ __launch_bounds__(256) void k_solve_wave(SolveParams p_in) {
     // L to LDS (row-major) for the transposed access of the backward sweep
 #pragma unroll
     for (int c = 0; c < N; ++c) if (lane < N && c <= lane) S[r * LD + c] = a[c];
-    // forward substitution L z = y
-#pragma unroll
-    for (int j = 0; j < N; ++j) {
-      if (lane == j) y *= d_own;
-      const double zj = readlane_f64(y, j);
-      if (lane > j) y = fma(-a[j], zj, y);
-    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
