@@ -1,0 +1,15 @@
+#!/bin/bash
+# Runs ON THE GPU BOX (via gpurun) from the repo root: kernel stats, two PMC passes and the bench line of configs[1].
+# Output: gpurun_out/prof_<tag>/ ; copy the summaries into profiles/rNN/ afterwards (tools/collect_profiles.py).
+set -u
+TAG=${1:-final}
+OUT=$PWD/gpurun_out/prof_$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+BENCH="python $OLDPWD/bench.py --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o s -- $BENCH > "$OUT/bench_under_rocprof.json" 2> /dev/null
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o f -- $BENCH > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o w -- $BENCH > /dev/null 2>&1
+cd "$OLDPWD"
+python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
+tail -1 "$OUT/bench.json"
