@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--points", type=int, default=50000, help="points per GPU")
     ap.add_argument("--radius", type=int, default=2)
     ap.add_argument("--huber", type=float, default=0.0)
+    ap.add_argument("--visibility", choices=("dense", "causal"), default="dense")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-points", type=int, default=50000, help="points of the bounded CPU-baseline sample")
     ap.add_argument("--cpu-steps", type=int, default=20)
@@ -72,8 +73,9 @@ def main():
 
     # ---- synthetic window: identical frames/cameras on every rank, rank-specific points ----------------------
     t0 = time.time()
+    default_shape = (args.frames, args.points, args.radius, args.huber, args.visibility) == (8, 50000, 2, 0.0, "dense")
     prob = synthetic.make_window(n_frames=args.frames, n_points=args.points, radius=args.radius, huber=args.huber,
-                                 visibility="dense", point_seed_offset=rank)
+                                 visibility=args.visibility, point_seed_offset=rank)
     t_gen = time.time() - t0
     rows, cols = prob.images.shape[1:]
     P = prob.patch_len
@@ -88,6 +90,9 @@ def main():
             uid.copy_(torch.frombuffer(bytearray(Engine.comm_unique_id()), dtype=torch.uint8))
         dist.broadcast(uid, 0)
         eng.comm_init_rccl(bytes(uid.cpu().numpy().tobytes()), rank, world)
+    elif os.environ.get("PBA_FORCE_MULTI") == "1":
+        # diagnostics: the multi-rank code path (RCCL all-reduces on the engine's stream, k_decide) at world = 1
+        eng.comm_init_rccl(Engine.comm_unique_id(), 0, 1)
 
     def reset_state():
         eng.set_problem(prob.xyz, prob.desc, prob.obs_point, prob.obs_slot, prob.weights)
@@ -175,8 +180,9 @@ def main():
         "value": value, "unit": "LM iters/s (50k-point windows; x N under weak scaling)",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(1, iters_done),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "configs[1]: %d-frame window, %d points/GPU, %dx%d patch, single level, dense visibility"
-                               % (prob.n_frames, prob.n_points, 2 * prob.radius + 1, 2 * prob.radius + 1),
+        "config": {"workload": "%s%d-frame window, %d points/GPU, %dx%d patch, single level, %s visibility"
+                               % ("configs[1]: " if default_shape else "", prob.n_frames, prob.n_points, 2 * prob.radius + 1,
+                                  2 * prob.radius + 1, args.visibility),
                    "image": "%dx%d u8" % (cols, rows), "observations": int(n_obs_global), "huber": prob.huber,
                    "parallelism": "points sharded x%d, cameras+frames replicated, RCCL all-reduce of the reduced camera system" % world},
         "iters_per_sec": iters_per_sec, "residuals_per_sec": residuals_per_sec,

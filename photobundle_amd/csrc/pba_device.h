@@ -85,6 +85,7 @@ struct LmState {
   double function_tolerance, gradient_tolerance, parameter_tolerance;
   double max_radius, min_radius, min_relative_decrease;
   int32_t max_num_iterations, max_invalid;
+  unsigned long long done_seq;   // sequence number of the step that terminated the solve (0 while running)
 };
 
 }  // namespace pba

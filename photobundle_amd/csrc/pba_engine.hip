@@ -804,6 +804,7 @@ int pba_reset_counters(pba_engine* e) {
 extern "C" {
 int pba_internal_world(const pba_engine* e) { return e->comm.world; }
 int pba_internal_rank(const pba_engine* e) { return e->comm.rank; }
+int pba_internal_is_multi(const pba_engine* e) { return e->comm.multi() ? 1 : 0; }
 int64_t pba_internal_local_blocks(const pba_engine* e) { return e->n_obs; }
 int pba_internal_patch_len(const pba_engine* e) { return (2 * e->cfg.radius + 1) * (2 * e->cfg.radius + 1); }
 // ---- asynchronous driver ----------------------------------------------------------------------------------------

@@ -8,6 +8,7 @@ int pba_internal_step(pba_engine* e, double radius, int32_t init_scale, const pb
                       int grad_only);
 int pba_internal_world(const pba_engine* e);
 int pba_internal_rank(const pba_engine* e);
+int pba_internal_is_multi(const pba_engine* e);   /* collectives are enqueued with every step */
 int64_t pba_internal_local_blocks(const pba_engine* e);
 int pba_internal_patch_len(const pba_engine* e);
 int pba_internal_allreduce_host(pba_engine* e, double* v, int n, int op);

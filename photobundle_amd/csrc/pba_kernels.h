@@ -415,6 +415,7 @@ __global__ void k_decide(DecideParams p) {
   if (threadIdx.x == 0) {
     if (p.xchg) xchg_unpack(p.xchg, p.scal, p.world);
     lm_decide(p.lm, p.scal, p.log, p.max_log, p.grad_only);
+    if (p.lm->done && p.lm->done_seq == 0) p.lm->done_seq = p.seq;
   }
   __syncthreads();
   lm_publish(p.lm, p.host_state, p.scal, p.host_scal, p.host_seq, p.seq, threadIdx.x, blockDim.x);
@@ -914,6 +915,7 @@ __global__ __launch_bounds__(WAVES * 64, (R <= 2 ? (JAC ? 3 : 2) : 1)) void k_sa
         p.scal[kCandCost] = s_r4[3 * WAVES]; p.scal[kEvalFailCand] = (double)s_f[0];
         *p.ticket = 0;
         if (p.lm && p.decide) lm_decide(p.lm, p.scal, p.log, p.max_log, 0);
+        if (p.lm && p.decide && p.lm->done && p.lm->done_seq == 0) p.lm->done_seq = p.seq;
         t_fin3 = p.dbg ? __builtin_amdgcn_s_memrealtime() : 0;
       }
       if (p.host_scal) {

@@ -37,7 +37,11 @@ static int solve_async(pba_engine* e, const pba_solver_options* o, pba_solver_su
   if ((rc = pba_internal_async_enqueue(e, 0, 0, o, &seq))) return rc;
   int enq = 0;
   unsigned long long last_seq = 0;
-  while (enq < o->max_num_iterations && !st->done) {
+  // Multi-rank: every enqueued step carries collectives, so all ranks must enqueue the SAME number of steps although
+  // each sees the termination flag at a different moment: they all stop kAhead steps after the terminating one.
+  const bool multi = pba_internal_is_multi(e) != 0;
+  while (enq < o->max_num_iterations) {
+    if (st->done && (!multi || last_seq >= st->done_seq + kAhead)) break;
     if ((rc = pba_internal_async_enqueue(e, 1, enq == 0 ? 1 : 0, o, &seq))) return rc;
     seqs[enq % (kAhead + 1)] = seq;
     last_seq = seq;

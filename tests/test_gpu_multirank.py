@@ -99,9 +99,11 @@ def test_rccl_collectives_on_the_device_stream(tmp_path):
         "import test_gpu_multirank as t\n"
         "p = t._make()\n"
         "e = make_engine(p); e.comm_init_rccl(Engine.comm_unique_id(), 0, 1)\n"
-        "res = e.solve(default_solver_options(max_num_iterations=8)); e.close()\n"
+        "res = e.solve(default_solver_options(max_num_iterations=8))\n"
+        "e.load(p); conv = e.solve(default_solver_options(max_num_iterations=200, function_tolerance=1e-4)); e.close()\n"
         "np.savez(%r + '/out_' + sys.argv[1] + '.npz', cams=res['cams'], xyz=res['xyz'], costs=np.array([i['cost'] for i in res['iterations']]),"
-        " g=np.array([i['gradient_max_norm'] for i in res['iterations']]))\n"
+        " g=np.array([i['gradient_max_norm'] for i in res['iterations']]), conv_costs=np.array([i['cost'] for i in conv['iterations']]),"
+        " conv_type=conv['termination_type'])\n"
     ) % (ROOT, os.path.join(ROOT, "tests"), str(tmp_path))
     outs = {}
     for tag, env in [("plain", {}), ("multi_async", {"PBA_FORCE_MULTI": "1"}), ("multi_sync", {"PBA_FORCE_MULTI": "1", "PBA_ASYNC": "0"})]:
@@ -116,3 +118,8 @@ def test_rccl_collectives_on_the_device_stream(tmp_path):
     assert np.abs(outs["multi_sync"]["cams"] - outs["plain"]["cams"]).max() <= 1e-9
     for tag in ("multi_async", "multi_sync"):
         assert np.allclose(outs[tag]["g"], outs["plain"]["g"], rtol=1e-9)
+    # tolerance-terminated solve: the multi-rank driver stops a fixed number of steps after the terminating one (every
+    # rank must enqueue the same number of collectives), with the same trace as the single-rank driver
+    assert int(outs["plain"]["conv_type"]) == 0 and len(outs["plain"]["conv_costs"]) < 200
+    assert np.array_equal(outs["multi_async"]["conv_costs"], outs["plain"]["conv_costs"])
+    assert int(outs["multi_async"]["conv_type"]) == 0
