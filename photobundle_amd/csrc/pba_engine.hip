@@ -200,15 +200,21 @@ SampleParams make_sample_params(pba_engine* e, int which_point) {
 }
 
 // ONE sum all-reduce for the step scalars of all ranks (sum group + rank-slotted max group, see k_xchg_pack)
-int exchange_step_scalars(pba_engine* e) {
+int ensure_xchg(pba_engine* e) {
+  if (e->d_xchg) return PBA_OK;
+  return dev_alloc(e, &e->d_xchg, (size_t)kSumBCount + (size_t)kMaxCount * e->comm.world);
+}
+
+// packed == true: the fused sampling kernel's last workgroup already filled the exchange buffer
+int exchange_step_scalars(pba_engine* e, bool packed) {
   const int world = e->comm.world;
   const size_t n = (size_t)kSumBCount + (size_t)kMaxCount * world;
-  if (!e->d_xchg) {
-    int rc = dev_alloc(e, &e->d_xchg, n);
-    if (rc) return rc;
+  int rc = ensure_xchg(e);
+  if (rc) return rc;
+  if (!packed) {
+    hipLaunchKernelGGL(k_xchg_pack, dim3(1), dim3(64), 0, e->stream, e->d_scal, e->d_xchg, e->comm.rank, world);
+    HIP_TRY(e, hipGetLastError());
   }
-  hipLaunchKernelGGL(k_xchg_pack, dim3(1), dim3(64), 0, e->stream, e->d_scal, e->d_xchg, e->comm.rank, world);
-  HIP_TRY(e, hipGetLastError());
   if (e->comm.allreduce_device(e->d_xchg, n, 0, e->stream))
     return fail(e, PBA_ERR_COMM, "allreduce(step scalars) failed: %s", e->comm.err.c_str());
   return PBA_OK;
@@ -605,6 +611,7 @@ int pba_internal_step(pba_engine* e, double radius, int32_t init_scale, const pb
   launch_solve(e, so, n);
   const unsigned long long seq = ++e->seq;
   unsigned long long* h_seq_dev = reinterpret_cast<unsigned long long*>(e->h_scal_dev + kNumScal);
+  bool xchg_packed = false;
   if (!grad_only && fused_capable(e)) {
     // one kernel: back-substitution -> candidate pass (Jacobian pass when speculating) -> step finalisation
     SampleParams sp = make_sample_params(e, cand);
@@ -613,6 +620,11 @@ int pba_internal_step(pba_engine* e, double radius, int32_t init_scale, const pb
     sp.delta_c = e->d_delta_c; sp.block_bs = e->d_bs_out; sp.ticket = e->d_ticket; sp.scal = e->d_scal;
     sp.host_scal = multi ? nullptr : e->h_scal_dev; sp.host_seq = h_seq_dev; sp.seq = seq; sp.n_tiles = e->n_tiles;
     sp.dbg = (e->dbg_left > 0 && e->d_dbg) ? e->d_dbg + 8 * 1024 : nullptr;
+    if (multi) {
+      int rcx = ensure_xchg(e);
+      if (rcx) return rcx;
+      sp.xchg = e->d_xchg; sp.xchg_rank = e->comm.rank; sp.xchg_world = e->comm.world; xchg_packed = true;
+    }
     if (e->speculate) {
       ev_begin(e, 0);
       launch_sample<true, true>(e, sp);
@@ -695,7 +707,7 @@ int pba_internal_step(pba_engine* e, double radius, int32_t init_scale, const pb
   }
   HIP_TRY(e, hipGetLastError());
   if (multi) {
-    int rc2 = exchange_step_scalars(e);
+    int rc2 = exchange_step_scalars(e, xchg_packed);
     if (rc2) return rc2;
   }
   if (multi || grad_only) {
@@ -873,10 +885,9 @@ int pba_internal_async_enqueue(pba_engine* e, int kind, int init_scale, const pb
   sc.obs_slot = e->d_obs_slot; sc.tile_info = e->d_tile_info; sc.obs_l0 = e->d_obs_l0; sc.obs_cnt = e->d_obs_cnt; sc.sp = e->d_sp;
   sc.ptrec = e->d_ptrec; sc.partial = e->d_partial; sc.rec_stride = e->rec_stride; sc.n_tiles = e->n_tiles; sc.n_frames = e->n_frames;
   sc.n_free = e->n_free; sc.n_pairs = e->n_pairs; sc.part_stride = e->part_stride; sc.init_scale = init_scale;
-  if (!multi) {
-    // the fused sampling kernel of the previous enqueue decided on the device without publishing; this kernel does
-    sc.pub_state = e->h_lm_dev; sc.pub_scal = e->d_scal; sc.pub_host_scal = e->h_scal_dev; sc.pub_host_seq = h_seq_dev; sc.pub_seq = e->seq;
-  }
+  // the previous enqueue decided on the device (last workgroup of the fused sampling kernel, or k_decide after the
+  // multi-rank exchange) without publishing; this kernel does
+  sc.pub_state = e->h_lm_dev; sc.pub_scal = e->d_scal; sc.pub_host_scal = e->h_scal_dev; sc.pub_host_seq = h_seq_dev; sc.pub_seq = e->seq;
   sc.jacobi = o->jacobi_scaling; sc.fx = e->cfg.fx; sc.fy = e->cfg.fy; sc.radius = 1.0; sc.inv_radius = 1.0;
   sc.min_diag = o->min_lm_diagonal; sc.max_diag = o->max_lm_diagonal; sc.dbg = nullptr;
   sc.lm = e->d_lm; sc.enq_cur = cur; sc.final_pass = (kind == 2) ? 1 : 0; sc.xyz_alt = e->d_xyz[cand]; sc.geom_alt = e->d_geom[cand]; sc.rec_alt = e->d_rec[cand];
@@ -904,19 +915,25 @@ int pba_internal_async_enqueue(pba_engine* e, int kind, int init_scale, const pb
     sp.lm = e->d_lm; sp.enq_cur = cur; sp.decide = multi ? 0 : 1;
     sp.host_scal = nullptr;     // published by the next k_schur (or k_flush): see SchurParams::pub_*
     sp.host_seq = h_seq_dev; sp.seq = seq;
+    if (multi) {
+      int rcx = ensure_xchg(e);
+      if (rcx) return rcx;
+      sp.xchg = e->d_xchg; sp.xchg_rank = e->comm.rank; sp.xchg_world = e->comm.world;
+    }
     launch_sample<true, true>(e, sp);
     e->jac_passes++;
     HIP_TRY(e, hipGetLastError());
   }
   if (multi) {
-    int rc2 = exchange_step_scalars(e);
+    int rc2 = exchange_step_scalars(e, kind == 1);
     if (rc2) return rc2;
   }
   if (multi || kind == 2) {
     DecideParams dp{};
     dp.lm = e->d_lm; dp.host_state = e->h_lm_dev; dp.scal = e->d_scal; dp.host_scal = e->h_scal_dev; dp.log = e->d_log;
     dp.xchg = multi ? e->d_xchg : nullptr; dp.world = e->comm.world;
-    dp.max_log = pba_engine::kMaxLog; dp.grad_only = (kind == 2) ? 1 : 0; dp.host_seq = h_seq_dev; dp.seq = seq;
+    dp.max_log = pba_engine::kMaxLog; dp.grad_only = (kind == 2) ? 1 : 0; dp.seq = seq;
+    dp.host_seq = (kind == 1) ? nullptr : h_seq_dev;      // a full step is published by the next k_schur / k_flush
     hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, e->stream, dp);
   }
   HIP_TRY(e, hipGetLastError());

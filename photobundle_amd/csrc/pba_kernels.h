@@ -386,13 +386,15 @@ __device__ inline void lm_publish(const LmState* st, LmState* host_state, const 
 // ---- multi-rank exchange of the step scalars in ONE sum all-reduce -----------------------------------------------
 // xchg = [ sum group (kSumBCount) | world x max group (kMaxCount) ]: every rank writes its max-group values into its
 // own slot and zeros into the others, so the SUM all-reduce doubles as an all-gather; the max is taken afterwards.
-__global__ void k_xchg_pack(const double* __restrict__ scal, double* __restrict__ xchg, int rank, int world) {
-  const int i = threadIdx.x;
-  if (i < kSumBCount) xchg[i] = scal[kCandCost + i];
-  for (int k = i; k < kMaxCount * world; k += blockDim.x) {
+__device__ inline void xchg_pack(const double* scal, double* xchg, int rank, int world, int tid, int nthreads) {
+  for (int i = tid; i < kSumBCount; i += nthreads) xchg[i] = scal[kCandCost + i];
+  for (int k = tid; k < kMaxCount * world; k += nthreads) {
     const int r = k / kMaxCount, j = k - r * kMaxCount;
     xchg[kSumBCount + k] = (r == rank) ? scal[kGmaxPts + j] : 0.0;
   }
+}
+__global__ void k_xchg_pack(const double* __restrict__ scal, double* __restrict__ xchg, int rank, int world) {
+  xchg_pack(scal, xchg, rank, world, threadIdx.x, blockDim.x);
 }
 __device__ inline void xchg_unpack(const double* xchg, double* scal, int world) {   // one thread
   for (int i = 0; i < kSumBCount; ++i) scal[kCandCost + i] = xchg[i];
@@ -418,7 +420,7 @@ __global__ void k_decide(DecideParams p) {
     if (p.lm->done && p.lm->done_seq == 0) p.lm->done_seq = p.seq;
   }
   __syncthreads();
-  lm_publish(p.lm, p.host_state, p.scal, p.host_scal, p.host_seq, p.seq, threadIdx.x, blockDim.x);
+  if (p.host_seq) lm_publish(p.lm, p.host_state, p.scal, p.host_scal, p.host_seq, p.seq, threadIdx.x, blockDim.x);   // null: deferred to k_schur / k_flush
 }
 
 // =====================================================================================================
@@ -509,6 +511,8 @@ struct SampleParams {
   double* block_cost_alt;     // the other parity's block arrays
   int32_t* block_fail_alt;
   int32_t decide;             // run lm_decide in the last workgroup (single rank)
+  double* xchg;               // multi-rank: exchange buffer of the step scalars, packed by the last workgroup
+  int32_t xchg_rank, xchg_world;
   unsigned long long* dbg;    // optional [gridDim.x][8] per-phase cycle stamps of thread 0 (diagnostics)
 };
 
@@ -917,6 +921,10 @@ __global__ __launch_bounds__(WAVES * 64, (R <= 2 ? (JAC ? 3 : 2) : 1)) void k_sa
         if (p.lm && p.decide) lm_decide(p.lm, p.scal, p.log, p.max_log, 0);
         if (p.lm && p.decide && p.lm->done && p.lm->done_seq == 0) p.lm->done_seq = p.seq;
         t_fin3 = p.dbg ? __builtin_amdgcn_s_memrealtime() : 0;
+      }
+      if (p.xchg) {
+        __syncthreads();
+        xchg_pack(p.scal, p.xchg, p.xchg_rank, p.xchg_world, threadIdx.x, NTH);
       }
       if (p.host_scal) {
         __syncthreads();
