@@ -129,6 +129,24 @@ def main():
         eng.set_frame(s_, prob.images[s_])
     reset_state()
     upload_s = time.perf_counter() - t2
+    # measured device-copy bandwidth (SURVEY.md 8d asks for it next to the 8 TB/s spec figure): 1 GiB device-to-device
+    copy_gbps = None
+    if rank == 0:
+        try:
+            src_t = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
+            dst_t = torch.empty_like(src_t)
+            dst_t.copy_(src_t)
+            torch.cuda.synchronize()
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+            for _ in range(5):
+                dst_t.copy_(src_t)
+            ev1.record()
+            torch.cuda.synchronize()
+            copy_gbps = 5 * 2.0 * (1 << 30) / (ev0.elapsed_time(ev1) * 1e-3) / 1e9     # read + write
+            del src_t, dst_t
+        except Exception:
+            copy_gbps = None
     # per-kernel launch durations: a separate short profiled solve (HIP events on the engine's stream, one stream
     # sync per step) so that the timed region above carries no instrumentation
     reset_state()
@@ -192,6 +210,7 @@ def main():
         "roofline": roofline,
         "pcie_inclusive": {"upload_ms": 1e3 * upload_s, "iters_per_sec": iters_done / (elapsed + upload_s),
                            "note": "host->device upload of the whole window (frames, points, descriptors, observations, cameras) + the same solve"},
+        "device_copy_GBps": copy_gbps,
         "gen_seconds": t_gen,
     }
 

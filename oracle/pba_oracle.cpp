@@ -366,6 +366,10 @@ inline void HuberEvaluate(double a, double s, double rho[3]) {
 // ---------------------------------------------------------------------------------------------
 // Program state: materialised block-sparse Jacobian like Ceres' BlockSparseMatrix for SPARSE_SCHUR.
 // ---------------------------------------------------------------------------------------------
+// Points per parallel work item of the reductions over points (gradient, column norms, Schur elimination): the
+// partial sums are combined in chunk order, which makes every result independent of the thread count.
+constexpr int kChunkPoints = 1024;
+
 struct Program {
   const oracle_problem* p;
   int P, n_c, n_p, n_obs;
@@ -448,18 +452,29 @@ struct Program {
     for (int o = 0; o < n_obs; ++o) c += block_cost[o];
     *cost = c;
     if (want_jac && gradient) {
+      // Ceres accumulates J^T r with per-thread scratch (ProgramEvaluator); here: fixed chunks of kChunkPoints points, the
+      // camera part reduced in chunk order, so the result does not depend on the thread count
       gradient->assign(n_params, 0.0);
-      for (int o = 0; o < n_obs; ++o) {
-        const int cc = cam_col[p->obs_slot[o]];
-        double* gp = gradient->data() + n_cam_params + 3 * (size_t)p->obs_point[o];
-        const double* rb = &r[(size_t)o * P];
-        const double* jc = &Jc[(size_t)o * P * 6];
-        const double* jp = &Jp[(size_t)o * P * 3];
-        for (int i = 0; i < P; ++i) {
-          if (cc >= 0) for (int k = 0; k < 6; ++k) (*gradient)[cc + k] += jc[6 * i + k] * rb[i];
-          for (int k = 0; k < 3; ++k) gp[k] += jp[3 * i + k] * rb[i];
+      const int n_chunks = (n_p + kChunkPoints - 1) / kChunkPoints;
+      std::vector<double> part((size_t)n_chunks * n_cam_params, 0.0);
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 1)
+      for (int ch = 0; ch < n_chunks; ++ch) {
+        double* gc = part.data() + (size_t)ch * n_cam_params;
+        const int o0 = pt_begin[ch * kChunkPoints], o1 = pt_begin[std::min(n_p, (ch + 1) * kChunkPoints)];
+        for (int o = o0; o < o1; ++o) {
+          const int cc = cam_col[p->obs_slot[o]];
+          double* gp = gradient->data() + n_cam_params + 3 * (size_t)p->obs_point[o];
+          const double* rb = &r[(size_t)o * P];
+          const double* jc = &Jc[(size_t)o * P * 6];
+          const double* jp = &Jp[(size_t)o * P * 3];
+          for (int i = 0; i < P; ++i) {
+            if (cc >= 0) for (int k = 0; k < 6; ++k) gc[cc + k] += jc[6 * i + k] * rb[i];
+            for (int k = 0; k < 3; ++k) gp[k] += jp[3 * i + k] * rb[i];
+          }
         }
       }
+      for (int ch = 0; ch < n_chunks; ++ch)
+        for (int k = 0; k < n_cam_params; ++k) (*gradient)[k] = (ch == 0) ? part[k] : (*gradient)[k] + part[(size_t)ch * n_cam_params + k];
     }
     return ok;
   }
@@ -467,16 +482,25 @@ struct Program {
   // BlockSparseMatrix::SquaredColumnNorm
   void squared_column_norm(std::vector<double>& out) const {
     out.assign(n_params, 0.0);
-    for (int o = 0; o < n_obs; ++o) {
-      const int cc = cam_col[p->obs_slot[o]];
-      double* np = out.data() + n_cam_params + 3 * (size_t)p->obs_point[o];
-      const double* jc = &Jc[(size_t)o * P * 6];
-      const double* jp = &Jp[(size_t)o * P * 3];
-      for (int i = 0; i < P; ++i) {
-        if (cc >= 0) for (int k = 0; k < 6; ++k) out[cc + k] += jc[6 * i + k] * jc[6 * i + k];
-        for (int k = 0; k < 3; ++k) np[k] += jp[3 * i + k] * jp[3 * i + k];
+    const int n_chunks = (n_p + kChunkPoints - 1) / kChunkPoints;
+    std::vector<double> part((size_t)n_chunks * n_cam_params, 0.0);
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 1)
+    for (int ch = 0; ch < n_chunks; ++ch) {
+      double* oc = part.data() + (size_t)ch * n_cam_params;
+      const int o0 = pt_begin[ch * kChunkPoints], o1 = pt_begin[std::min(n_p, (ch + 1) * kChunkPoints)];
+      for (int o = o0; o < o1; ++o) {
+        const int cc = cam_col[p->obs_slot[o]];
+        double* np = out.data() + n_cam_params + 3 * (size_t)p->obs_point[o];
+        const double* jc = &Jc[(size_t)o * P * 6];
+        const double* jp = &Jp[(size_t)o * P * 3];
+        for (int i = 0; i < P; ++i) {
+          if (cc >= 0) for (int k = 0; k < 6; ++k) oc[cc + k] += jc[6 * i + k] * jc[6 * i + k];
+          for (int k = 0; k < 3; ++k) np[k] += jp[3 * i + k] * jp[3 * i + k];
+        }
       }
     }
+    for (int ch = 0; ch < n_chunks; ++ch)
+      for (int k = 0; k < n_cam_params; ++k) out[k] = (ch == 0) ? part[k] : out[k] + part[(size_t)ch * n_cam_params + k];
   }
   // BlockSparseMatrix::ScaleColumns
   void scale_columns(const std::vector<double>& scale) {
@@ -557,12 +581,20 @@ bool SchurSolve(const Program& g, const std::vector<double>& D, std::vector<doub
   const oracle_problem* p = g.p;
   const int n = g.n_cam_params, P = g.P;
   std::vector<double> S((size_t)n * n, 0.0), rhs(n, 0.0);
-  for (int i = 0; i < n; ++i) S[(size_t)i * n + i] = D[i] * D[i];
   std::vector<double> inv_ete((size_t)g.n_p * 9), gvec((size_t)g.n_p * 3);
   bool ok = true;
-  const int max_obs = g.n_c;
-  std::vector<double> buf((size_t)max_obs * 18 + 64);
-  for (int pt = 0; pt < g.n_p; ++pt) {
+  // SchurEliminator::Eliminate runs its chunks on num_linear_solver_threads threads (photobundle.cc:754) with per-thread
+  // buffers; here every chunk of kChunkPoints points accumulates into its own S / rhs and the chunks are added in order
+  const int n_chunks = (g.n_p + kChunkPoints - 1) / kChunkPoints;
+  std::vector<double> S_part((size_t)n_chunks * n * n, 0.0), rhs_part((size_t)n_chunks * n, 0.0);
+  std::vector<char> chunk_ok(n_chunks, 1);
+  for (int i = 0; i < n; ++i) S_part[(size_t)i * n + i] = D[i] * D[i];     // chunk 0 starts from the LM diagonal
+#pragma omp parallel for num_threads(g.threads) schedule(dynamic, 1)
+  for (int ch = 0; ch < n_chunks; ++ch) {
+  double* S = S_part.data() + (size_t)ch * n * n;
+  double* rhs = rhs_part.data() + (size_t)ch * n;
+  std::vector<double> buf((size_t)g.n_c * 18 + 64);
+  for (int pt = ch * kChunkPoints; pt < std::min(g.n_p, (ch + 1) * kChunkPoints); ++pt) {
     const int b = g.pt_begin[pt], e = g.pt_begin[pt + 1];
     if (b == e) continue;
     const double* Dp = D.data() + n + 3 * (size_t)pt;
@@ -588,7 +620,7 @@ bool SchurSolve(const Program& g, const std::vector<double>& D, std::vector<doub
       }
     }
     double* inv = &inv_ete[(size_t)pt * 9];
-    if (!InvertPSD3(ete, inv)) { ok = false; break; }
+    if (!InvertPSD3(ete, inv)) { chunk_ok[ch] = 0; break; }
     for (int a = 0; a < 3; ++a) gvec[(size_t)pt * 3 + a] = ge[a];
     double ig[3];
     for (int a = 0; a < 3; ++a) ig[a] = inv[3 * a] * ge[0] + inv[3 * a + 1] * ge[1] + inv[3 * a + 2] * ge[2];
@@ -615,12 +647,22 @@ bool SchurSolve(const Program& g, const std::vector<double>& D, std::vector<doub
       }
     }
   }
+  }
+  for (int ch = 0; ch < n_chunks; ++ch) {
+    if (!chunk_ok[ch]) ok = false;
+    const double* Sc = S_part.data() + (size_t)ch * n * n;
+    const double* rc = rhs_part.data() + (size_t)ch * n;
+    for (size_t k = 0; k < (size_t)n * n; ++k) S[k] = (ch == 0) ? Sc[k] : S[k] + Sc[k];
+    for (int k = 0; k < n; ++k) rhs[k] = (ch == 0) ? rc[k] : rhs[k] + rc[k];
+  }
+  if (n_chunks == 0) for (int i = 0; i < n; ++i) S[(size_t)i * n + i] = D[i] * D[i];
   if (!ok) return false;
   std::vector<double> yc = rhs;
   if (n > 0 && !CholeskySolve(S, n, yc)) return false;
   y.assign(g.n_params, 0.0);
   for (int i = 0; i < n; ++i) y[i] = yc[i];
-  // BackSubstitute
+  // BackSubstitute (points are independent)
+#pragma omp parallel for num_threads(g.threads) schedule(static)
   for (int pt = 0; pt < g.n_p; ++pt) {
     const int b = g.pt_begin[pt], e = g.pt_begin[pt + 1];
     if (b == e) continue;
