@@ -166,6 +166,11 @@ void launch_solve(pba_engine* e, const SolveParams& so, int n) {
     case 8: launch_solve_wave<8>(e, so); return;
     case 9: launch_solve_wave<9>(e, so); return;
     case 10: launch_solve_wave<10>(e, so); return;
+    case 11: hipLaunchKernelGGL((k_solve_wave2<11>), dim3(1), dim3(128), 0, e->stream, so); return;
+    case 12: hipLaunchKernelGGL((k_solve_wave2<12>), dim3(1), dim3(128), 0, e->stream, so); return;
+    case 13: hipLaunchKernelGGL((k_solve_wave2<13>), dim3(1), dim3(128), 0, e->stream, so); return;
+    case 14: hipLaunchKernelGGL((k_solve_wave2<14>), dim3(1), dim3(128), 0, e->stream, so); return;
+    case 15: hipLaunchKernelGGL((k_solve_wave2<15>), dim3(1), dim3(128), 0, e->stream, so); return;
     default: break;
   }
   const size_t solve_smem = sizeof(double) * ((size_t)n * (n + 1) + 5 * n);

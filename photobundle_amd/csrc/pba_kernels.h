@@ -1582,6 +1582,113 @@ __global__ __launch_bounds__(256) void k_solve_wave(SolveParams p_in) {
   if (PBA_PHASE_TIMING && p.dbg && tid == 0) printf("k_solve_wave cycles: prologue %llu cholesky %llu substitution %llu epilogue %llu\n", t1 - t0, t2 - t1, t3 - t2, t4 - t3);
 }
 
+// 60 < n = 6 NF <= 96 (11..16 free cameras, BASELINE configs[3]): two waves, thread r owns row r of L in registers,
+// LEFT-looking: at step j every thread reads row j of L (entries k < j, written to LDS as they were produced) with
+// wave-uniform broadcast reads and forms  L_rj = (A_rj - sum_k L_rk L_jk) / L_jj;  the pivot L_jj^2 = A_jj - sum_k L_jk^2
+// is recomputed by every thread from the same broadcast row, so there is no second exchange.  Only the newest entry
+// L_j,j-1 sits on the dependent chain; the prefix of the dot product can be issued as early as its operands exist.
+// One workgroup barrier per column (two waves).  The right-hand side is folded in one step behind (z_j is published
+// with column j and consumed at step j + 1).  The backward sweep runs inside each wave with v_readlane: wave 1
+// (rows >= 64) first, its solution crosses to wave 0 through LDS once.
+template <int NF>
+__global__ __launch_bounds__(128) void k_solve_wave2(SolveParams p_in) {
+  SolveParams p = p_in;
+  p.dbg = 0;
+  if (!solve_resolve(p)) return;
+  constexpr int N = 6 * NF;
+  constexpr int LD = N + 1;
+  static_assert(N > 64 && N <= 96, "two-wave solve");
+  __shared__ __attribute__((aligned(16))) double S[N * LD + 1];
+  __shared__ double y_s[N], sc[N], D2[N], gcs[N], gc[N];
+  __shared__ double z_s[N];          // z_j = (L^-1 y)_j, published with column j
+  __shared__ int s_ok;
+  const int tid = threadIdx.x;
+  solve_prologue<128>(p, N, LD, S, y_s, sc, D2, gcs, gc, tid);
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = tid < N ? tid : N - 1;
+  const bool live = tid < N;
+  // L rows for the broadcast reads and the backward sweep: even stride => 16-byte aligned pairs (ds_read_b128)
+  constexpr int LE = N + (N & 1) + 2;
+  __shared__ __attribute__((aligned(16))) double LT[N * LE];
+  __shared__ double inv_s[N];        // 1 / L_jj, published by row j one step ahead
+  double L[N];
+#pragma unroll
+  for (int c = 0; c < N; ++c) L[c] = 0.0;
+  double y = live ? y_s[r] : 0.0;
+  double d_own = 1.0;
+  double diag = S[r * LD + r];       // running A_rr - sum_k L_rk^2
+  bool ok = true;
+  if (tid == 0) {
+    ok = (diag > 0.0) && isfinite(diag);
+    d_own = fast_rsqrt((diag > 0.0) ? diag : 1.0);
+    inv_s[0] = ok ? d_own : -1.0;    // a negative entry flags a non-positive pivot
+  }
+  lds_barrier();
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    // own entry of column j (original matrix) minus the dot product with row j of L (wave-uniform broadcast reads)
+    double v0 = S[r * LD + j], v1 = 0.0;
+    const double inv = inv_s[j];
+    ok = ok && (inv > 0.0);
+    if (j > 0 && tid >= j) y = fma(-L[j - 1], z_s[j - 1], y);   // rhs: one step behind, rows below j - 1 only
+#pragma unroll
+    for (int k = 0; k + 1 < j; k += 2) {
+      const double2 l2 = *reinterpret_cast<const double2*>(&LT[j * LE + k]);
+      v0 = fma(-L[k], l2.x, v0);
+      v1 = fma(-L[k + 1], l2.y, v1);
+      // bound the number of broadcast reads in flight: with the whole row hoisted the allocator moves L[] to AGPRs
+      // and every FMA pays two v_accvgpr_read
+      if ((k & 15) == 14) __builtin_amdgcn_sched_barrier(0);
+    }
+    if (j & 1) v0 = fma(-L[j - 1], LT[j * LE + j - 1], v0);
+    const double lrj = (tid > j) ? (v0 + v1) * inv : 0.0;
+    L[j] = lrj;
+    if (tid == j) { y *= inv; z_s[j] = y; }
+    if (live && tid > j) LT[r * LE + j] = lrj;
+    diag = fma(-lrj, lrj, diag);
+    if (j + 1 < N && tid == j + 1) {
+      // next pivot, one step ahead: its rsqrt overlaps the barrier and the next broadcast reads
+      const bool pd = (diag > 0.0) && isfinite(diag);
+      d_own = fast_rsqrt(pd ? diag : 1.0);
+      inv_s[j + 1] = pd ? d_own : -1.0;
+    }
+    lds_barrier();
+  }
+  // backward substitution L^T x = z (LT holds L row-major): rows N-1 .. 64 inside wave 1
+  if (wave == 1) {
+#pragma unroll
+    for (int j = N - 1; j >= 64; --j) {
+      const double ljr = (tid < j) ? LT[j * LE + r] : 0.0;
+      if (tid == j) y *= d_own;
+      const double xj = readlane_f64(y, j - 64);
+      if (tid < j) y = fma(-ljr, xj, y);
+    }
+    if (live) y_s[tid] = y;
+  }
+  lds_barrier();
+  if (wave == 0) {
+    // contributions of the rows below (independent loads), then this wave's own chain
+#pragma unroll
+    for (int j = N - 1; j >= 64; --j) y = fma(-LT[j * LE + r], y_s[j], y);
+#pragma unroll
+    for (int j = 63; j >= 0; --j) {
+      const double ljr = (tid < j) ? LT[j * LE + r] : 0.0;
+      if (tid == j) y *= d_own;
+      const double xj = readlane_f64(y, j);
+      if (tid < j) y = fma(-ljr, xj, y);
+    }
+    y_s[tid] = y;
+  }
+  {
+    const unsigned long long okm = __ballot(ok);
+    if (tid == 0) s_ok = 1;
+    lds_barrier();
+    if ((tid & 63) == 0 && okm != ~0ull) s_ok = 0;
+  }
+  __syncthreads();
+  solve_epilogue<128>(p, N, y_s, sc, D2, gcs, gc, s_ok != 0, tid);
+}
+
 // Generic path (any n <= 96): matrix in LDS, 256 threads, 2-D trailing update, one barrier pair per column.
 constexpr int kSolveThreads = 256;
 
