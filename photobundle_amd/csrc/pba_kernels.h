@@ -1425,18 +1425,32 @@ __device__ __forceinline__ void solve_prologue(const SolveParams& p, int n, int 
     gcs[i] = s * g;
     y[i] = s * src[nT + i];
   }
-  __syncthreads();
-  for (int e = tid; e < nT; e += T) {
-    const int pair = e / 36, k = e - pair * 36;
-    const int i = k / 6, j = k - i * 6;
-    int a = 0, rem = pair;
+  // pair index -> (a, b), decoded once (the packed blocks are enumerated row by row: (a, a..nf-1))
+  __shared__ unsigned char s_pa[kMaxFrames * (kMaxFrames + 1) / 2], s_pb[kMaxFrames * (kMaxFrames + 1) / 2];
+  for (int pr = tid; pr < p.n_pairs; pr += T) {
+    int a = 0, rem = pr;
     while (rem >= p.n_free - a) { rem -= p.n_free - a; ++a; }
-    const int b = a + rem;
-    const int r = 6 * a + i, c = 6 * b + j;
-    double v = sc[r] * src[e] * sc[c];
-    if (r == c) v += D2[r];
-    if (a != b || c >= r) S[r * ld + c] = v;   // diagonal blocks: take the upper triangle, mirror below
-    if (a != b || c > r) S[c * ld + r] = v;
+    s_pa[pr] = (unsigned char)a; s_pb[pr] = (unsigned char)(a + rem);
+  }
+  __syncthreads();
+  // four packed entries in flight per thread (the loop is otherwise one dependent global load per trip)
+  for (int e0 = tid; e0 < nT; e0 += 4 * T) {
+    double val[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int e = e0 + u * T; val[u] = (e < nT) ? src[e] : 0.0; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = e0 + u * T;
+      if (e >= nT) continue;
+      const int pair = e / 36, k = e - pair * 36;
+      const int i = k / 6, j = k - i * 6;
+      const int a = s_pa[pair], b = s_pb[pair];
+      const int r = 6 * a + i, c = 6 * b + j;
+      double v = sc[r] * val[u] * sc[c];
+      if (r == c) v += D2[r];
+      if (a != b || c >= r) S[r * ld + c] = v;   // diagonal blocks: take the upper triangle, mirror below
+      if (a != b || c > r) S[c * ld + r] = v;
+    }
   }
   __syncthreads();
   if (p.S_dbg) {
@@ -1583,17 +1597,19 @@ __global__ __launch_bounds__(256) void k_solve_wave(SolveParams p_in) {
 }
 
 // 60 < n = 6 NF <= 96 (11..16 free cameras, BASELINE configs[3]): two waves, thread r owns row r of L in registers,
-// LEFT-looking: at step j every thread reads row j of L (entries k < j, written to LDS as they were produced) with
-// wave-uniform broadcast reads and forms  L_rj = (A_rj - sum_k L_rk L_jk) / L_jj;  the pivot L_jj^2 = A_jj - sum_k L_jk^2
-// is recomputed by every thread from the same broadcast row, so there is no second exchange.  Only the newest entry
-// L_j,j-1 sits on the dependent chain; the prefix of the dot product can be issued as early as its operands exist.
+// LEFT-looking and software-pipelined: L_rj = (A_rj - sum_k L_rk L_jk) / L_jj with row j of L read from LDS by
+// wave-uniform broadcasts.  All terms k < j - 1 of column j are accumulated during step j - 1 (their operands were
+// published a step earlier), so after the barrier only the newest term L_j,j-1 and the scaling remain on the dependent
+// chain; the owner of row j + 1 then derives the next pivot from its running diagonal and publishes 1 / L_j+1,j+1 while
+// everybody accumulates the next prefix.
 // One workgroup barrier per column (two waves).  The right-hand side is folded in one step behind (z_j is published
 // with column j and consumed at step j + 1).  The backward sweep runs inside each wave with v_readlane: wave 1
 // (rows >= 64) first, its solution crosses to wave 0 through LDS once.
 template <int NF>
 __global__ __launch_bounds__(128) void k_solve_wave2(SolveParams p_in) {
   SolveParams p = p_in;
-  p.dbg = 0;
+  if (!PBA_PHASE_TIMING) p.dbg = 0;
+  unsigned long long t0 = (PBA_PHASE_TIMING ? __builtin_amdgcn_s_memtime() : 0ull), t1 = 0, t2 = 0, t3 = 0;
   if (!solve_resolve(p)) return;
   constexpr int N = 6 * NF;
   constexpr int LD = N + 1;
@@ -1604,6 +1620,7 @@ __global__ __launch_bounds__(128) void k_solve_wave2(SolveParams p_in) {
   __shared__ int s_ok;
   const int tid = threadIdx.x;
   solve_prologue<128>(p, N, LD, S, y_s, sc, D2, gcs, gc, tid);
+  t1 = (PBA_PHASE_TIMING ? __builtin_amdgcn_s_memtime() : 0ull);
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = tid < N ? tid : N - 1;
   const bool live = tid < N;
@@ -1623,37 +1640,49 @@ __global__ __launch_bounds__(128) void k_solve_wave2(SolveParams p_in) {
     d_own = fast_rsqrt((diag > 0.0) ? diag : 1.0);
     inv_s[0] = ok ? d_own : -1.0;    // a negative entry flags a non-positive pivot
   }
+  // pre = A_r,j - sum_{k < j-1} L_rk L_jk for the column about to be finished: everything except the newest term
+  double pre0 = S[r * LD + 0], pre1 = 0.0;
   lds_barrier();
 #pragma unroll
   for (int j = 0; j < N; ++j) {
-    // own entry of column j (original matrix) minus the dot product with row j of L (wave-uniform broadcast reads)
-    double v0 = S[r * LD + j], v1 = 0.0;
     const double inv = inv_s[j];
     ok = ok && (inv > 0.0);
+    // finish column j: only the term with L_j,j-1 (written during the previous step) was still missing
+    double v = pre0 + pre1;
+    if (j > 0) v = fma(-L[j - 1], LT[j * LE + j - 1], v);
     if (j > 0 && tid >= j) y = fma(-L[j - 1], z_s[j - 1], y);   // rhs: one step behind, rows below j - 1 only
-#pragma unroll
-    for (int k = 0; k + 1 < j; k += 2) {
-      const double2 l2 = *reinterpret_cast<const double2*>(&LT[j * LE + k]);
-      v0 = fma(-L[k], l2.x, v0);
-      v1 = fma(-L[k + 1], l2.y, v1);
-      // bound the number of broadcast reads in flight: with the whole row hoisted the allocator moves L[] to AGPRs
-      // and every FMA pays two v_accvgpr_read
-      if ((k & 15) == 14) __builtin_amdgcn_sched_barrier(0);
-    }
-    if (j & 1) v0 = fma(-L[j - 1], LT[j * LE + j - 1], v0);
-    const double lrj = (tid > j) ? (v0 + v1) * inv : 0.0;
+    const double lrj = (tid > j) ? v * inv : 0.0;
     L[j] = lrj;
     if (tid == j) { y *= inv; z_s[j] = y; }
     if (live && tid > j) LT[r * LE + j] = lrj;
     diag = fma(-lrj, lrj, diag);
     if (j + 1 < N && tid == j + 1) {
-      // next pivot, one step ahead: its rsqrt overlaps the barrier and the next broadcast reads
+      // next pivot: its rsqrt chain overlaps the prefix accumulation below (and the barrier)
       const bool pd = (diag > 0.0) && isfinite(diag);
       d_own = fast_rsqrt(pd ? diag : 1.0);
       inv_s[j + 1] = pd ? d_own : -1.0;
     }
+    if (j + 1 < N) {
+      // prefix of column j + 1 from row j + 1 of L, entries k < j (all published before the last barrier): four
+      // independent partial sums, wave-uniform 16-byte broadcast reads
+      pre0 = S[r * LD + j + 1]; pre1 = 0.0;
+      double pre2 = 0.0, pre3 = 0.0;
+#pragma unroll
+      for (int k = 0; k + 3 < j; k += 4) {
+        const double2 la = *reinterpret_cast<const double2*>(&LT[(j + 1) * LE + k]);
+        const double2 lb = *reinterpret_cast<const double2*>(&LT[(j + 1) * LE + k + 2]);
+        pre0 = fma(-L[k], la.x, pre0);
+        pre1 = fma(-L[k + 1], la.y, pre1);
+        pre2 = fma(-L[k + 2], lb.x, pre2);
+        pre3 = fma(-L[k + 3], lb.y, pre3);
+      }
+#pragma unroll
+      for (int k = j & ~3; k < j; ++k) pre0 = fma(-L[k], LT[(j + 1) * LE + k], pre0);
+      pre0 += pre2; pre1 += pre3;
+    }
     lds_barrier();
   }
+  t2 = (PBA_PHASE_TIMING ? __builtin_amdgcn_s_memtime() : 0ull);
   // backward substitution L^T x = z (LT holds L row-major): rows N-1 .. 64 inside wave 1
   if (wave == 1) {
 #pragma unroll
@@ -1686,7 +1715,11 @@ __global__ __launch_bounds__(128) void k_solve_wave2(SolveParams p_in) {
     if ((tid & 63) == 0 && okm != ~0ull) s_ok = 0;
   }
   __syncthreads();
+  t3 = (PBA_PHASE_TIMING ? __builtin_amdgcn_s_memtime() : 0ull);
   solve_epilogue<128>(p, N, y_s, sc, D2, gcs, gc, s_ok != 0, tid);
+  if (PBA_PHASE_TIMING && p.dbg && tid == 0)
+    printf("k_solve_wave2 cycles: prologue %llu cholesky %llu substitution %llu epilogue %llu\n", t1 - t0, t2 - t1, t3 - t2,
+           (unsigned long long)__builtin_amdgcn_s_memtime() - t3);
 }
 
 // Generic path (any n <= 96): matrix in LDS, 256 threads, 2-D trailing update, one barrier pair per column.
