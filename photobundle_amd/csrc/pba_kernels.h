@@ -1511,11 +1511,18 @@ __device__ __forceinline__ void solve_epilogue(const SolveParams& p, int n, cons
   }
 }
 
-// Fast path, n = 6 NF <= 60: wave 0 keeps row r of the matrix in lane r's registers (compile-time indexed).  Per
-// column ONE LDS round trip broadcasts the unscaled column v = A[:, j]; with t_r = v_r / v_j the trailing update is
-// a[c] -= t_r * v_c and the factor entry is L_rj = v_r * rsqrt(v_j): no second broadcast, no barriers (one wave).
-// The right-hand side is carried as an extra column, which makes the forward substitution part of the factorisation.
-// The other three waves only help with the prologue / epilogue.
+// Fast path, n = 6 NF <= 60: lane r of wave 0 keeps row r of L in registers (compile-time indexed) and runs the
+// left-looking, software-pipelined factorisation described at k_solve_wave2 (same algorithm, one wave: the exchange
+// through LDS needs no barrier, only the compiler-level ordering of wave_lds_sync).  The right-hand side is folded in
+// one step behind; the backward sweep uses v_readlane.  The other three waves only help with the prologue / epilogue.
+// Orders the LDS traffic of ONE wave (its LDS operations execute in order; this only stops the compiler from moving
+// them): used where a single wave exchanges data with itself through LDS.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <int NF>
 __global__ __launch_bounds__(256) void k_solve_wave(SolveParams p_in) {
   SolveParams p = p_in;
@@ -1523,9 +1530,10 @@ __global__ __launch_bounds__(256) void k_solve_wave(SolveParams p_in) {
   if (!solve_resolve(p)) return;
   constexpr int N = 6 * NF;
   constexpr int LD = N + 1;
+  constexpr int LE = N + (N & 1) + 2;       // even stride: 16-byte aligned pairs for the broadcast reads
   __shared__ double S[N * LD];
-  __shared__ __attribute__((aligned(16))) double s_col[128];
-  __shared__ double y_s[N], sc[N], D2[N], gcs[N], gc[N];
+  __shared__ __attribute__((aligned(16))) double LT[N * LE];
+  __shared__ double y_s[N], sc[N], D2[N], gcs[N], gc[N], z_s[N], inv_s[N];
   __shared__ int s_ok;
   const int tid = threadIdx.x;
   unsigned long long t0 = (PBA_PHASE_TIMING ? __builtin_amdgcn_s_memtime() : 0ull), t1 = 0, t2 = 0, t3 = 0, t4 = 0;
@@ -1534,60 +1542,73 @@ __global__ __launch_bounds__(256) void k_solve_wave(SolveParams p_in) {
   if (tid < 64) {
     const int lane = tid;
     const int r = lane < N ? lane : N - 1;
-    double a[N];
+    const bool live = lane < N;
+    double L[N];
 #pragma unroll
-    for (int c = 0; c < N; ++c) a[c] = (lane < N && c <= lane) ? S[r * LD + c] : 0.0;
-    double y = lane < N ? y_s[r] : 0.0;
-    double d_own = 1.0;      // 1 / L_rr of this lane's row
+    for (int c = 0; c < N; ++c) L[c] = 0.0;
+    double y = live ? y_s[r] : 0.0;
+    double d_own = 1.0;              // 1 / L_rr of this lane's row
+    double diag = S[r * LD + r];     // running A_rr - sum_k L_rk^2
     bool ok = true;
-    // look-ahead: column j+1 is finished and broadcast (double-buffered) BEFORE the rest of column j's trailing
-    // update, so the LDS round trip and the rsqrt chain of the next pivot overlap the FMAs of this one
-    s_col[lane] = a[0];
-    if (lane == 0) s_col[63] = y;     // the right-hand side rides along as one more column (slot 63: N <= 60)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane == 0) {
+      ok = (diag > 0.0) && isfinite(diag);
+      d_own = fast_rsqrt((diag > 0.0) ? diag : 1.0);
+      inv_s[0] = ok ? d_own : -1.0;  // a negative entry flags a non-positive pivot
+    }
+    double pre0 = S[r * LD + 0], pre1 = 0.0;
+    wave_lds_sync();
 #pragma unroll
     for (int j = 0; j < N; ++j) {
-      const double* col = s_col + (j & 1) * 64;
-      double* col_next = s_col + ((j + 1) & 1) * 64;
-      const double piv = col[j];
-      ok = ok && (piv > 0.0) && isfinite(piv);
-      const double pv = (piv > 0.0) ? piv : 1.0;
-      const double inv = fast_rsqrt(pv);
-      const double t = a[j] * (inv * inv);
-      if (lane == j) d_own = inv;
-      a[j] = a[j] * inv;                 // L_rj (lane j: sqrt(piv))
-      // forward substitution folded in: z_j = y_j / L_jj, y_r -= (L_rj / L_jj) y_j for the rows below
-      y = (lane > j) ? fma(-t, col[63], y) : ((lane == j) ? y * inv : y);
-      if (j + 1 < N) {
-        a[j + 1] = fma(-t, col[j + 1], a[j + 1]);
-        col_next[lane] = a[j + 1];
-        if (lane == j + 1) col_next[63] = y;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      const double inv = inv_s[j];
+      ok = ok && (inv > 0.0);
+      // finish column j: only the term with L_j,j-1 (written during the previous step) was still missing
+      double v = pre0 + pre1;
+      if (j > 0) v = fma(-L[j - 1], LT[j * LE + j - 1], v);
+      if (j > 0 && lane >= j) y = fma(-L[j - 1], z_s[j - 1], y);   // rhs: one step behind, rows below j - 1 only
+      const double lrj = (lane > j) ? v * inv : 0.0;
+      L[j] = lrj;
+      if (lane == j) { y *= inv; z_s[j] = y; }
+      if (live && lane > j) LT[r * LE + j] = lrj;
+      diag = fma(-lrj, lrj, diag);
+      if (j + 1 < N && lane == j + 1) {
+        // next pivot, one step ahead: derived from this row's running diagonal
+        const bool pd = (diag > 0.0) && isfinite(diag);
+        d_own = fast_rsqrt(pd ? diag : 1.0);
+        inv_s[j + 1] = pd ? d_own : -1.0;
       }
+      if (j + 1 < N) {
+        // prefix of column j + 1 from row j + 1 of L, entries k < j (published before the last sync)
+        pre0 = S[r * LD + j + 1]; pre1 = 0.0;
+        double pre2 = 0.0, pre3 = 0.0;
 #pragma unroll
-      for (int c = j + 2; c < N; ++c) a[c] = fma(-t, col[c], a[c]);   // meaningful for lanes >= c
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int k = 0; k + 3 < j; k += 4) {
+          const double2 la = *reinterpret_cast<const double2*>(&LT[(j + 1) * LE + k]);
+          const double2 lb = *reinterpret_cast<const double2*>(&LT[(j + 1) * LE + k + 2]);
+          pre0 = fma(-L[k], la.x, pre0);
+          pre1 = fma(-L[k + 1], la.y, pre1);
+          pre2 = fma(-L[k + 2], lb.x, pre2);
+          pre3 = fma(-L[k + 3], lb.y, pre3);
+        }
+#pragma unroll
+        for (int k = j & ~3; k < j; ++k) pre0 = fma(-L[k], LT[(j + 1) * LE + k], pre0);
+        pre0 += pre2; pre1 += pre3;
+      }
+      wave_lds_sync();
     }
     t2 = (PBA_PHASE_TIMING ? __builtin_amdgcn_s_memtime() : 0ull);
-    // L to LDS (row-major) for the transposed access of the backward sweep
-#pragma unroll
-    for (int c = 0; c < N; ++c) if (lane < N && c <= lane) S[r * LD + c] = a[c];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // backward substitution L^T x = z: lane r reads L[j][r] (row j, contiguous across lanes)
 #pragma unroll
     for (int j = N - 1; j >= 0; --j) {
-      const double ljr = (lane < j) ? S[j * LD + r] : 0.0;
+      const double ljr = (lane < j) ? LT[j * LE + r] : 0.0;
       if (lane == j) y *= d_own;
       const double xj = readlane_f64(y, j);
       if (lane < j) y = fma(-ljr, xj, y);
     }
     if (lane < N) y_s[lane] = y;
-    if (lane == 0) s_ok = ok ? 1 : 0;
+    {
+      const unsigned long long okm = __ballot(ok);
+      if (lane == 0) s_ok = (okm == ~0ull) ? 1 : 0;
+    }
     t3 = (PBA_PHASE_TIMING ? __builtin_amdgcn_s_memtime() : 0ull);
   }
   __syncthreads();
@@ -1657,7 +1678,7 @@ __global__ __launch_bounds__(128) void k_solve_wave2(SolveParams p_in) {
     if (live && tid > j) LT[r * LE + j] = lrj;
     diag = fma(-lrj, lrj, diag);
     if (j + 1 < N && tid == j + 1) {
-      // next pivot: its rsqrt chain overlaps the prefix accumulation below (and the barrier)
+      // next pivot, one step ahead: derived from this row's running diagonal
       const bool pd = (diag > 0.0) && isfinite(diag);
       d_own = fast_rsqrt(pd ? diag : 1.0);
       inv_s[j + 1] = pd ? d_own : -1.0;
