@@ -165,6 +165,15 @@ def test_sixteen_frames_reduced_system():
     assert np.abs(rhs - ref["rhs"]).max() <= 1e-9 * np.abs(ref["rhs"]).max()
 
 
+@pytest.mark.parametrize("n_frames", [6, 9, 11, 12, 14])
+def test_lm_trace_other_window_lengths(n_frames):
+    """Every instantiation family of the reduced-system solve: k_solve_wave<NF> (n <= 60) and k_solve_wave2<NF>
+    (60 < n <= 90) against the oracle's trust-region trace."""
+    p = synthetic.make_window(n_frames=n_frames, n_points=60, radius=2, size=(120, 200), K=(250.0, 250.0, 100.0, 60.0),
+                              seed_offset=3 + n_frames, visibility="causal")
+    _compare_traces(p, 12)
+
+
 def test_error_paths(small_window):
     from photobundle_amd.engine import Engine, EngineError
     p = small_window
