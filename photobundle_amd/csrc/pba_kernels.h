@@ -248,6 +248,13 @@ __device__ inline void lm_log(LmState* st, pba_iteration_summary* log, int max_l
 }
 
 // `s` = the step's (fully reduced) scalar block.  grad_only: only the gradient norms of the current point are valid.
+// Gate of the final (gradient-only) pass, evaluated on the device so that the host can enqueue that pass without first
+// reading the state back: it is needed for iteration zero of a zero-iteration solve and when the iteration limit was
+// reached right after an accepted step (whose gradient norms are still to be reported).
+__device__ __forceinline__ bool lm_final_pass_needed(const LmState* st) {
+  return st->first || (st->pending_grad >= 0 && (st->done == kLmRunning || st->done == kLmMaxIterations));
+}
+
 __device__ inline void lm_decide(LmState* st, const double* s, pba_iteration_summary* log, int max_log, int grad_only) {
   const double gmax = fmax(s[kGmaxPts], s[kGmaxCams]);
   const double gnorm = sqrt(s[kGnorm2Pts] + s[kGnorm2Cams]);
@@ -1003,6 +1010,7 @@ __global__ __launch_bounds__(kTile, 2) void k_schur(SchurParams p_in) {
     lm_publish(p.lm, p.pub_state, p.pub_scal, p.pub_host_scal, p.pub_host_seq, p.pub_seq, threadIdx.x, kTile);
   if (p.lm) {
     if (p.lm->done && !p.final_pass) return;
+    if (p.final_pass && !lm_final_pass_needed(p.lm)) return;
     if (p.lm->cur != p.enq_cur) { p.xyz = p.xyz_alt; p.geom = p.geom_alt; p.rec = p.rec_alt; }
     p.radius = p.lm->radius;
     p.inv_radius = 1.0 / p.radius;
@@ -1313,6 +1321,7 @@ __global__ __launch_bounds__(1024) void k_reduce_final(const double* __restrict_
                                                         const int32_t* block_fail_alt, int final_pass) {
   if (lm) {
     if (lm->done && !final_pass) return;
+    if (final_pass && !lm_final_pass_needed(lm)) return;
     if (lm->cur != enq_cur) { block_cost = block_cost_alt; block_fail = block_fail_alt; }
   }
   constexpr int EX = kReduceEntries, SUB = 1024 / EX;
@@ -1392,6 +1401,7 @@ struct SolveParams {
 __device__ __forceinline__ bool solve_resolve(SolveParams& p) {
   if (!p.lm) return true;
   if (p.lm->done && !p.final_pass) return false;
+  if (p.final_pass && !lm_final_pass_needed(p.lm)) return false;
   if (p.lm->cur != p.enq_cur) {
     p.cams = p.cams_alt; p.cams_cand = p.cams_cand_alt; p.geom = p.geom_alt;
     if (p.geom_cand) p.geom_cand = p.geom_cand_alt;

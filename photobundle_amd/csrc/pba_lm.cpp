@@ -48,15 +48,14 @@ static int solve_async(pba_engine* e, const pba_solver_options* o, pba_solver_su
     ++enq;
     if (enq > kAhead) { if ((rc = pba_internal_async_wait(e, seqs[(enq - kAhead) % (kAhead + 1)]))) return rc; }
   }
-  // flush: the last step's outcome and the iteration log reach the host mirror
+  // Iteration limit (or max_num_iterations <= 0): the gradient norms of the final point may still be missing.  The pass
+  // that computes them is enqueued unconditionally and gates itself on the device state (lm_final_pass_needed), which
+  // saves a host round trip; then ONE flush brings the last outcome and the iteration log to the host mirror.
+  if (enq >= o->max_num_iterations) {
+    if ((rc = pba_internal_async_enqueue(e, 2, o->max_num_iterations <= 0 ? 1 : 0, o, &seq))) return rc;
+  }
   if ((rc = pba_internal_async_enqueue(e, 3, 0, o, &seq))) return rc;
   if ((rc = pba_internal_async_wait(e, seq))) return rc;
-  if (o->max_num_iterations <= 0 || (st->pending_grad >= 0 && (st->done == pba::kLmRunning || st->done == pba::kLmMaxIterations))) {
-    // gradient norms of the final point (iteration limit reached right after an accepted step, or max_it == 0)
-    if ((rc = pba_internal_async_enqueue(e, 2, o->max_num_iterations <= 0 ? 1 : 0, o, &seq))) return rc;
-    if ((rc = pba_internal_async_enqueue(e, 3, 0, o, &seq))) return rc;
-    if ((rc = pba_internal_async_wait(e, seq))) return rc;
-  }
   (void)last_seq;
   if ((rc = pba_internal_async_end(e))) return rc;
   LmState fin;
