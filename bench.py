@@ -84,12 +84,31 @@ def main():
 
     eng = Engine(rows, cols, prob.K, prob.radius, prob.n_frames, huber=prob.huber, device=local_rank)
     eng.load(prob)
+    transport = "RCCL all-reduce of the reduced camera system"
     if world > 1:
         uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
         if rank == 0:
             uid.copy_(torch.frombuffer(bytearray(Engine.comm_unique_id()), dtype=torch.uint8))
         dist.broadcast(uid, 0)
-        eng.comm_init_rccl(bytes(uid.cpu().numpy().tobytes()), rank, world)
+        rccl_ok = 1
+        try:
+            eng.comm_init_rccl(bytes(uid.cpu().numpy().tobytes()), rank, world)
+        except Exception as exc:     # keep the multi-GPU line alive: host-staged all-reduce through torch.distributed
+            print("rank %d: RCCL transport unavailable (%s), falling back to the host-staged transport" % (rank, exc), file=sys.stderr)
+            rccl_ok = 0
+        flag = torch.tensor([rccl_ok], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            transport = "host-staged all-reduce via torch.distributed (RCCL init failed)"
+            def _allreduce(a, op):
+                t = torch.from_numpy(a.copy()).cuda()
+                dist.all_reduce(t, op=dist.ReduceOp.MAX if op == 1 else dist.ReduceOp.SUM)
+                a[:] = t.cpu().numpy()
+            if rccl_ok:          # mixed outcome: rebuild the engine so that every rank uses the same transport
+                eng.close()
+                eng = Engine(rows, cols, prob.K, prob.radius, prob.n_frames, huber=prob.huber, device=local_rank)
+                eng.load(prob)
+            eng.comm_init_callback(_allreduce, rank, world)
     elif os.environ.get("PBA_FORCE_MULTI") == "1":
         # diagnostics: the multi-rank code path (RCCL all-reduces on the engine's stream, k_decide) at world = 1
         eng.comm_init_rccl(Engine.comm_unique_id(), 0, 1)
@@ -202,7 +221,7 @@ def main():
                                % ("configs[1]: " if default_shape else "", prob.n_frames, prob.n_points, 2 * prob.radius + 1,
                                   2 * prob.radius + 1, args.visibility),
                    "image": "%dx%d u8" % (cols, rows), "observations": int(n_obs_global), "huber": prob.huber,
-                   "parallelism": "points sharded x%d, cameras+frames replicated, RCCL all-reduce of the reduced camera system" % world},
+                   "parallelism": "points sharded x%d, cameras+frames replicated, %s" % (world, transport)},
         "iters_per_sec": iters_per_sec, "residuals_per_sec": residuals_per_sec,
         "lm": {"iterations": iters_done, "successful": res["num_successful_steps"] - 1, "jacobian_passes": n_jac,
                "cost_passes": n_cost, "resolve_passes": n_res, "initial_cost": res["initial_cost"],
