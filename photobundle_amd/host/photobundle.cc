@@ -149,19 +149,19 @@ void check(pba_engine* e, int rc, const char* what) {
 
 PhotometricBundleAdjustment::Options::Options(const utils::ConfigFile& cf)
     : maxNumPoints(cf.get<int>("maxNumPoints", 4096)),
-      slidingWindowSize(cf.get<int>("slidingWindowSize", 5)),
-      patchRadius(cf.get<int>("patchRadius", 2)),
+      nonMaxSuppRadius(cf.get<int>("nonMaxSuppRadius", 1)),
       maskBlockRadius(cf.get<int>("maskBlockRadius", 1)),
       maxFrameDistance(cf.get<int>("maxFrameDistance", 1)),
-      numThreads(cf.get<int>("numThreads", -1)),
-      doGaussianWeighting((bool)cf.get<int>("doGaussianWeighting", 0)),
-      verbose((bool)cf.get<int>("verbose", 1)),
       minScore(cf.get<double>("minScore", 0.75)),
-      robustThreshold(cf.get<double>("robustThreshold", 0.05)),
       minValidDepth(cf.get<double>("minValidDepth", 0.01)),
       maxValidDepth(cf.get<double>("maxValidDepth", 1000.0)),
-      nonMaxSuppRadius(cf.get<int>("nonMaxSuppRadius", 1)),
+      slidingWindowSize(cf.get<int>("slidingWindowSize", 5)),
+      patchRadius(cf.get<int>("patchRadius", 2)),
+      doGaussianWeighting((bool)cf.get<int>("doGaussianWeighting", 0)),
+      robustThreshold(cf.get<double>("robustThreshold", 0.05)),
       descriptorType(DescriptorTypeFromString(cf.get<std::string>("descriptorType", "Intensity"))),
+      numThreads(cf.get<int>("numThreads", -1)),
+      verbose((bool)cf.get<int>("verbose", 1)),
       device(cf.get<int>("device", 0)) {}
 
 bool PhotometricBundleAdjustment::Result::Writer::add(const Result&) {
