@@ -1,0 +1,118 @@
+"""Edge cases of the hot path through the C-ABI: ragged visibility (1..16 observations per point, points that straddle
+the wave boundary of a Schur tile), a one-point problem, no constant camera, a free camera that nobody observes.
+Reference behaviour: every (point, frame) pair handed to AddResidualBlock is a block of its own, nothing is rejected
+(photobundle.cc:791-804, :725-726); SetParameterBlockConstant is optional (:809-813)."""
+import copy
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from oracle import oracle
+from photobundle_amd import synthetic
+from photobundle_amd.engine import Engine, EngineError, default_solver_options
+
+from gpu_util import dense_system, make_engine, reference_step
+
+pytestmark = pytest.mark.gpu
+
+SMALL = dict(size=(120, 200), K=(250.0, 250.0, 100.0, 60.0))
+
+
+def _subsample(p, keep_mask):
+    """WindowProblem with a subset of the observations (every point keeps >= 1)."""
+    q = copy.copy(p)
+    q.obs_point = p.obs_point[keep_mask].copy()
+    q.obs_slot = p.obs_slot[keep_mask].copy()
+    assert len(np.unique(q.obs_point)) == p.n_points
+    return q
+
+
+def _ragged(n_frames, n_points, seed):
+    p = synthetic.make_window(n_frames=n_frames, n_points=n_points, radius=2, seed_offset=seed, **SMALL)
+    rng = np.random.default_rng(seed)
+    keep = np.zeros(p.n_obs, bool)
+    begin = np.searchsorted(p.obs_point, np.arange(p.n_points + 1))
+    for pt in range(p.n_points):
+        n = begin[pt + 1] - begin[pt]
+        k = int(rng.integers(1, n + 1))                     # 1 .. n_frames observations
+        keep[begin[pt] + rng.choice(n, size=k, replace=False)] = True
+    return _subsample(p, keep)
+
+
+def _check_against_oracle(p, iterations=8):
+    lin = oracle.linearize(p, blocks=False)
+    with make_engine(p) as e:
+        cost = e.linearize()
+        rec = e.obs_records()
+        assert np.isclose(cost, lin["cost"], rtol=1e-12)
+        assert np.allclose(rec[:, 5], 0.5 * lin["block_sqnorm"], rtol=1e-12)
+        res = e.solve(default_solver_options(max_num_iterations=iterations))
+    ref = oracle.solve(p, oracle.default_options(max_num_iterations=iterations))
+    assert len(ref["iterations"]) == len(res["iterations"]), (ref["message"], res["message"])
+    for a, b in zip(ref["iterations"], res["iterations"]):
+        assert a["step_is_successful"] == b["step_is_successful"], a["iteration"]
+        assert np.isclose(a["cost"], b["cost"], rtol=1e-9), a["iteration"]
+    assert np.abs(res["cams"] - ref["cams"]).max() <= 1e-5
+    return ref, res
+
+
+@pytest.mark.parametrize("n_frames,seed", [(16, 1), (8, 2), (5, 3)])
+def test_ragged_visibility(n_frames, seed):
+    p = _ragged(n_frames, 300, seed)
+    counts = np.bincount(p.obs_point)
+    assert counts.min() == 1 and counts.max() >= n_frames - 1
+    _check_against_oracle(p)
+
+
+def test_ragged_reduced_system_matches_dense_algebra():
+    p = _ragged(16, 60, 7)
+    J, r, n_cam = dense_system(p)
+    ref = reference_step(J, r, n_cam, 1e4)
+    with make_engine(p) as e:
+        e.linearize()
+        e.step(1e4, init_scale=True)
+        S, rhs = e.reduced_system()
+    assert np.abs(S - ref["S"]).max() <= 1e-9 * np.abs(ref["S"]).max()
+    assert np.abs(rhs - ref["rhs"]).max() <= 1e-9 * np.abs(ref["rhs"]).max()
+
+
+def test_single_point():
+    p = synthetic.make_window(n_frames=3, n_points=1, radius=2, seed_offset=4, **SMALL)
+    assert p.n_obs == 3
+    _check_against_oracle(p, iterations=5)
+
+
+def test_no_constant_camera():
+    """fixed_slot = -1: all cameras free (gauge freedom is absorbed by the LM damping, as in Ceres)."""
+    p = synthetic.make_window(n_frames=4, n_points=200, radius=2, seed_offset=6, **SMALL)
+    p.fixed_slot = -1
+    _check_against_oracle(p, iterations=6)
+
+
+def test_unobserved_free_camera():
+    """A free camera without residual blocks keeps its pose (its block of the reduced system is the LM diagonal only)."""
+    p = synthetic.make_window(n_frames=5, n_points=200, radius=2, seed_offset=8, **SMALL)
+    q = _subsample(p, p.obs_slot != 3)
+    ref, res = _check_against_oracle(q, iterations=6)
+    assert np.array_equal(res["cams"][3], q.cams[3])
+
+
+def test_rejected_inputs(small_window_edge=None):
+    p = synthetic.make_window(n_frames=3, n_points=20, radius=2, seed_offset=9, **SMALL)
+    e = Engine(120, 200, p.K, 2, 3)
+    try:
+        for s_ in range(3):
+            e.set_frame(s_, p.images[s_])
+        with pytest.raises(EngineError):       # empty problem
+            e.set_problem(p.xyz[:0], p.desc[:0], p.obs_point[:0], p.obs_slot[:0], p.weights)
+        bad = p.obs_slot.copy(); bad[0] = 7
+        with pytest.raises(EngineError):       # slot outside the window
+            e.set_problem(p.xyz, p.desc, p.obs_point, bad, p.weights)
+        e.set_problem(p.xyz, p.desc, p.obs_point, p.obs_slot, p.weights)
+        with pytest.raises(EngineError):       # a single frame cannot form a window
+            e.set_cameras(p.cams[:1], 0)
+    finally:
+        e.close()
