@@ -10,6 +10,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
+#include <omp.h>
 #include <map>
 #include <stdexcept>
 
@@ -177,13 +179,16 @@ PhotometricBundleAdjustment::Result PhotometricBundleAdjustment::Result::FromFil
 struct PhotometricBundleAdjustment::DescriptorFrame {
   uint32_t id;
   Image_<float> I;
-  DescriptorFrame(uint32_t frame_id, const uint8_t* img, int rows, int cols) : id(frame_id), I(rows, cols) {
-    for (size_t i = 0; i < (size_t)rows * cols; ++i) I.d[i] = (float)img[i];
+  DescriptorFrame(uint32_t frame_id, const uint8_t* img, int rows, int cols, int nt) : id(frame_id), I(rows, cols) {
+    const long n = (long)rows * cols;
+#pragma omp parallel for schedule(static) num_threads(nt)
+    for (long i = 0; i < n; ++i) I.d[i] = (float)img[i];
   }
   // computeSaliencyMap (:213-221) = |Ix| + |Iy| with imgradient semantics (imgproc.cc:27-95)
-  void computeSaliencyMap(Image_<float>& smap) const {
+  void computeSaliencyMap(Image_<float>& smap, int nt) const {
     const int rows = I.rows(), cols = I.cols();
     std::fill(smap.d.begin(), smap.d.end(), 0.0f);
+#pragma omp parallel for schedule(static) num_threads(nt)
     for (int y = 1; y < rows - 1; ++y)
       for (int x = 1; x < cols - 1; ++x) {
         const float ix = 0.5f * (I(y, x + 1) - I(y, x - 1));
@@ -231,14 +236,29 @@ PhotometricBundleAdjustment::PhotometricBundleAdjustment(const Calibration& cali
 
 PhotometricBundleAdjustment::~PhotometricBundleAdjustment() { pba_destroy(_engine); }
 
+namespace {
+double wall_ms() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return 1e3 * (double)ts.tv_sec + 1e-6 * (double)ts.tv_nsec;
+}
+}  // namespace
+
 void PhotometricBundleAdjustment::addFrame(const uint8_t* I_ptr, const float* Z_ptr, const Mat44& T, Result* result) {
+  const double t_enter = wall_ms();
   _trajectory.push_back(T, _frame_id);
   const Mat44 T_w = _trajectory.back();
   const Mat44 T_c = T_w.inverse();
   const int rows = _image_size.rows, cols = _image_size.cols;
   const U8View I{I_ptr, rows, cols};
 
-  UniquePointer<DescriptorFrame> frame(new DescriptorFrame(_frame_id, I_ptr, rows, cols));
+  // host threads of the front-end loops: Options::numThreads if given, else at most 8 (the loops are short)
+  const int nt = _options_ptr->numThreads > 0 ? _options_ptr->numThreads : std::max(1, std::min(8, omp_get_max_threads()));
+  double t_ph[6] = {0, 0, 0, 0, 0, 0};
+  double t_last = wall_ms();
+  auto lap = [&](int k) { const double t = wall_ms(); t_ph[k] += t - t_last; t_last = t; };
+  UniquePointer<DescriptorFrame> frame(new DescriptorFrame(_frame_id, I_ptr, rows, cols, nt));
+  lap(5);
   // the engine keeps its own device plane of this frame in the ring slot id % window
   const int window = _options_ptr->slidingWindowSize;
   check(_engine, pba_set_frame_u8(_engine, (int)(_frame_id % window), I_ptr), "pba_set_frame_u8");
@@ -248,31 +268,44 @@ void PhotometricBundleAdjustment::addFrame(const uint8_t* I_ptr, const float* Z_
   const int radius = _options_ptr->patchRadius, patch_length = PatchSizeFromRadius(radius);
   const int mask_radius = _options_ptr->maskBlockRadius;
 
+  lap(0);
   // ---- visibility list update (reference :505-542) ------------------------------------------------------------
   std::fill(_mask.d.begin(), _mask.d.end(), (uint16_t)1);
   int num_updated = 0, max_num_to_update = 0;
-  for (auto& pt : _scene_points) {
-    const int f_dist = (int)_frame_id - (int)pt->lastFrameId();
-    if (f_dist <= _options_ptr->maxFrameDistance) {
-      const Vec2 uv = _calib.project(TransformPoint(T_c, pt->X));
-      ++max_num_to_update;
+  {
+    // the ZNCC test of every tracked point is independent: evaluated on all host threads, applied in list order
+    const int n_sp = (int)_scene_points.size();
+    std::vector<int> hit_r(n_sp, -1), hit_c(n_sp, 0);
+    std::vector<char> tried(n_sp, 0);
+#pragma omp parallel for schedule(dynamic, 64) num_threads(nt)
+    for (int k = 0; k < n_sp; ++k) {
+      const ScenePoint& pt = *_scene_points[k];
+      const int f_dist = (int)_frame_id - (int)pt.lastFrameId();
+      if (f_dist > _options_ptr->maxFrameDistance) continue;
+      tried[k] = 1;
+      const Vec2 uv = _calib.project(TransformPoint(T_c, pt.X));
       const int r = (int)std::round(uv[1]), c = (int)std::round(uv[0]);
       if (r >= B && r < max_rows && c >= B && c <= max_cols) {
         ZnccPatch other;
         other.set(I, uv[0], uv[1]);
-        if (pt->patch.score(other) > _options_ptr->minScore) {
-          ++num_updated;
-          pt->f.push_back(_frame_id);
-          for (int r_i = -mask_radius; r_i <= mask_radius; ++r_i)
-            for (int c_i = -mask_radius; c_i <= mask_radius; ++c_i) _mask(r + r_i, c + c_i) = 0;
-        }
+        if (pt.patch.score(other) > _options_ptr->minScore) { hit_r[k] = r; hit_c[k] = c; }
       }
+    }
+    for (int k = 0; k < n_sp; ++k) {
+      max_num_to_update += tried[k];
+      if (hit_r[k] < 0) continue;
+      ++num_updated;
+      _scene_points[k]->f.push_back(_frame_id);
+      for (int r_i = -mask_radius; r_i <= mask_radius; ++r_i)
+        for (int c_i = -mask_radius; c_i <= mask_radius; ++c_i) _mask(hit_r[k] + r_i, hit_c[k] + c_i) = 0;
     }
   }
 
+  lap(1);
   // ---- new scene points (reference :545-585): valid depth AND strict local maximum of the saliency under the mask --
   ScenePointPointerList new_points;
-  frame->computeSaliencyMap(_saliency_map);
+  frame->computeSaliencyMap(_saliency_map, nt);
+  lap(2);
   const int nms = _options_ptr->nonMaxSuppRadius;
   auto is_local_max = [&](int row, int col) {
     if (nms > 0) {
@@ -284,26 +317,47 @@ void PhotometricBundleAdjustment::addFrame(const uint8_t* I_ptr, const float* Z_
     }
     return true;
   };
-  for (int y = B; y < max_rows; ++y) {
-    for (int x = B; x < max_cols; ++x) {
-      const float z = Z_ptr[(size_t)y * cols + x];
-      if (z >= _options_ptr->minValidDepth && z <= _options_ptr->maxValidDepth && is_local_max(y, x)) {
-        const Vec3 ray = _K_inv * MakeVec3((double)x, (double)y, 1.0);
-        const Vec3 X = TransformPoint(T_w, MakeVec3((double)z * ray[0], (double)z * ray[1], (double)z * ray[2]));
-        ScenePointPointer p(new ScenePoint(X, _frame_id));
-        p->patch.set(I, (double)x, (double)y);
-        p->descriptor.resize(patch_length);
-        p->saliency = _saliency_map(y, x);
-        p->x0 = x; p->y0 = y;
-        new_points.push_back(std::move(p));
+  // The reference builds a ScenePoint for every candidate and cuts to the maxNumPoints most salient ones afterwards
+  // (:545-585, :587-595).  Same selection here on flat (saliency, x, y) records: nth_element sees the same sequence of
+  // comparison outcomes as on the pointer list, so the same candidates survive in the same order -- but only those
+  // get their scene point, ZNCC patch and descriptor built.
+  struct Candidate { float saliency; int x, y; };
+  std::vector<Candidate> cands;
+  {
+    std::vector<std::vector<Candidate>> per_row(max_rows > B ? max_rows - B : 0);
+#pragma omp parallel for schedule(dynamic, 8) num_threads(nt)
+    for (int y = B; y < max_rows; ++y) {
+      std::vector<Candidate>& row = per_row[y - B];
+      for (int x = B; x < max_cols; ++x) {
+        const float z = Z_ptr[(size_t)y * cols + x];
+        if (z >= _options_ptr->minValidDepth && z <= _options_ptr->maxValidDepth && is_local_max(y, x))
+          row.push_back(Candidate{_saliency_map(y, x), x, y});
       }
     }
+    size_t total = 0;
+    for (const auto& row : per_row) total += row.size();
+    cands.reserve(total);
+    for (const auto& row : per_row) cands.insert(cands.end(), row.begin(), row.end());   // row-major, like the scan
   }
-  if (new_points.size() > (size_t)_options_ptr->maxNumPoints) {
-    auto nth = new_points.begin() + _options_ptr->maxNumPoints;
-    std::nth_element(new_points.begin(), nth, new_points.end(),
-                     [](const ScenePointPointer& a, const ScenePointPointer& b) { return a->saliency > b->saliency; });
-    new_points.erase(nth, new_points.end());
+  lap(3);
+  if (cands.size() > (size_t)_options_ptr->maxNumPoints) {
+    auto nth = cands.begin() + _options_ptr->maxNumPoints;
+    std::nth_element(cands.begin(), nth, cands.end(), [](const Candidate& a, const Candidate& b) { return a.saliency > b.saliency; });
+    cands.erase(nth, cands.end());
+  }
+  new_points.resize(cands.size());
+#pragma omp parallel for schedule(static) num_threads(nt)
+  for (int k = 0; k < (int)cands.size(); ++k) {
+    const int x = cands[k].x, y = cands[k].y;
+    const float z = Z_ptr[(size_t)y * cols + x];
+    const Vec3 ray = _K_inv * MakeVec3((double)x, (double)y, 1.0);
+    const Vec3 X = TransformPoint(T_w, MakeVec3((double)z * ray[0], (double)z * ray[1], (double)z * ray[2]));
+    ScenePointPointer p(new ScenePoint(X, _frame_id));
+    p->patch.set(I, (double)x, (double)y);
+    p->descriptor.resize(patch_length);
+    p->saliency = cands[k].saliency;
+    p->x0 = x; p->y0 = y;
+    new_points[k] = std::move(p);
   }
   std::fprintf(stderr, "updated %d [%0.2f%%] max %d new %d\n", num_updated,
                _scene_points.empty() ? 0.0 : 100.0 * num_updated / _scene_points.size(), max_num_to_update, (int)new_points.size());
@@ -326,11 +380,20 @@ void PhotometricBundleAdjustment::addFrame(const uint8_t* I_ptr, const float* Z_
 
   if ((int)_frame_buffer.size() == window) _frame_buffer.erase(_frame_buffer.begin());
   _frame_buffer.push_back(std::move(frame));
+  lap(4);
+  const double t_front = wall_ms();
   if ((int)_frame_buffer.size() == window) optimize(result);
+  if (_options_ptr->verbose)
+    std::fprintf(stderr, "addFrame %.2f ms (front-end %.2f ms, optimize %.2f ms)  [frame+upload %.2f, visibility %.2f, saliency %.2f, "
+                 "candidates %.2f, top-N+descriptors %.2f]  (float plane %.2f)\n", wall_ms() - t_enter, t_front - t_enter, wall_ms() - t_front,
+                 t_ph[0] + t_ph[5], t_ph[1], t_ph[2], t_ph[3], t_ph[4], t_ph[5]);
   ++_frame_id;
 }
 
 void PhotometricBundleAdjustment::optimize(Result* result) {
+  double t_o[6] = {0, 0, 0, 0, 0, 0};
+  double t_lo = wall_ms();
+  auto lap_o = [&](int k) { const double t = wall_ms(); t_o[k] += t - t_lo; t_lo = t; };
   const uint32_t frame_id_start = _frame_buffer.front()->id, frame_id_end = _frame_buffer.back()->id;
   const int window = _options_ptr->slidingWindowSize;
   const std::vector<double> patch_weights = MakePatchWeights(_options_ptr->patchRadius, _options_ptr->doGaussianWeighting);
@@ -345,33 +408,44 @@ void PhotometricBundleAdjustment::optimize(Result* result) {
   std::vector<ScenePoint*> selected;
   std::vector<double> xyz, desc;
   std::vector<int32_t> obs_point, obs_slot;
+  selected.reserve(_scene_points.size());
+  xyz.reserve(3 * _scene_points.size());
+  desc.reserve((size_t)P * _scene_points.size());
+  obs_point.reserve((size_t)window * _scene_points.size());
+  obs_slot.reserve((size_t)window * _scene_points.size());
   for (auto& pt : _scene_points) {
     if (pt->numFrames() >= 3 && pt->refFrameId() >= frame_id_start) {
-      std::vector<int32_t> slots;
-      for (uint32_t id : pt->f) if (id >= frame_id_start && id <= frame_id_end) slots.push_back((int32_t)(id % window));
-      if (slots.empty()) continue;
-      std::sort(slots.begin(), slots.end());
+      int32_t slots[PBA_MAX_FRAMES];
+      int n_slots = 0;
+      for (uint32_t id : pt->f)
+        if (id >= frame_id_start && id <= frame_id_end && n_slots < PBA_MAX_FRAMES) slots[n_slots++] = (int32_t)(id % window);
+      if (n_slots == 0) continue;
+      std::sort(slots, slots + n_slots);
       pt->was_refined = true;
       const int32_t idx = (int32_t)selected.size();
       selected.push_back(pt.get());
       for (int k = 0; k < 3; ++k) xyz.push_back(pt->X[k]);
       desc.insert(desc.end(), pt->descriptor.begin(), pt->descriptor.end());
-      for (int32_t s : slots) { obs_point.push_back(idx); obs_slot.push_back(s); }
+      for (int k = 0; k < n_slots; ++k) { obs_point.push_back(idx); obs_slot.push_back(slots[k]); }
     }
   }
   std::fprintf(stderr, "Using %d points (%d residual blocks) [id start %d]\n", (int)selected.size(), (int)obs_point.size(), (int)frame_id_start);
 
+  lap_o(0);
   pba_solver_summary summary;
   std::memset(&summary, 0, sizeof(summary));
   std::vector<pba_iteration_summary> its(512);
   if (!selected.empty()) {
     check(_engine, pba_set_problem(_engine, (int32_t)selected.size(), xyz.data(), desc.data(), (int32_t)obs_point.size(),
                                   obs_point.data(), obs_slot.data(), patch_weights.data()), "pba_set_problem");
+    lap_o(1);
     check(_engine, pba_set_cameras(_engine, cams.data(), window, (int32_t)(frame_id_start % window)), "pba_set_cameras");
+    lap_o(2);
     pba_solver_options so;
     pba_default_solver_options(&so);     // GetSolverOptions (:738-761)
     so.verbose = _options_ptr->verbose ? 1 : 0;
     check(_engine, pba_solve(_engine, &so, &summary, its.data(), (int32_t)its.size()), "pba_solve");
+    lap_o(3);
     if (_options_ptr->verbose)
       std::printf("pba_solve: %s  initial %.6e  final %.6e  iterations %d (successful %d)  %.3f s\n", summary.message,
                   summary.initial_cost, summary.final_cost, summary.num_iterations, summary.num_successful_steps,
@@ -386,8 +460,13 @@ void PhotometricBundleAdjustment::optimize(Result* result) {
   }
   (void)P;
 
+  lap_o(4);
   auto points_to_remove = removePointsAtFrame(frame_id_start);
   std::printf("removing %zu old points\n", points_to_remove.size());
+  lap_o(5);
+  if (_options_ptr->verbose)
+    std::fprintf(stderr, "optimize phases ms: assemble %.2f, set_problem %.2f, set_cameras %.2f, solve %.2f, read-back %.2f, evict %.2f\n",
+                 t_o[0], t_o[1], t_o[2], t_o[3], t_o[4], t_o[5]);
 
   if (result) {
     result->poses = _trajectory.poses();
