@@ -49,6 +49,8 @@ def main():
     ap.add_argument("--radius", type=int, default=2)
     ap.add_argument("--huber", type=float, default=0.0)
     ap.add_argument("--visibility", choices=("dense", "causal"), default="dense")
+    ap.add_argument("--precision", choices=("exact", "fp32", "bf16"), default="exact",
+                    help="sampler precision (configs[4] tolerance sweep); only \"exact\" has reference parity")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-points", type=int, default=50000, help="points of the bounded CPU-baseline sample")
     ap.add_argument("--cpu-steps", type=int, default=20)
@@ -73,7 +75,7 @@ def main():
 
     # ---- synthetic window: identical frames/cameras on every rank, rank-specific points ----------------------
     t0 = time.time()
-    default_shape = (args.frames, args.points, args.radius, args.huber, args.visibility) == (8, 50000, 2, 0.0, "dense")
+    default_shape = (args.frames, args.points, args.radius, args.huber, args.visibility, args.precision) == (8, 50000, 2, 0.0, "dense", "exact")
     prob = synthetic.make_window(n_frames=args.frames, n_points=args.points, radius=args.radius, huber=args.huber,
                                  visibility=args.visibility, point_seed_offset=rank)
     t_gen = time.time() - t0
@@ -82,7 +84,7 @@ def main():
     n_obs_local = prob.n_obs
     n_bar = n_obs_local / prob.n_points
 
-    eng = Engine(rows, cols, prob.K, prob.radius, prob.n_frames, huber=prob.huber, device=local_rank)
+    eng = Engine(rows, cols, prob.K, prob.radius, prob.n_frames, huber=prob.huber, device=local_rank, precision=args.precision)
     eng.load(prob)
     transport = "RCCL all-reduce of the reduced camera system"
     if world > 1:
@@ -221,6 +223,7 @@ def main():
                                % ("configs[1]: " if default_shape else "", prob.n_frames, prob.n_points, 2 * prob.radius + 1,
                                   2 * prob.radius + 1, args.visibility),
                    "image": "%dx%d u8" % (cols, rows), "observations": int(n_obs_global), "huber": prob.huber,
+                   "sampler_precision": args.precision,
                    "parallelism": "points sharded x%d, cameras+frames replicated, %s" % (world, transport)},
         "iters_per_sec": iters_per_sec, "residuals_per_sec": residuals_per_sec,
         "lm": {"iterations": iters_done, "successful": res["num_successful_steps"] - 1, "jacobian_passes": n_jac,

@@ -57,7 +57,11 @@ typedef struct pba_config {
   double fx, fy, cx, cy;     /* pinhole intrinsics */
   double huber;              /* Options::robustThreshold; <= 0 disables the loss (photobundle.cc:797-798) */
   int32_t device;            /* HIP device ordinal */
-  int32_t flags;             /* bit 0: keep a copy of the reduced system for pba_get_reduced_system (test hook) */
+  int32_t flags;             /* bit 0: keep a copy of the reduced system for pba_get_reduced_system (test hook);
+                              * bits 1-2: sampler precision for the BASELINE configs[4] tolerance sweep: 0 = exact
+                              * restatement of sample_eigen.h:82-101 (default, the only mode with reference parity),
+                              * 1 = fp32 interpolation and accumulation, 2 = fp32 with bf16-rounded residual/gradient
+                              * operands.  Modes 1-2 need unit patch weights. */
 } pba_config;
 
 /* ceres::Solver::Options as configured by GetSolverOptions (photobundle.cc:738-761) + the Ceres defaults

@@ -187,6 +187,7 @@ void launch_schur(pba_engine* e, const SchurParams& sp) {
 SampleParams make_sample_params(pba_engine* e, int which_point) {
   const int which_out = which_point;
   SampleParams sp{};
+  sp.prec = (e->cfg.flags >> 1) & 3;
   sp.frames = e->d_frames;
   sp.geom = e->d_geom[which_point];
   sp.xyz = e->d_xyz[which_point];

@@ -518,6 +518,7 @@ struct SampleParams {
   double* block_cost_alt;     // the other parity's block arrays
   int32_t* block_fail_alt;
   int32_t decide;             // run lm_decide in the last workgroup (single rank)
+  int32_t prec;               // 0: reference-exact sampler (default); 1: fp32 walk; 2: fp32 walk with bf16 operands (sweep)
   double* xchg;               // multi-rank: exchange buffer of the step scalars, packed by the last workgroup
   int32_t xchg_rank, xchg_world;
   unsigned long long* dbg;    // optional [gridDim.x][8] per-phase cycle stamps of thread 0 (diagnostics)
@@ -735,7 +736,61 @@ __global__ __launch_bounds__(WAVES * 64, (R <= 2 ? (JAC ? 3 : 2) : 1)) void k_sa
   double m11 = 0, m12 = 0, m22 = 0, b1 = 0, b2 = 0, cc = 0;
   if (active) {
     const float* p0 = p.desc + (size_t)pt * (W * W);
-    if (regular) {
+    if (regular && UNITW && p.prec != 0) {
+      // ---- reduced-precision walk (opt-in, BASELINE configs[4] tolerance sweep; NOT bit-compatible with the reference):
+      //   prec 1: fp32 interpolation and fp32 accumulation of M, b, c;  prec 2: additionally the residual and the
+      //   gradients are rounded to bf16 before they enter the (fp32) accumulation.
+      float dxs[W], dys[W];
+#pragma unroll
+      for (int j = 0; j < W; ++j) { dxs[j] = (float)(bx + j + 1) - xf[j]; dys[j] = (float)(by + j + 1) - yf[j]; }
+      constexpr int NPL = JAC ? 3 : 1;
+      float Hp[NPL][W], Hc[NPL][W];
+      float a11 = 0.f, a12 = 0.f, a22 = 0.f, c1 = 0.f, c2 = 0.f, c0 = 0.f;
+      const bool bf16 = p.prec == 2;
+      auto rnd = [&](float v) {      // round-to-nearest-even to 8 significant bits (bf16), only in the sweep's third mode
+        if (!bf16) return v;
+        unsigned u = __float_as_uint(v);
+        u += 0x7fffu + ((u >> 16) & 1u);
+        return __uint_as_float(u & 0xffff0000u);
+      };
+#pragma unroll
+      for (int r = 0; r < F; ++r) {
+        uint32_t t[F];
+#pragma unroll
+        for (int c = 0; c < F; ++c) t[c] = s_tex[wave][(r * F + c) * LSTRIDE + lane];
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+          const float om = 1.0f - dxs[j];
+          Hc[0][j] = fmaf(dxs[j], tex_I(t[j]), om * tex_I(t[j + 1]));
+          if (JAC) {
+            Hc[1][j] = fmaf(dxs[j], tex_gx2(t[j]), om * tex_gx2(t[j + 1]));
+            Hc[2][j] = fmaf(dxs[j], tex_gy2(t[j]), om * tex_gy2(t[j + 1]));
+          }
+        }
+        if (r >= 1) {
+          const int i = r - 1;
+          const float dy = dys[i], omdy = 1.0f - dy;
+#pragma unroll
+          for (int j = 0; j < W; ++j) {
+            const float sI = fmaf(dy, Hp[0][j], omdy * Hc[0][j]);
+            const float e = rnd(p0[i * W + j] - sI);
+            c0 = fmaf(e, e, c0);
+            if (JAC) {
+              const float gx = rnd(fmaf(dy, Hp[1][j], omdy * Hc[1][j]));
+              const float gy = rnd(fmaf(dy, Hp[2][j], omdy * Hc[2][j]));
+              a11 = fmaf(gx, gx, a11); a12 = fmaf(gx, gy, a12); a22 = fmaf(gy, gy, a22);
+              c1 = fmaf(gx, e, c1); c2 = fmaf(gy, e, c2);
+            }
+          }
+        }
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+          for (int j = 0; j < W; ++j) Hp[pl][j] = Hc[pl][j];
+      }
+      cc = (double)c0;
+      if (JAC) { m11 = 0.25 * (double)a11; m12 = 0.25 * (double)a12; m22 = 0.25 * (double)a22; b1 = 0.5 * (double)c1; b2 = 0.5 * (double)c2; }
+    } else if (regular) {
       float dxs[W], dys[W];
       double omdx[W];
 #pragma unroll

@@ -29,14 +29,15 @@ def _ptr(a):
 class Engine:
     """One engine = one GPU = one shard of points (all cameras and frames replicated)."""
 
-    def __init__(self, rows, cols, K, radius, max_frames, huber=0.0, device=0, keep_reduced_system=False):
+    def __init__(self, rows, cols, K, radius, max_frames, huber=0.0, device=0, keep_reduced_system=False, precision="exact"):
         self._L = _lib.lib()
         cfg = _lib.Config()
         cfg.rows, cfg.cols, cfg.max_frames, cfg.radius = int(rows), int(cols), int(max_frames), int(radius)
         cfg.fx, cfg.fy, cfg.cx, cfg.cy = [float(v) for v in K]
         cfg.huber = float(huber)
         cfg.device = int(device)
-        cfg.flags = 1 if keep_reduced_system else 0
+        # precision: "exact" (reference-exact sampler, default) | "fp32" | "bf16" (configs[4] tolerance sweep, include/pba.h)
+        cfg.flags = (1 if keep_reduced_system else 0) | ({"exact": 0, "fp32": 1, "bf16": 2}[precision] << 1)
         self._h = C.c_void_p()
         rc = self._L.pba_create(C.byref(cfg), C.byref(self._h))
         if rc != 0:
