@@ -1,6 +1,8 @@
 // photobundle_pyramid.cc -- see photobundle_pyramid.h
 #include "photobundle_pyramid.h"
 
+#include <ctime>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -14,12 +16,16 @@ inline int reflect101(int i, int n) {
 }
 }  // namespace
 
+// rows are independent in both passes: a few host threads (integer / per-pixel arithmetic, results unchanged)
+constexpr int kPyrThreads = 4;
+
 void pyrDownU8(const uint8_t* src, int rows, int cols, std::vector<uint8_t>& dst) {
   const int drows = (rows + 1) / 2, dcols = (cols + 1) / 2;
   dst.assign((size_t)drows * dcols, 0);
   static const int w[5] = {1, 4, 6, 4, 1};
   std::vector<int> hrow((size_t)dcols);
   std::vector<int> hbuf((size_t)rows * dcols);
+#pragma omp parallel for schedule(static) num_threads(kPyrThreads)
   for (int y = 0; y < rows; ++y) {           // horizontal pass at the even columns, integer sums
     const uint8_t* s = src + (size_t)y * cols;
     for (int x = 0; x < dcols; ++x) {
@@ -28,6 +34,7 @@ void pyrDownU8(const uint8_t* src, int rows, int cols, std::vector<uint8_t>& dst
       hbuf[(size_t)y * dcols + x] = acc;
     }
   }
+#pragma omp parallel for schedule(static) num_threads(kPyrThreads)
   for (int y = 0; y < drows; ++y) {
     for (int x = 0; x < dcols; ++x) {
       int acc = 0;
@@ -50,6 +57,7 @@ void resizeBilinearF32(const float* src, int rows, int cols, int drows, int dcol
     if (ix >= cols - 1) { fx = 0.f; ix = cols - 1; }
     sx[dx] = ix; ax[dx] = fx;
   }
+#pragma omp parallel for schedule(static) num_threads(kPyrThreads)
   for (int dy = 0; dy < drows; ++dy) {
     float fy = (float)((dy + 0.5) * scale_y - 0.5);
     int iy = (int)std::floor(fy);
@@ -88,12 +96,16 @@ PhotometricBundleAdjustmentPyr::~PhotometricBundleAdjustmentPyr() {}
 
 void PhotometricBundleAdjustmentPyr::addFrame(const uint8_t* image, const float* depth, const Mat44& T, Result* result) {
   const int n = (int)_pyr.size();
+  timespec ts0, ts1;
+  clock_gettime(CLOCK_MONOTONIC, &ts0);
   _im_pyr[0].assign(image, image + (size_t)_rows * _cols);
   _z_pyr[0].assign(depth, depth + (size_t)_rows * _cols);
   for (int i = 1; i < n; ++i) {
     pyrDownU8(_im_pyr[i - 1].data(), _sizes[i - 1].rows, _sizes[i - 1].cols, _im_pyr[i]);
     resizeBilinearF32(_z_pyr[i - 1].data(), _sizes[i - 1].rows, _sizes[i - 1].cols, _sizes[i].rows, _sizes[i].cols, _z_pyr[i]);
   }
+  clock_gettime(CLOCK_MONOTONIC, &ts1);
+  std::fprintf(stderr, "pyramid build %.2f ms (%d levels)\n", 1e3 * (double)(ts1.tv_sec - ts0.tv_sec) + 1e-6 * (double)(ts1.tv_nsec - ts0.tv_nsec), n);
   Mat44 T_init(T);
   Result last;
   for (int i = n - 1; i >= 0; --i) {

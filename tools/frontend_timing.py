@@ -10,12 +10,13 @@ from test_gpu_dropin_class import _write_sequence, RUN
 n_frames = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 window = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 max_points = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
+levels = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 tmp = tempfile.mkdtemp()
 _write_sequence(tmp, n_frames, synthetic.KITTI_SIZE, synthetic.KITTI_K)
 cfg = os.path.join(tmp, "t.cfg")
 with open(cfg, "w") as f:
     f.write("DataDirectory = %s\nTrajectory = %s/init.txt\nmaxNumPoints = %d\nslidingWindowSize = %d\npatchRadius = 2\n"
-            "minScore = 0.65\nrobustThreshold = 0.05\nverbose = 1\n" % (tmp, tmp, max_points, window))
+            "minScore = 0.65\nrobustThreshold = 0.05\nverbose = 1\nnumLevels = %d\n" % (tmp, tmp, max_points, window, levels))
 t = time.perf_counter()
 r = subprocess.run([RUN, "-c", cfg, "-o", os.path.join(tmp, "out.txt")], capture_output=True, text=True, timeout=1200)
 wall = time.perf_counter() - t
@@ -38,3 +39,6 @@ for line in r.stderr.splitlines():
 for line in r.stderr.splitlines():
     if line.startswith("optimize phases"):
         print(line)
+pb = re.findall(r"pyramid build ([0-9.]+) ms", r.stderr)
+if pb:
+    print("pyramid build mean %.2f ms per frame (%d levels); addFrame lines above are per LEVEL" % (np.mean([float(v) for v in pb[2:]]), levels))
