@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <unordered_map>
 #include <string>
 #include <vector>
 
@@ -99,6 +100,7 @@ struct pba_engine {
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   bool ev_used[3] = {false, false, false};
   pba_counters ctr{};
+  std::unordered_map<void*, size_t> dev_cap;   // capacity in bytes of every dev_alloc'ed buffer, keyed by its owner field
 };
 
 namespace {
@@ -119,11 +121,19 @@ int fail(pba_engine* e, int code, const char* fmt, ...) {
     if (_r != hipSuccess) return fail((e), PBA_ERR_HIP, "%s: %s", #call, hipGetErrorString(_r)); \
   } while (0)
 
+// Grow-only device buffers: a sliding-window caller re-submits a problem of similar size for every frame, and a
+// hipFree + hipMalloc pair per buffer per frame is pure overhead.  Contents are undefined after the call (every user
+// overwrites or uploads the whole buffer).
 template <class T>
 int dev_alloc(pba_engine* e, T** p, size_t n) {
-  if (*p) { (void)hipFree(*p); *p = nullptr; }
   if (n == 0) n = 1;
-  HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(p), n * sizeof(T)));
+  const size_t bytes = n * sizeof(T);
+  auto it = e->dev_cap.find(static_cast<void*>(p));
+  if (*p && it != e->dev_cap.end() && it->second >= bytes) return PBA_OK;
+  if (*p) { (void)hipFree(*p); *p = nullptr; }
+  const size_t want = bytes + bytes / 8;            // a little headroom against frame-to-frame jitter
+  HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(p), want));
+  e->dev_cap[static_cast<void*>(p)] = want;
   return PBA_OK;
 }
 template <class T>
