@@ -88,16 +88,22 @@ def main():
     eng.load(prob)
     transport = "RCCL all-reduce of the reduced camera system"
     if world > 1:
-        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        uid = torch.zeros(129, dtype=torch.uint8, device="cuda")     # 128-byte ncclUniqueId + "valid" byte
         if rank == 0:
-            uid.copy_(torch.frombuffer(bytearray(Engine.comm_unique_id()), dtype=torch.uint8))
+            try:
+                raw = bytearray(Engine.comm_unique_id()) + bytearray([1])
+                uid.copy_(torch.frombuffer(raw, dtype=torch.uint8))
+            except Exception as exc:
+                print("rank 0: no RCCL unique id (%s)" % exc, file=sys.stderr)
         dist.broadcast(uid, 0)
-        rccl_ok = 1
-        try:
-            eng.comm_init_rccl(bytes(uid.cpu().numpy().tobytes()), rank, world)
-        except Exception as exc:     # keep the multi-GPU line alive: host-staged all-reduce through torch.distributed
-            print("rank %d: RCCL transport unavailable (%s), falling back to the host-staged transport" % (rank, exc), file=sys.stderr)
-            rccl_ok = 0
+        uid_host = uid.cpu().numpy()
+        rccl_ok = int(uid_host[128])
+        if rccl_ok:
+            try:
+                eng.comm_init_rccl(bytes(uid_host[:128].tobytes()), rank, world)
+            except Exception as exc:     # keep the multi-GPU line alive: host-staged all-reduce through torch.distributed
+                print("rank %d: RCCL transport unavailable (%s), falling back to the host-staged transport" % (rank, exc), file=sys.stderr)
+                rccl_ok = 0
         flag = torch.tensor([rccl_ok], dtype=torch.int32, device="cuda")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0:
@@ -108,7 +114,8 @@ def main():
                 a[:] = t.cpu().numpy()
             if rccl_ok:          # mixed outcome: rebuild the engine so that every rank uses the same transport
                 eng.close()
-                eng = Engine(rows, cols, prob.K, prob.radius, prob.n_frames, huber=prob.huber, device=local_rank)
+                eng = Engine(rows, cols, prob.K, prob.radius, prob.n_frames, huber=prob.huber, device=local_rank,
+                             precision=args.precision)
                 eng.load(prob)
             eng.comm_init_callback(_allreduce, rank, world)
     elif os.environ.get("PBA_FORCE_MULTI") == "1":
