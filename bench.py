@@ -64,11 +64,20 @@ def main():
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
+    # PBA_BENCH_BACKEND=gloo is a test hook: N ranks sharing the GPUs that exist (RCCL refuses duplicate devices, so
+    # this exercises the host-staged fallback and the rest of the multi-rank logic on a 1-GPU box)
+    backend = os.environ.get("PBA_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
+    ctl = "cuda" if backend == "nccl" else "cpu"       # device of the control-plane tensors
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from photobundle_amd import synthetic
     from photobundle_amd.engine import Engine, default_solver_options
@@ -88,7 +97,7 @@ def main():
     eng.load(prob)
     transport = "RCCL all-reduce of the reduced camera system"
     if world > 1:
-        uid = torch.zeros(129, dtype=torch.uint8, device="cuda")     # 128-byte ncclUniqueId + "valid" byte
+        uid = torch.zeros(129, dtype=torch.uint8, device=ctl)     # 128-byte ncclUniqueId + "valid" byte
         if rank == 0:
             try:
                 raw = bytearray(Engine.comm_unique_id()) + bytearray([1])
@@ -104,12 +113,12 @@ def main():
             except Exception as exc:     # keep the multi-GPU line alive: host-staged all-reduce through torch.distributed
                 print("rank %d: RCCL transport unavailable (%s), falling back to the host-staged transport" % (rank, exc), file=sys.stderr)
                 rccl_ok = 0
-        flag = torch.tensor([rccl_ok], dtype=torch.int32, device="cuda")
+        flag = torch.tensor([rccl_ok], dtype=torch.int32, device=ctl)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0:
             transport = "host-staged all-reduce via torch.distributed (RCCL init failed)"
             def _allreduce(a, op):
-                t = torch.from_numpy(a.copy()).cuda()
+                t = torch.from_numpy(a.copy()).to(ctl)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX if op == 1 else dist.ReduceOp.SUM)
                 a[:] = t.cpu().numpy()
             if rccl_ok:          # mixed outcome: rebuild the engine so that every rank uses the same transport
@@ -146,7 +155,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t1
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=ctl)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     # PCIe-inclusive variant (never `value`): the C-ABI receives HOST buffers, so a cold window also pays the upload of
