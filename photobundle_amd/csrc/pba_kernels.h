@@ -72,6 +72,14 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// Orders the LDS traffic of ONE wave (its LDS operations execute in order; this only stops the compiler from moving
+// them): used where a single wave exchanges data with itself through LDS.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // =====================================================================================================
 // frames
 // =====================================================================================================
@@ -729,7 +737,8 @@ __global__ __launch_bounds__(WAVES * 64, (R <= 2 ? (JAC ? 3 : 2) : 1)) void k_sa
       }
     }
   }
-  lds_barrier();
+  // every wave staged its OWN 64 footprints and walks only those: no workgroup barrier, the waves drift apart freely
+  wave_lds_sync();
 
   PBA_STK(3);
   // ---- phase 3: per-lane patch walk ------------------------------------------------------------------------
@@ -1580,14 +1589,6 @@ __device__ __forceinline__ void solve_epilogue(const SolveParams& p, int n, cons
 // left-looking, software-pipelined factorisation described at k_solve_wave2 (same algorithm, one wave: the exchange
 // through LDS needs no barrier, only the compiler-level ordering of wave_lds_sync).  The right-hand side is folded in
 // one step behind; the backward sweep uses v_readlane.  The other three waves only help with the prologue / epilogue.
-// Orders the LDS traffic of ONE wave (its LDS operations execute in order; this only stops the compiler from moving
-// them): used where a single wave exchanges data with itself through LDS.
-__device__ __forceinline__ void wave_lds_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 template <int NF>
 __global__ __launch_bounds__(256) void k_solve_wave(SolveParams p_in) {
   SolveParams p = p_in;
