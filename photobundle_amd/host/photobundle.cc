@@ -272,6 +272,7 @@ void PhotometricBundleAdjustment::addFrame(const uint8_t* I_ptr, const float* Z_
   // ---- visibility list update (reference :505-542) ------------------------------------------------------------
   std::fill(_mask.d.begin(), _mask.d.end(), (uint16_t)1);
   int num_updated = 0, max_num_to_update = 0;
+  double t_vis_par = 0.0; int n_vis = 0;
   {
     // the ZNCC test of every tracked point is independent: evaluated on all host threads, applied in list order
     const int n_sp = (int)_scene_points.size();
@@ -291,6 +292,8 @@ void PhotometricBundleAdjustment::addFrame(const uint8_t* I_ptr, const float* Z_
         if (pt.patch.score(other) > _options_ptr->minScore) { hit_r[k] = r; hit_c[k] = c; }
       }
     }
+    t_vis_par = wall_ms() - t_last;
+    n_vis = n_sp;
     for (int k = 0; k < n_sp; ++k) {
       max_num_to_update += tried[k];
       if (hit_r[k] < 0) continue;
@@ -385,8 +388,8 @@ void PhotometricBundleAdjustment::addFrame(const uint8_t* I_ptr, const float* Z_
   if ((int)_frame_buffer.size() == window) optimize(result);
   if (_options_ptr->verbose)
     std::fprintf(stderr, "addFrame %.2f ms (front-end %.2f ms, optimize %.2f ms)  [frame+upload %.2f, visibility %.2f, saliency %.2f, "
-                 "candidates %.2f, top-N+descriptors %.2f]  (float plane %.2f)\n", wall_ms() - t_enter, t_front - t_enter, wall_ms() - t_front,
-                 t_ph[0] + t_ph[5], t_ph[1], t_ph[2], t_ph[3], t_ph[4], t_ph[5]);
+                 "candidates %.2f, top-N+descriptors %.2f]  (float plane %.2f, visibility parallel part %.2f of %d points, %d tried)\n", wall_ms() - t_enter, t_front - t_enter, wall_ms() - t_front,
+                 t_ph[0] + t_ph[5], t_ph[1], t_ph[2], t_ph[3], t_ph[4], t_ph[5], t_vis_par, n_vis, max_num_to_update);
   ++_frame_id;
 }
 
