@@ -77,8 +77,9 @@ def test_linearisation_and_reduced_system(radius, huber, gaussian, vis):
         cams_g, xyz_g = e.get_state()
         assert np.abs(cams_g - cams_c).max() <= 1e-7 * max(1.0, np.abs(ref["delta"][:n_cam]).max())
         assert np.abs(xyz_g - xyz_c).max() <= 1e-6 * max(1.0, np.abs(ref["delta"][n_cam:]).max())
-        # the cost pass and the Jacobian pass agree bit for bit at the same point
-        assert e.linearize() == info["candidate_cost"]
+        # the candidate pass and a fresh linearisation at the same point agree: bit for bit per observation; the total
+        # may differ in the last place when the two passes ran on different workgroup grids (PBA_SPECULATE=0 / PBA_FUSE=0)
+        assert np.isclose(e.linearize(), info["candidate_cost"], rtol=1e-14, atol=0.0)
         c_here, _ = oracle.cost(p, cams=cams_g, xyz=xyz_g)
         assert np.isclose(info["candidate_cost"], c_here, rtol=1e-12)
 
