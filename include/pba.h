@@ -160,7 +160,12 @@ int pba_set_frame_u8(pba_engine* e, int slot, const uint8_t* image);
 /* Debug/test readback of the device planes as float I, Gx, Gy (each rows*cols). */
 int pba_get_frame_planes(pba_engine* e, int slot, float* I, float* Gx, float* Gy);
 
-/* ---- problem: replaces the AddResidualBlock loop (photobundle.cc:786-806) ------------------------------- */
+/* ---- problem: replaces the AddResidualBlock loop (photobundle.cc:786-806) -------------------------------
+ * Call order: pba_set_frame_u8 (every slot the observation list uses), pba_set_problem and pba_set_cameras may come in
+ * any order, all three before pba_linearize / pba_solve; a pass that finds one of them missing, an observation whose
+ * slot is >= n_frames, or a slot without an uploaded frame returns PBA_ERR_STATE (nothing is launched).
+ * Limit: at most 15 FREE cameras (n_frames - 1 with a constant camera, i.e. 16 window slots need fixed_slot >= 0);
+ * pba_set_cameras returns PBA_ERR_INVALID beyond that. */
 int pba_set_problem(pba_engine* e, int32_t n_points, const double* xyz, const double* desc,
                     int32_t n_obs, const int32_t* obs_point, const int32_t* obs_slot, const double* weights);
 /* cams6: [n_frames][6]; fixed_slot: SetParameterBlockConstant (photobundle.cc:809-813), -1 for none. */

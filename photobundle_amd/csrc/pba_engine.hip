@@ -9,6 +9,7 @@
 #include "pba_kernels.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -32,6 +33,7 @@ struct pba_engine {
   hipEvent_t ev_img_stage = nullptr;
   bool img_stage_busy = false;
   std::vector<uint8_t> frame_set;
+  uint32_t slot_mask = 0;           // window slots referenced by the observation list
 
   // problem
   int n_points = 0, n_obs = 0, n_frames = 0, fixed_slot = -1, n_free = 0;
@@ -85,9 +87,9 @@ struct pba_engine {
   pba_iteration_summary* h_log_dev = nullptr;
   pba_iteration_summary* d_log = nullptr;      // device iteration log of the asynchronous driver (flushed at the end)
   static constexpr int kMaxLog = 1024;
-  bool async_on = false;
   int async_cur = 0;                // parity assumed at enqueue time
   bool use_async = true;            // PBA_ASYNC=0 disables
+  double wait_timeout_s = 120.0;    // PBA_WAIT_TIMEOUT_S: watchdog of the publication waits
   unsigned long long* d_dbg = nullptr;   // PBA_SCHUR_TIMING diagnostics
   int dbg_left = 0;
   int n_pairs = 0, part_stride = 0;
@@ -104,6 +106,8 @@ struct pba_engine {
 };
 
 namespace {
+
+double wall_seconds() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 int fail(pba_engine* e, int code, const char* fmt, ...) {
   char buf[512];
@@ -138,6 +142,18 @@ int dev_alloc(pba_engine* e, T** p, size_t n) {
 }
 template <class T>
 void dev_free(T** p) { if (*p) { (void)hipFree(*p); *p = nullptr; } }
+
+// Call-order / consistency check before any pass touches the device (include/pba.h: PBA_ERR_STATE).
+int check_ready(pba_engine* e, const char* who) {
+  if (!e->have_problem || !e->have_cams)
+    return fail(e, PBA_ERR_STATE, "call order violated: %s before set_problem/set_cameras", who);
+  for (int s = 0; s < kMaxFrames; ++s) {
+    if (!((e->slot_mask >> s) & 1u)) continue;
+    if (s >= e->n_frames) return fail(e, PBA_ERR_STATE, "call order violated: an observation uses slot %d but only %d cameras are set", s, e->n_frames);
+    if (!e->frame_set[s]) return fail(e, PBA_ERR_STATE, "call order violated: an observation uses slot %d but no frame was uploaded to it", s);
+  }
+  return PBA_OK;
+}
 
 template <int R, bool JAC, bool FUSED>
 void launch_sample_r(pba_engine* e, const SampleParams& sp) {
@@ -220,7 +236,7 @@ SampleParams make_sample_params(pba_engine* e, int which_point) {
 
 // ONE sum all-reduce for the step scalars of all ranks (sum group + rank-slotted max group, see k_xchg_pack)
 int ensure_xchg(pba_engine* e) {
-  if (e->d_xchg) return PBA_OK;
+  // grow-only and cheap when large enough: a transport re-initialised with a larger world must not overrun the buffer
   return dev_alloc(e, &e->d_xchg, (size_t)kSumBCount + (size_t)kMaxCount * e->comm.world);
 }
 
@@ -329,6 +345,7 @@ int pba_create(const pba_config* cfg, pba_engine** out) {
   if (const char* sv = getenv("PBA_SPECULATE")) e->speculate = atoi(sv) != 0;
   if (const char* sv = getenv("PBA_FUSE")) e->fuse = atoi(sv) != 0;
   if (const char* sv = getenv("PBA_ASYNC")) e->use_async = atoi(sv) != 0;
+  if (const char* sv = getenv("PBA_WAIT_TIMEOUT_S")) { const double v = atof(sv); if (v > 0.0) e->wait_timeout_s = v; }
   if ((rc = dev_alloc(e, &e->d_lm, (size_t)1))) return bail(rc);
   if (hipHostMalloc(reinterpret_cast<void**>(&e->h_lm), sizeof(LmState), hipHostMallocMapped) != hipSuccess) return bail(PBA_ERR_HIP);
   if (hipHostGetDevicePointer(reinterpret_cast<void**>(&e->h_lm_dev), e->h_lm, 0) != hipSuccess) return bail(PBA_ERR_HIP);
@@ -488,7 +505,9 @@ int pba_set_problem(pba_engine* e, int32_t n_points, const double* xyz, const do
   if ((rc = dev_alloc(e, &e->d_bs_out, (size_t)3 * std::max(e->backsub_grid, e->fused_grid)))) return rc;
   e->schur_grid = std::min(e->n_tiles, 256 * 4);
 
-  HIP_TRY(e, hipMemcpyAsync(e->d_xyz[0], xyz, sizeof(double) * 3 * n_points, hipMemcpyHostToDevice, e->stream));
+  // the points go to the CURRENT parity: the cameras of an earlier pba_set_cameras live there too, so the two calls may
+  // come in either order
+  HIP_TRY(e, hipMemcpyAsync(e->d_xyz[e->cur], xyz, sizeof(double) * 3 * n_points, hipMemcpyHostToDevice, e->stream));
   HIP_TRY(e, hipMemcpyAsync(e->d_desc, descf.data(), sizeof(float) * descf.size(), hipMemcpyHostToDevice, e->stream));
   HIP_TRY(e, hipMemcpyAsync(e->d_w2, w2.data(), sizeof(double) * P, hipMemcpyHostToDevice, e->stream));
   HIP_TRY(e, hipMemcpyAsync(e->d_obs_point, obs_point, sizeof(int32_t) * n_obs, hipMemcpyHostToDevice, e->stream));
@@ -498,7 +517,8 @@ int pba_set_problem(pba_engine* e, int32_t n_points, const double* xyz, const do
   HIP_TRY(e, hipMemcpyAsync(e->d_obs_l0, obs_l0.data(), n_obs, hipMemcpyHostToDevice, e->stream));
   HIP_TRY(e, hipMemcpyAsync(e->d_obs_cnt, obs_cnt.data(), n_obs, hipMemcpyHostToDevice, e->stream));
   HIP_TRY(e, hipStreamSynchronize(e->stream));
-  e->cur = 0;
+  e->slot_mask = 0;
+  for (int o = 0; o < n_obs; ++o) e->slot_mask |= 1u << slot8[o];
   e->have_problem = true;
   e->have_lin = false;
   e->lin_valid[0] = e->lin_valid[1] = false;
@@ -540,7 +560,7 @@ int pba_get_state(pba_engine* e, double* cams6, double* xyz) {
 
 int pba_linearize(pba_engine* e, double* cost) {
   if (!e) return PBA_ERR_INVALID;
-  if (!e->have_problem || !e->have_cams) return fail(e, PBA_ERR_STATE, "call order violated: pba_linearize before set_problem/set_cameras");
+  { const int rc0 = check_ready(e, "pba_linearize"); if (rc0) return rc0; }
   HIP_TRY(e, hipSetDevice(e->cfg.device));
   if (!e->lin_valid[e->cur]) {
     SampleParams sp = make_sample_params(e, e->cur);
@@ -748,13 +768,18 @@ int pba_internal_step(pba_engine* e, double radius, int32_t init_scale, const pb
   {
     volatile unsigned long long* h_seq = reinterpret_cast<volatile unsigned long long*>(e->h_scal + kNumScal);
     unsigned long spins = 0;
+    double t_first = -1.0;
     while (*h_seq != seq) {
       // hipStreamQuery is not free for the device (it showed up as a ~6 us bubble in front of the next kernel), so it only
-    // serves as a watchdog here: roughly every 50 ms of spinning
-    if ((++spins & 0x3ffffff) == 0) {
+      // serves as a watchdog here: roughly every 50 ms of spinning
+      if ((++spins & 0x3ffffff) == 0) {
         const hipError_t q = hipStreamQuery(e->stream);
         if (q != hipSuccess && q != hipErrorNotReady) return fail(e, PBA_ERR_HIP, "stream error while waiting: %s", hipGetErrorString(q));
         if (q == hipSuccess && *h_seq != seq) return fail(e, PBA_ERR_HIP, "step finished without publishing its scalars");
+        const double t = wall_seconds();
+        if (t_first < 0.0) t_first = t;
+        else if (t - t_first > e->wait_timeout_s)
+          return fail(e, multi ? PBA_ERR_COMM : PBA_ERR_HIP, "timed out after %.0f s waiting for step %llu", e->wait_timeout_s, seq);
       }
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
@@ -853,7 +878,10 @@ int pba_internal_async_capable(const pba_engine* e, const pba_solver_options* o)
   return e->use_async && fused_capable(e) && e->comm.kind != 2 && o->max_num_iterations < pba_engine::kMaxLog - 2 && !e->profile;
 }
 
+int pba_internal_ready(pba_engine* e) { return check_ready(e, "pba_solve"); }
+
 int pba_internal_async_begin(pba_engine* e, const pba_solver_options* o) {
+  { const int rc0 = check_ready(e, "pba_solve"); if (rc0) return rc0; }
   HIP_TRY(e, hipSetDevice(e->cfg.device));
   LmState st;
   std::memset(&st, 0, sizeof(st));
@@ -866,7 +894,6 @@ int pba_internal_async_begin(pba_engine* e, const pba_solver_options* o) {
   *e->h_lm = st;
   // device copy of the initial state straight from the host-mapped mirror (stream ordered, no host sync)
   HIP_TRY(e, hipMemcpyAsync(e->d_lm, e->h_lm_dev, sizeof(st), hipMemcpyDeviceToDevice, e->stream));
-  e->async_on = true;
   e->async_cur = e->cur;
   return PBA_OK;
 }
@@ -973,6 +1000,7 @@ int pba_internal_async_enqueue(pba_engine* e, int kind, int init_scale, const pb
 int pba_internal_async_wait(pba_engine* e, unsigned long long seq) {
   volatile unsigned long long* h_seq = reinterpret_cast<volatile unsigned long long*>(e->h_scal + kNumScal);
   unsigned long spins = 0;
+  double t_first = -1.0;
   while (*h_seq < seq) {
     // hipStreamQuery is not free for the device (it showed up as a ~6 us bubble in front of the next kernel), so it only
     // serves as a watchdog here: roughly every 50 ms of spinning
@@ -984,6 +1012,13 @@ int pba_internal_async_wait(pba_engine* e, unsigned long long seq) {
         if (reinterpret_cast<volatile LmState*>(e->h_lm)->done) return PBA_OK;
         return fail(e, PBA_ERR_HIP, "step finished without publishing");
       }
+      // a collective that never completes (a peer died, or the ranks disagree on the number of enqueued steps) would
+      // otherwise spin forever: bounded by PBA_WAIT_TIMEOUT_S (default 120 s) of wall-clock per awaited step
+      const double t = wall_seconds();
+      if (t_first < 0.0) t_first = t;
+      else if (t - t_first > e->wait_timeout_s)
+        return fail(e, e->comm.multi() ? PBA_ERR_COMM : PBA_ERR_HIP, "timed out after %.0f s waiting for step %llu (last published %llu)",
+                    e->wait_timeout_s, seq, (unsigned long long)*h_seq);
     }
   }
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
@@ -1002,7 +1037,6 @@ int pba_internal_async_end(pba_engine* e) {
   e->cur = st.cur;
   e->lin_valid[e->cur] = true; e->lin_valid[1 - e->cur] = false;
   e->have_lin = true;
-  e->async_on = false;
   return PBA_OK;
 }
 

@@ -6,6 +6,7 @@ extern "C" {
 // grad_only != 0: stop after the reduced solve (cost / gradient norms of the linearisation point only).
 int pba_internal_step(pba_engine* e, double radius, int32_t init_scale, const pba_solver_options* o, pba_step_info* out,
                       int grad_only);
+int pba_internal_ready(pba_engine* e);   /* PBA_OK, or PBA_ERR_STATE with the reason in pba_last_error */
 int pba_internal_world(const pba_engine* e);
 int pba_internal_rank(const pba_engine* e);
 int pba_internal_is_multi(const pba_engine* e);   /* collectives are enqueued with every step */

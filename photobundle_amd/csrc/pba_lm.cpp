@@ -41,7 +41,12 @@ static int solve_async(pba_engine* e, const pba_solver_options* o, pba_solver_su
   // each sees the termination flag at a different moment: they all stop kAhead steps after the terminating one.
   const bool multi = pba_internal_is_multi(e) != 0;
   while (enq < o->max_num_iterations) {
-    if (st->done && (!multi || last_seq >= st->done_seq + kAhead)) break;
+    // done and done_seq reach the host mirror as independent 32-bit stores: act on `done` in multi-rank mode only once
+    // the (non-zero) sequence number of the terminating step is visible too
+    {
+      const unsigned long long ds = st->done_seq;
+      if (st->done && (!multi || (ds != 0 && last_seq >= ds + kAhead))) break;
+    }
     if ((rc = pba_internal_async_enqueue(e, 1, enq == 0 ? 1 : 0, o, &seq))) return rc;
     seqs[enq % (kAhead + 1)] = seq;
     last_seq = seq;
@@ -116,6 +121,7 @@ static int solve_async(pba_engine* e, const pba_solver_options* o, pba_solver_su
 extern "C" int pba_solve(pba_engine* e, const pba_solver_options* o, pba_solver_summary* sum, pba_iteration_summary* its,
                          int32_t max_out) {
   if (!e || !o || !sum) return PBA_ERR_INVALID;
+  { const int rc0 = pba_internal_ready(e); if (rc0) return rc0; }   // solve before set_problem / set_cameras: PBA_ERR_STATE
   const double t_start = now();
   std::memset(sum, 0, sizeof(*sum));
   sum->termination_type = 1;

@@ -116,3 +116,48 @@ def test_rejected_inputs(small_window_edge=None):
             e.set_cameras(p.cams[:1], 0)
     finally:
         e.close()
+
+
+def test_solve_call_order_is_checked_before_anything_is_launched():
+    """include/pba.h: PBA_ERR_STATE for a solve before set_problem / set_cameras (both drivers), for an observation whose
+    slot has no camera, and for a slot that never received a frame; the three setters may come in any order."""
+    p = synthetic.make_window(n_frames=3, n_points=20, radius=2, seed_offset=9, **SMALL)
+    o = default_solver_options(max_num_iterations=3)
+    e = Engine(120, 200, p.K, 2, 3)
+    try:
+        with pytest.raises(EngineError, match="call order"):
+            e.solve(o)                                          # nothing set
+        e.set_cameras(p.cams, 0)
+        with pytest.raises(EngineError, match="call order"):
+            e.solve(o)                                          # cameras but no problem
+        e.set_problem(p.xyz, p.desc, p.obs_point, p.obs_slot, p.weights)
+        with pytest.raises(EngineError, match="no frame"):
+            e.solve(o)                                          # frames missing
+        for s_ in range(3):
+            e.set_frame(s_, p.images[s_])
+        a = e.solve(o)                                          # cameras -> problem -> frames: fine
+        e.set_cameras(p.cams[:2], 0)
+        with pytest.raises(EngineError, match="slot 2"):
+            e.solve(o)                                          # observations of slot 2, two cameras
+    finally:
+        e.close()
+    e = Engine(120, 200, p.K, 2, 3)
+    try:
+        e.set_problem(p.xyz, p.desc, p.obs_point, p.obs_slot, p.weights)
+        with pytest.raises(EngineError, match="call order"):
+            e.solve(o)                                          # problem but no cameras
+        with pytest.raises(EngineError, match="call order"):
+            e.linearize()
+        e.load(p)
+        b = e.solve(o)
+        # a second window on the same handle after a solve that may have ended on either parity
+        e.set_problem(p.xyz, p.desc, p.obs_point, p.obs_slot, p.weights)
+        e.set_cameras(p.cams, 0)
+        c = e.solve(o)
+        e.set_cameras(p.cams, 0)
+        e.set_problem(p.xyz, p.desc, p.obs_point, p.obs_slot, p.weights)
+        d = e.solve(o)
+    finally:
+        e.close()
+    for r in (b, c, d):
+        assert r["final_cost"] == a["final_cost"] and np.array_equal(r["cams"], a["cams"]) and np.array_equal(r["xyz"], a["xyz"])
