@@ -44,10 +44,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--frames", type=int, default=8)
-    ap.add_argument("--points", type=int, default=50000, help="points per GPU")
-    ap.add_argument("--radius", type=int, default=2)
-    ap.add_argument("--huber", type=float, default=0.0)
+    ap.add_argument("--config", type=int, default=1, choices=(1, 3, 4),
+                    help="BASELINE.json configs[k]: 1 = 8 frames x 50k points x 5x5 per GPU (weak scaling, the headline); "
+                         "3 = ONE 16-frame x 200k-point window point-sharded over the N ranks (STRONG scaling: 200k / N points per "
+                         "rank, value is not multiplied by N); 4 = 8 frames x 50k points x 11x11 + Huber 0.05 per GPU")
+    ap.add_argument("--frames", type=int, default=None)
+    ap.add_argument("--points", type=int, default=None, help="points per GPU (config 3: points of the whole window)")
+    ap.add_argument("--radius", type=int, default=None)
+    ap.add_argument("--huber", type=float, default=None)
     ap.add_argument("--visibility", choices=("dense", "causal"), default="dense")
     ap.add_argument("--precision", choices=("exact", "fp32", "bf16"), default="exact",
                     help="sampler precision (configs[4] tolerance sweep); only \"exact\" has reference parity")
@@ -55,6 +59,13 @@ def main():
     ap.add_argument("--cpu-points", type=int, default=50000, help="points of the bounded CPU-baseline sample")
     ap.add_argument("--cpu-steps", type=int, default=20)
     args = ap.parse_args()
+    preset = {1: dict(frames=8, points=50000, radius=2, huber=0.0), 3: dict(frames=16, points=200000, radius=2, huber=0.0),
+              4: dict(frames=8, points=50000, radius=5, huber=0.05)}[args.config]
+    explicit = any(getattr(args, k) is not None for k in preset)
+    for k, v in preset.items():
+        if getattr(args, k) is None:
+            setattr(args, k, v)
+    strong = args.config == 3
 
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -84,9 +95,16 @@ def main():
 
     # ---- synthetic window: identical frames/cameras on every rank, rank-specific points ----------------------
     t0 = time.time()
-    default_shape = (args.frames, args.points, args.radius, args.huber, args.visibility, args.precision) == (8, 50000, 2, 0.0, "dense", "exact")
-    prob = synthetic.make_window(n_frames=args.frames, n_points=args.points, radius=args.radius, huber=args.huber,
-                                 visibility=args.visibility, point_seed_offset=rank)
+    default_shape = not explicit and (args.visibility, args.precision) == ("dense", "exact")
+    if strong:
+        # the SAME window on every rank (same seeds), each rank keeps its contiguous shard of whole points
+        whole = synthetic.make_window(n_frames=args.frames, n_points=args.points, radius=args.radius, huber=args.huber,
+                                      visibility=args.visibility, dense_births=(0, 8) if args.frames > 8 else (0,))
+        prob = whole.shard(rank, world) if world > 1 else whole
+        del whole
+    else:
+        prob = synthetic.make_window(n_frames=args.frames, n_points=args.points, radius=args.radius, huber=args.huber,
+                                     visibility=args.visibility, point_seed_offset=rank)
     t_gen = time.time() - t0
     rows, cols = prob.images.shape[1:]
     P = prob.patch_len
@@ -214,7 +232,7 @@ def main():
     n_jac, n_cost, n_res = tot["n_jac"], tot["n_cost"], tot["n_res"]
     n_obs_global = res["num_residual_blocks"]
     iters_per_sec = iters_done / elapsed
-    value = world * iters_per_sec
+    value = iters_per_sec if strong else world * iters_per_sec
     residuals_per_sec = n_obs_global * P * (n_jac + n_cost) / elapsed   # residuals actually evaluated by the engine
 
     ab = algorithmic_bytes(prob.radius, n_bar)
@@ -251,11 +269,13 @@ def main():
 
     out = {
         "metric": "LM iters/sec + residuals/sec, 8-frame KITTI window, 50k pts, 5x5 patch",
-        "value": value, "unit": "LM iters/s (50k-point windows; x N under weak scaling)",
+        "value": value, "unit": ("LM iters/s of the one %d-point window (strong scaling)" % args.points) if strong
+                                 else "LM iters/s (%dk-point windows; x N under weak scaling)" % (args.points // 1000),
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(1, iters_done),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "%s%d-frame window, %d points/GPU, %dx%d patch, single level, %s visibility"
-                               % ("configs[1]: " if default_shape else "", prob.n_frames, prob.n_points, 2 * prob.radius + 1,
+        "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "%s%d-frame window, %d points%s, %dx%d patch, single level, %s visibility"
+                               % (("configs[%d]: " % args.config) if default_shape else "", prob.n_frames, args.points,
+                                  " sharded over the ranks" if strong else "/GPU", 2 * prob.radius + 1,
                                   2 * prob.radius + 1, args.visibility),
                    "image": "%dx%d u8" % (cols, rows), "observations": int(n_obs_global), "huber": prob.huber,
                    "sampler_precision": args.precision,
@@ -274,7 +294,7 @@ def main():
     # ---- CPU baseline: the oracle ("restated Ceres-equivalent CPU path") on a bounded sample, rank 0, N = 1 ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.cpu_steps > 0:
         from oracle import oracle
-        n_cpu = min(args.cpu_points, prob.n_points)
+        n_cpu = min(args.cpu_points, prob.n_points, max(1000, int(400000 / n_bar)))     # bounded: <= 400k residual blocks
         sub = prob.shard(0, 1)
         hi = int(np.searchsorted(prob.obs_point, n_cpu, side="left"))
         sub.xyz, sub.desc = prob.xyz[:n_cpu].copy(), prob.desc[:n_cpu]
@@ -289,9 +309,9 @@ def main():
         frac = hi / float(n_obs_local)
         cpu_iters_per_sec_full = (it_cpu / cpu_s) * frac   # time scales linearly with the observation count
         out["cpu_baseline"] = {
-            "value": cpu_iters_per_sec_full, "unit": "LM iters/s (extrapolated to the full 50k-point window)",
+            "value": cpu_iters_per_sec_full, "unit": "LM iters/s (extrapolated to the full %d-point window)" % prob.n_points,
             "cores": threads, "kind": "port",
-            "sample": "%d of %d points (%d observations), %d LM iterations, dual-number autodiff + materialised Jacobian "
+            "sample": "first %d of %d points (%d observations), %d LM iterations, dual-number autodiff + materialised Jacobian "
                       "+ Schur, %d OpenMP threads, %.1f s wall" % (n_cpu, prob.n_points, hi, it_cpu, threads, cpu_s),
             "sample_iters_per_sec": it_cpu / cpu_s,
             "residuals_per_sec": hi * P * (cres["num_jacobian_passes"] + cres["num_cost_passes"]) / cpu_s,

@@ -230,6 +230,15 @@ def cost(prob, threads=4, cams=None, xyz=None):
     return c.value, sq
 
 
+def block_products(prob, autodiff=True, threads=4, cams=None, xyz=None):
+    """Per residual block: dict(JcJc [n,6,6], JcJp [n,6,3], JpJp [n,3,3], Jcr [n,6], Jpr [n,3]) of the corrected rows."""
+    h = Holder(prob, cams, xyz)
+    out = np.zeros((h.c.n_obs, 72))
+    lib().oracle_block_products(C.byref(h.c), int(autodiff), int(threads), _ptr(out))
+    return dict(JcJc=out[:, :36].reshape(-1, 6, 6), JcJp=out[:, 36:54].reshape(-1, 6, 3), JpJp=out[:, 54:63].reshape(-1, 3, 3),
+                Jcr=out[:, 63:69], Jpr=out[:, 69:72])
+
+
 ITER_FIELDS = [f for f, _ in Iteration._fields_]
 
 

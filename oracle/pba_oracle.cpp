@@ -818,6 +818,35 @@ void oracle_linearize(const oracle_problem* p, int use_autodiff, int num_threads
   }
 }
 
+void oracle_block_products(const oracle_problem* p, int use_autodiff, int num_threads, double* out) {
+  // test hook: what one residual block contributes to J^T J and J^T r (ResidualBlock::Evaluate + Corrector applied)
+  const int P = (2 * p->radius + 1) * (2 * p->radius + 1);
+#pragma omp parallel for num_threads(std::max(1, num_threads)) schedule(static)
+  for (int o = 0; o < p->n_obs; ++o) {
+    std::vector<double> r(P), jc((size_t)P * 6), jp((size_t)P * 3);
+    EvalBlock(p, o, use_autodiff != 0, r.data(), jc.data(), jp.data());
+    double s = 0.0;
+    for (int i = 0; i < P; ++i) s += r[i] * r[i];
+    if (p->huber > 0.0) {
+      double rho[3];
+      HuberEvaluate(p->huber, s, rho);
+      const double k = std::sqrt(rho[1]);
+      for (double& v : jc) v *= k;
+      for (double& v : jp) v *= k;
+      for (double& v : r) v *= k;
+    }
+    double* q = out + 72 * (size_t)o;
+    for (int k = 0; k < 72; ++k) q[k] = 0.0;
+    for (int i = 0; i < P; ++i) {
+      for (int a = 0; a < 6; ++a) for (int c = 0; c < 6; ++c) q[6 * a + c] += jc[6 * i + a] * jc[6 * i + c];
+      for (int a = 0; a < 6; ++a) for (int c = 0; c < 3; ++c) q[36 + 3 * a + c] += jc[6 * i + a] * jp[3 * i + c];
+      for (int a = 0; a < 3; ++a) for (int c = 0; c < 3; ++c) q[54 + 3 * a + c] += jp[3 * i + a] * jp[3 * i + c];
+      for (int a = 0; a < 6; ++a) q[63 + a] += jc[6 * i + a] * r[i];
+      for (int a = 0; a < 3; ++a) q[69 + a] += jp[3 * i + a] * r[i];
+    }
+  }
+}
+
 int oracle_solve(oracle_problem* p, const oracle_options* opt, oracle_summary* sum, oracle_iteration* its, int max_its_out) {
   // ceres::Solve (photobundle.cc:829) -> TrustRegionMinimizer::Minimize (Ceres >= 1.12 control flow)
   const double t_start = Now();

@@ -140,6 +140,10 @@ void oracle_linearize(const oracle_problem* p, int use_autodiff, int num_threads
                       double* block_sqnorm, double* grad_cams, double* grad_pts,
                       double* U, double* V, double* W);
 
+/* Test hook: per residual block o, out[72 o ..] = Jc^T Jc (36, row-major) | Jc^T Jp (18) | Jp^T Jp (9) | Jc^T r (6) |
+ * Jp^T r (3) of the loss-corrected rows (the camera derivative is reported for the constant camera too). */
+void oracle_block_products(const oracle_problem* p, int use_autodiff, int num_threads, double* out);
+
 /* Ceres-faithful trust-region LM with Schur elimination of the points; updates p->cams / p->xyz in place. */
 int oracle_solve(oracle_problem* p, const oracle_options* o, oracle_summary* s,
                  oracle_iteration* iterations, int max_iterations_out);

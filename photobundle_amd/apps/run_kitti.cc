@@ -38,14 +38,31 @@ static bool readPgm(const std::string& fn, std::vector<uint8_t>& img, int& rows,
   return (bool)ifs;
 }
 
+static void dumpResult(const std::string& fn, int frame, const PhotometricBundleAdjustment::Result& r) {
+  std::FILE* f = std::fopen(fn.c_str(), "a");
+  if (!f) throw std::runtime_error("cannot open " + fn);
+  std::fprintf(f, "result frame %d poses %zu points %zu iterations %zu\n", frame, r.poses.size(), r.refinedPoints.size(), r.iterationSummary.size());
+  std::fprintf(f, "cost %.17g %.17g %.17g steps %d residuals %d\n", r.initialCost, r.finalCost, r.fixedCost, r.numSuccessfulStep, r.numResiduals);
+  std::fprintf(f, "message %s\n", r.message.c_str());
+  for (const auto& it : r.iterationSummary)
+    std::fprintf(f, "it %d %d %d %.17g %.17g %.17g %.17g %.17g %.17g\n", it.iteration, (int)it.step_is_valid, (int)it.step_is_successful, it.cost,
+                 it.cost_change, it.gradient_max_norm, it.step_norm, it.relative_decrease, it.trust_region_radius);
+  for (size_t i = 0; i < r.refinedPoints.size(); ++i)
+    std::fprintf(f, "pt %.17g %.17g %.17g %.17g %.17g %.17g\n", r.refinedPoints[i][0], r.refinedPoints[i][1], r.refinedPoints[i][2],
+                 r.originalPoints[i][0], r.originalPoints[i][1], r.originalPoints[i][2]);
+  std::fclose(f);
+}
+
 int main(int argc, char** argv) {
   signal(SIGINT, sigHandler);
-  std::string config = "../config/kitti_stereo.cfg", output = "refined_poses.txt";
+  // -r (not in the reference's driver): text dump of every Result the class hands back (reference photobundle.cc:857-875)
+  std::string config = "../config/kitti_stereo.cfg", output = "refined_poses.txt", results;
   for (int i = 1; i < argc; ++i) {
     const std::string a = argv[i];
     if ((a == "-c" || a == "--config") && i + 1 < argc) config = argv[++i];
     else if ((a == "-o" || a == "--output") && i + 1 < argc) output = argv[++i];
-    else { std::fprintf(stderr, "usage: %s [-c config] [-o output]\n", argv[0]); return 1; }
+    else if ((a == "-r" || a == "--results") && i + 1 < argc) results = argv[++i];
+    else { std::fprintf(stderr, "usage: %s [-c config] [-o output] [-r result-dump]\n", argv[0]); return 1; }
   }
   try {
     utils::ConfigFile cf(config);
@@ -83,8 +100,10 @@ int main(int argc, char** argv) {
       std::ifstream dfs(data + name, std::ios::binary);
       if (!dfs.read(reinterpret_cast<char*>(depth.data()), depth.size() * sizeof(float))) throw std::runtime_error("bad depth file");
       std::printf("Frame %05d\n", f_i);
+      result.initialCost = -1.0;    // the class only touches `result` when an optimisation ran (photobundle.cc:857)
       if (photoba_pyr) photoba_pyr->addFrame(img.data(), depth.data(), T_init[f_i], &result);
       else photoba->addFrame(img.data(), depth.data(), T_init[f_i], &result);
+      if (!results.empty() && result.initialCost >= 0.0) dumpResult(results, f_i, result);
     }
     std::fprintf(stderr, "Writing refined poses to %s\n", output.c_str());
     writePosesKittiFormat(output, result.poses);

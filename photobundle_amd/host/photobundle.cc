@@ -442,7 +442,11 @@ void PhotometricBundleAdjustment::optimize(Result* result) {
     check(_engine, pba_set_problem(_engine, (int32_t)selected.size(), xyz.data(), desc.data(), (int32_t)obs_point.size(),
                                   obs_point.data(), obs_slot.data(), patch_weights.data()), "pba_set_problem");
     lap_o(1);
-    check(_engine, pba_set_cameras(_engine, cams.data(), window, (int32_t)(frame_id_start % window)), "pba_set_cameras");
+    // "set the first camera constant" only if it is part of the problem (reference :809-815, HasParameterBlock)
+    const int32_t first_slot = (int32_t)(frame_id_start % window);
+    const bool first_in_bundle = std::find(obs_slot.begin(), obs_slot.end(), first_slot) != obs_slot.end();
+    if (!first_in_bundle) std::fprintf(stderr, "first camera is not in bundle\n");
+    check(_engine, pba_set_cameras(_engine, cams.data(), window, first_in_bundle ? first_slot : -1), "pba_set_cameras");
     lap_o(2);
     pba_solver_options so;
     pba_default_solver_options(&so);     // GetSolverOptions (:738-761)
@@ -459,7 +463,7 @@ void PhotometricBundleAdjustment::optimize(Result* result) {
     for (uint32_t id = frame_id_start; id <= frame_id_end; ++id)
       _trajectory.atId((int)id) = ParamsToPose(&cams[6 * (id % window)]).inverse();
   } else {
-    std::fprintf(stderr, "first camera is not in bundle\n");
+    std::fprintf(stderr, "first camera is not in bundle\n");   // empty problem: ceres::Solve would return at once
   }
   (void)P;
 

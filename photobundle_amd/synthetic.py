@@ -111,7 +111,7 @@ def project(K, T_cw, X):
 
 def make_window(n_frames=8, n_points=50000, radius=2, size=KITTI_SIZE, K=KITTI_K, visibility="dense",
                 huber=0.0, gaussian=False, depth_noise=0.01, rot_deg=0.1, trans=0.02, seed_offset=0,
-                point_seed_offset=0):
+                point_seed_offset=0, dense_births=(0,)):
     """Builds a WindowProblem of the named shape.
 
     visibility = "dense": every point is born in frame 0 and observed in every frame (sites whose ground-truth
@@ -119,6 +119,9 @@ def make_window(n_frames=8, n_points=50000, radius=2, size=KITTI_SIZE, K=KITTI_K
                  "causal": points are born uniformly over frames 0..n_frames-3 and observed from birth on while
                           inside the margin (mirrors the selection rule of reference photobundle.cc:789).
     point_seed_offset only changes the drawn points (multi-GPU shards share frames and cameras).
+    dense_births: frames the "dense" sites (and their descriptors) are taken from; every point is still observed in ALL
+                  frames.  One frame does not hold 200k sites that stay inside a 16-frame window (BASELINE configs[3]):
+                  that shape uses (0, 8).
     """
     rows, cols = size
     tex = Texture(seed=SEED_TEXTURE + seed_offset)
@@ -137,7 +140,7 @@ def make_window(n_frames=8, n_points=50000, radius=2, size=KITTI_SIZE, K=KITTI_K
     fx, fy, cx, cy = K
     T_cw_gt = [np.linalg.inv(T) for T in T_gt]
 
-    births = [0] if visibility == "dense" else list(range(0, max(1, n_frames - 2)))
+    births = list(dense_births) if visibility == "dense" else list(range(0, max(1, n_frames - 2)))
     per_birth = [n_points // len(births) + (1 if i < n_points % len(births) else 0) for i in range(len(births))]
     xyz_all, desc_all, obs_p, obs_s = [], [], [], []
     base = 0
@@ -151,12 +154,12 @@ def make_window(n_frames=8, n_points=50000, radius=2, size=KITTI_SIZE, K=KITTI_K
         Xc = np.stack([(xs - cx) / fx * z_gt[ys, xs], (ys - cy) / fy * z_gt[ys, xs], z_gt[ys, xs]], 1)
         Xw_gt = Xc @ T_gt[b][:3, :3].T + T_gt[b][:3, 3]
         vis = np.zeros((len(xs), n_frames), bool)
-        for f in range(b, n_frames):
+        for f in range(0 if visibility == "dense" else b, n_frames):
             uv, zc = project(K, T_cw_gt[f], Xw_gt)
             vis[:, f] = (zc > 0.1) & (uv[:, 0] >= margin) & (uv[:, 0] <= cols - 1 - margin) & \
                         (uv[:, 1] >= margin) & (uv[:, 1] <= rows - 1 - margin)
         if visibility == "dense":
-            keep = vis[:, b:].all(1)
+            keep = vis.all(1)
         else:
             keep = vis[:, b:].sum(1) >= 3
         ys, xs, vis = ys[keep], xs[keep], vis[keep]

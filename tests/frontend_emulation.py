@@ -60,6 +60,7 @@ class Zncc:
 class Point:
     def __init__(self, X, fid):
         self.X = X.copy()
+        self.X0 = X.copy()           # ScenePoint::_X_original (photobundle.cc:380)
         self.f = [fid]
         self.patch = None
         self.desc = None
@@ -164,15 +165,22 @@ class Emulator:
             prob = WindowProblem(K=self.K, radius=self.radius, planes=np.stack([imgproc.planes_from_u8(im) for im in images]),
                                  cams=cams, xyz=np.stack([p.X for p in sel]), desc=np.stack([p.desc for p in sel]),
                                  obs_point=np.array(obs_p, np.int32), obs_slot=np.array(obs_s, np.int32),
-                                 weights=imgproc.make_patch_weights(self.radius), huber=self.huber, fixed_slot=start % W,
+                                 weights=imgproc.make_patch_weights(self.radius), huber=self.huber,
+                                 fixed_slot=(start % W) if (start % W) in obs_s else -1,     # photobundle.cc:809-815
                                  images=images)
             res = oracle.solve(prob, oracle.default_options(max_num_iterations=self.max_iterations))
             for p, X in zip(sel, res["xyz"]):
                 p.X = X.copy()
             for fid, _ in self.frames:
                 self.T_w[fid] = np.linalg.inv(se3.params_to_pose(res["cams"][fid % W]))
+            # Result write-back, photobundle.cc:857-875: the points that leave the window (refFrameId <= frame_id_start)
+            gone = [p for p in self.points if p.f[0] <= start]
             self.results.append(dict(n_points=len(sel), n_obs=len(obs_p), initial_cost=res["initial_cost"],
-                                     final_cost=res["final_cost"], iterations=len(res["iterations"])))
+                                     final_cost=res["final_cost"], iterations=len(res["iterations"]),
+                                     num_successful_steps=res["num_successful_steps"], num_residuals=res["num_residuals"],
+                                     message=res["message"], it=res["iterations"], n_poses=len(self.T_w),
+                                     refined=np.array([p.X for p in gone]).reshape(-1, 3),
+                                     original=np.array([p.X0 for p in gone]).reshape(-1, 3)))
         self.points = [p for p in self.points if p.f[0] > start]
 
 

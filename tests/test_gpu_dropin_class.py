@@ -34,6 +34,30 @@ def _write_sequence(tmp, n_frames, size, K):
     return imgs, depths, local
 
 
+def _read_results(path):
+    """Parses run_kitti -r: one record per Result the class returned."""
+    out, cur = [], None
+    for line in open(path):
+        t = line.split()
+        if t[0] == "result":
+            cur = dict(frame=int(t[2]), n_poses=int(t[4]), it=[], refined=[], original=[])
+            out.append(cur)
+        elif t[0] == "cost":
+            cur.update(initial=float(t[1]), final=float(t[2]), fixed=float(t[3]), steps=int(t[5]), residuals=int(t[7]))
+        elif t[0] == "message":
+            cur["message"] = line[len("message "):].rstrip("\n")
+        elif t[0] == "it":
+            cur["it"].append([int(t[1]), int(t[2]), int(t[3])] + [float(v) for v in t[4:]])
+        elif t[0] == "pt":
+            v = [float(x) for x in t[1:]]
+            cur["refined"].append(v[:3])
+            cur["original"].append(v[3:])
+    for r in out:
+        r["refined"] = np.array(r["refined"]).reshape(-1, 3)
+        r["original"] = np.array(r["original"]).reshape(-1, 3)
+    return out
+
+
 @pytest.mark.timeout(900)
 def test_run_kitti_matches_emulated_reference_pipeline(tmp_path):
     from frontend_emulation import Emulator
@@ -49,7 +73,8 @@ def test_run_kitti_matches_emulated_reference_pipeline(tmp_path):
         f.write("maxNumPoints = %d\nslidingWindowSize = %d\npatchRadius = %d\nminScore = 0.65\nrobustThreshold = 0.05\nverbose = 0\n"
                 % (max_points, window, radius))
     out = os.path.join(tmp, "refined.txt")
-    r = subprocess.run([RUN, "-c", cfg, "-o", out], capture_output=True, text=True, timeout=600)
+    dump = os.path.join(tmp, "results.txt")
+    r = subprocess.run([RUN, "-c", cfg, "-o", out, "-r", dump], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     refined = np.loadtxt(out).reshape(-1, 3, 4)
     assert refined.shape[0] == n_frames
@@ -68,6 +93,28 @@ def test_run_kitti_matches_emulated_reference_pipeline(tmp_path):
     from photobundle_amd import se3
     chained = np.stack([T[:3, :] for T in se3.chain_local_poses(local)])
     assert np.abs(refined - chained).max() > 1e-6
+    # every field of every Result the class handed back (reference photobundle.cc:857-875) against the emulation
+    got = _read_results(dump)
+    assert [g["frame"] for g in got] == list(range(window - 1, n_frames))
+    assert sum(len(g["refined"]) for g in got) > 0
+    for g, e in zip(got, emu.results):
+        assert g["n_poses"] == e["n_poses"]                                      # the whole trajectory so far (:858)
+        assert g["residuals"] == e["num_residuals"] == e["n_obs"] * (2 * radius + 1) ** 2
+        assert g["steps"] == e["num_successful_steps"]
+        assert np.isclose(g["initial"], e["initial_cost"], rtol=1e-12) and np.isclose(g["final"], e["final_cost"], rtol=1e-9)
+        assert g["fixed"] == 0.0
+        assert g["message"] == e["message"] or g["message"].split(".")[0] == e["message"].split(".")[0], (g["message"], e["message"])
+        assert len(g["it"]) == len(e["it"])
+        for a, b in zip(g["it"], e["it"]):
+            assert a[0] == b["iteration"] and a[1] == b["step_is_valid"] and a[2] == b["step_is_successful"]
+            assert np.isclose(a[3], b["cost"], rtol=1e-9) and np.isclose(a[8], b["trust_region_radius"], rtol=1e-6)
+            assert np.isclose(a[5], b["gradient_max_norm"], rtol=1e-6)
+        assert g["refined"].shape == e["refined"].shape
+        # originalPoints are the back-projections of addFrame (never touched by the solver), refinedPoints the solver's
+        assert np.abs(g["original"] - e["original"]).max() <= 1e-12 * max(1.0, np.abs(e["original"]).max())
+        assert np.abs(g["refined"] - e["refined"]).max() <= 1e-6 * max(1.0, np.abs(e["refined"]).max())
+        moved = np.abs(g["refined"] - g["original"]).max(1) > 0
+        assert moved.any()
 
 
 @pytest.mark.timeout(1500)
@@ -94,3 +141,88 @@ def test_pyramid_path_matches_emulation(tmp_path):
     assert len(fine.results) == n_frames - window + 1
     ref = np.stack([T[:3, :] for T in fine.T_w])
     assert np.abs(refined - ref).max() <= 1e-5, np.abs(refined - ref).max()
+
+
+@pytest.mark.timeout(1500)
+def test_pyramid_three_levels_matches_emulation(tmp_path):
+    """configs[2] path with numLevels = 3 (192x256 -> 96x128 -> 48x64) against the numpy emulation + oracle solves."""
+    from frontend_emulation import PyramidEmulator
+    size, K = (192, 256), (320.0, 320.0, 128.0, 96.0)
+    n_frames, window, radius, max_points = 5, 3, 1, 100000
+    tmp = str(tmp_path)
+    imgs, depths, local = _write_sequence(tmp, n_frames, size, K)
+    cfg = os.path.join(tmp, "pyr3.cfg")
+    with open(cfg, "w") as f:
+        f.write("DataDirectory = %s\nTrajectory = %s/init.txt\n" % (tmp, tmp))
+        f.write("numLevels = 3\nmaxNumPoints = %d\nslidingWindowSize = %d\npatchRadius = %d\nminScore = 0.65\nrobustThreshold = 0.05\nverbose = 0\n"
+                % (max_points, window, radius))
+    out = os.path.join(tmp, "refined.txt")
+    r = subprocess.run([RUN, "-c", cfg, "-o", out], capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for lvl in range(3):
+        assert r.stderr.count("Pyramid level %d" % lvl) == n_frames
+    refined = np.loadtxt(out).reshape(-1, 3, 4)
+    emu = PyramidEmulator(3, K, size, window=window, radius=radius, max_points=max_points, min_score=0.65, huber=0.05)
+    for im, z, T in zip(imgs, depths, local):
+        fine = emu.add_frame(im, z, T)
+    assert len(fine.results) == n_frames - window + 1
+    assert all(len(e_.results) == n_frames - window + 1 and all(r_["n_points"] > 10 for r_ in e_.results) for e_ in emu.emus)
+    ref = np.stack([T[:3, :] for T in fine.T_w])
+    assert np.abs(refined - ref).max() <= 1e-5, np.abs(refined - ref).max()
+
+
+def _pose_errors(T, T_gt):
+    rot, tr = [], []
+    for a, b in zip(T, T_gt):
+        d = np.linalg.inv(b) @ np.vstack([a, [0, 0, 0, 1]])
+        rot.append(np.arccos(np.clip((np.trace(d[:3, :3]) - 1) / 2, -1, 1)))
+        tr.append(np.linalg.norm(d[:3, 3]))
+    return np.array(rot), np.array(tr)
+
+
+@pytest.mark.timeout(2400)
+def test_configs2_full_size_three_level_pyramid(tmp_path):
+    """BASELINE configs[2] at its stated shape: 3-level pyramid (1241x376, 621x188, 311x94), 8-frame window, ~50k points
+    in the finest window, through PhotometricBundleAdjustmentPyr / run_kitti.  The emulator cannot cover this size, so
+    the checks are size-independent properties: every level ran for every frame, each Result's cost went down, the
+    refined trajectory is closer to the ground truth than the chained initial poses, and a second run reproduces the
+    output bit for bit."""
+    from photobundle_amd import se3, synthetic
+    size, K = synthetic.KITTI_SIZE, synthetic.KITTI_K
+    n_frames, window, radius = 10, 8, 2
+    tmp = str(tmp_path)
+    imgs, depths, local = _write_sequence(tmp, n_frames, size, K)
+    T_gt = synthetic.make_trajectory(n_frames)
+    cfg = os.path.join(tmp, "cfg2.cfg")
+    with open(cfg, "w") as f:
+        f.write("DataDirectory = %s\nTrajectory = %s/init.txt\n" % (tmp, tmp))
+        f.write("numLevels = 3\nmaxNumPoints = 12000\nslidingWindowSize = %d\npatchRadius = %d\nminScore = 0.75\nrobustThreshold = 0.05\nverbose = 0\n"
+                % (window, radius))
+    outs = []
+    for k in range(2):
+        out = os.path.join(tmp, "refined%d.txt" % k)
+        dump = os.path.join(tmp, "results%d.txt" % k)
+        r = subprocess.run([RUN, "-c", cfg, "-o", out, "-r", dump], capture_output=True, text=True, timeout=1000)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append((open(out).read(), open(dump).read(), r.stderr))
+    assert outs[0][0] == outs[1][0] and outs[0][1] == outs[1][1]          # run-to-run determinism of the whole pipeline
+    err = outs[0][2]
+    for lvl in range(3):
+        assert err.count("Pyramid level %d" % lvl) == n_frames
+    import re
+    used = [tuple(int(t) for t in m.groups()) for m in re.finditer(r"Using (\d+) points \((\d+) residual blocks\)", err)]
+    assert len(used) == 3 * (n_frames - window + 1)
+    finest = max(u[0] for u in used)
+    print("configs[2]: windows (points, residual blocks) per optimisation:", used)
+    assert finest >= 40000, used                                              # the "50k points" window of configs[2]
+    got = _read_results(os.path.join(tmp, "results0.txt"))
+    assert len(got) == n_frames - window + 1
+    for g in got:
+        assert g["final"] < g["initial"] and g["steps"] >= 2 and g["n_poses"] == g["frame"] + 1
+        assert g["residuals"] % ((2 * radius + 1) ** 2) == 0
+    refined = np.loadtxt(os.path.join(tmp, "refined0.txt")).reshape(-1, 3, 4)
+    chained = np.stack([T[:3, :] for T in se3.chain_local_poses(local)])
+    r_ref, t_ref = _pose_errors(refined, T_gt)
+    r_ini, t_ini = _pose_errors(chained, T_gt)
+    print("configs[2]: mean rotation error %.3e -> %.3e rad, mean translation error %.3e -> %.3e m" % (r_ini.mean(), r_ref.mean(), t_ini.mean(), t_ref.mean()))
+    assert r_ref.mean() < 0.5 * r_ini.mean() and t_ref.mean() < 0.5 * t_ini.mean()

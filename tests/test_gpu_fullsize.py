@@ -19,7 +19,7 @@ def full_window():
 def test_configs1_parity_with_oracle(full_window):
     from oracle import oracle
     from photobundle_amd.engine import default_solver_options
-    from gpu_util import make_engine
+    from gpu_util import check_obs_records, make_engine
     p = full_window
     assert p.n_obs == 400000
     c_ref, sq = oracle.cost(p)
@@ -28,6 +28,9 @@ def test_configs1_parity_with_oracle(full_window):
         assert np.isclose(c, c_ref, rtol=1e-12)
         rec = e.obs_records()
         assert np.allclose(rec[:, 5], 0.5 * sq, rtol=1e-12)
+        # all 400k Jacobian-pass records (M, b) against the oracle's dual-number rows
+        worst = check_obs_records(p, rec, threads=8)
+        print("configs[1] record check, worst relative block errors:", worst)
     n_it = 4
     ref = oracle.solve(p, oracle.default_options(max_num_iterations=n_it, num_threads=8))
     with make_engine(p, keep_reduced_system=False) as e:
@@ -117,3 +120,111 @@ def test_configs4_shape_huber_11x11():
             assert it["cost"] < cost
             cost = it["cost"]
     assert res["num_residuals"] == 400000 * 121
+
+
+def _trace_parity(ref, res, pose_tol=1e-5):
+    ri, gi = ref["iterations"], res["iterations"]
+    assert len(ri) == len(gi), (len(ri), len(gi), ref["message"], res["message"])
+    for a, b in zip(ri, gi):
+        assert a["step_is_successful"] == b["step_is_successful"] and a["step_is_valid"] == b["step_is_valid"], a["iteration"]
+        assert np.isclose(a["cost"], b["cost"], rtol=1e-9), (a["iteration"], a["cost"], b["cost"])
+        assert np.isclose(a["trust_region_radius"], b["trust_region_radius"], rtol=1e-6), a["iteration"]
+        assert np.isclose(a["gradient_max_norm"], b["gradient_max_norm"], rtol=1e-5), a["iteration"]
+    assert res["termination_type"] == ref["termination_type"], (ref["message"], res["message"])
+    assert res["num_successful_steps"] == ref["num_successful_steps"]
+    assert np.isclose(res["final_cost"], ref["final_cost"], rtol=1e-9)
+    free = [c for c in range(ref["cams"].shape[0])][1:]
+    d = res["cams"][free] - ref["cams"][free]
+    rmse_rot = np.sqrt(np.mean(d[:, :3] ** 2))
+    rmse_t = np.sqrt(np.mean(d[:, 3:] ** 2))
+    assert rmse_rot <= pose_tol and rmse_t <= pose_tol, (rmse_rot, rmse_t)
+    assert np.abs(d).max() <= pose_tol
+    return rmse_rot, rmse_t
+
+
+@pytest.mark.timeout(1800)
+def test_configs1_parity_to_convergence(full_window):
+    """configs[1] at full size with the reference's solver options (tolerances on, photobundle.cc:738-761): the whole
+    trust-region trace until a tolerance terminates the solve, refined poses compared at the END (north_star: pose RMSE
+    <= 1e-5, rotation in radians / translation in metres over the free cameras)."""
+    from oracle import oracle
+    from photobundle_amd.engine import default_solver_options
+    from gpu_util import make_engine
+    p = full_window
+    ref = oracle.solve(p, oracle.default_options(num_threads=8))
+    assert ref["termination_type"] == 0 and len(ref["iterations"]) >= 10, ref["message"]
+    with make_engine(p, keep_reduced_system=False) as e:
+        res = e.solve(default_solver_options())
+    rr, rt = _trace_parity(ref, res)
+    print("configs[1] to convergence: %d iterations (%s), pose RMSE rot %.3e rad, trans %.3e m, final cost rel diff %.3e"
+          % (len(res["iterations"]) - 1, res["message"], rr, rt, abs(res["final_cost"] - ref["final_cost"]) / ref["final_cost"]))
+    assert np.abs(res["xyz"] - ref["xyz"]).max() <= 1e-4 * max(1.0, np.abs(ref["xyz"]).max())
+
+
+@pytest.mark.timeout(2400)
+def test_configs4_ten_iterations_against_oracle():
+    """configs[4] shape (8 frames, 50k points, 11x11, Huber 0.05): >= 10 LM iterations of trace parity + poses."""
+    from oracle import oracle
+    from photobundle_amd import synthetic
+    from photobundle_amd.engine import default_solver_options
+    from gpu_util import make_engine
+    p = synthetic.make_window(n_frames=8, n_points=50000, radius=5, huber=0.05)
+    n_it = 10
+    ref = oracle.solve(p, oracle.default_options(max_num_iterations=n_it, num_threads=8, use_autodiff=0))
+    with make_engine(p, keep_reduced_system=False) as e:
+        res = e.solve(default_solver_options(max_num_iterations=n_it))
+    assert len(ref["iterations"]) == n_it + 1
+    rr, rt = _trace_parity(ref, res)
+    print("configs[4] %d iterations: pose RMSE rot %.3e rad, trans %.3e m" % (n_it, rr, rt))
+
+
+@pytest.fixture(scope="module")
+def window_configs3():
+    from photobundle_amd import synthetic
+    return synthetic.make_window(n_frames=16, n_points=200000, radius=2, dense_births=(0, 8))
+
+
+@pytest.mark.timeout(2400)
+def test_configs3_full_shape_on_one_gpu(window_configs3):
+    """configs[3] at its stated shape on ONE GPU: 16 frames x 200k points = 3.2 M residual blocks (80 M residuals),
+    90x90 reduced system.  Cost and every Jacobian-pass record against the oracle, 3 LM iterations of trace parity."""
+    from oracle import oracle
+    from photobundle_amd.engine import default_solver_options
+    from gpu_util import check_obs_records, make_engine
+    p = window_configs3
+    assert p.n_obs == 3200000 and p.n_frames == 16
+    c_ref, sq = oracle.cost(p, threads=8)
+    with make_engine(p, keep_reduced_system=False) as e:
+        c = e.linearize()
+        assert np.isclose(c, c_ref, rtol=1e-12)
+        rec = e.obs_records()
+        assert np.allclose(rec[:, 5], 0.5 * sq, rtol=1e-12)
+        worst = check_obs_records(p, rec, threads=8)
+        print("configs[3] record check, worst relative block errors:", worst)
+    del rec, sq
+    n_it = 3
+    ref = oracle.solve(p, oracle.default_options(max_num_iterations=n_it, num_threads=8, use_autodiff=0))
+    with make_engine(p, keep_reduced_system=False) as e:
+        res = e.solve(default_solver_options(max_num_iterations=n_it))
+    rr, rt = _trace_parity(ref, res)
+    assert res["num_residuals"] == 3200000 * 25
+    print("configs[3] %d iterations: pose RMSE rot %.3e rad, trans %.3e m" % (n_it, rr, rt))
+
+
+@pytest.mark.timeout(1200)
+def test_configs3_determinism_and_monotone_cost(window_configs3):
+    from photobundle_amd.engine import default_solver_options
+    from gpu_util import make_engine
+    o = default_solver_options(max_num_iterations=8, function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0)
+    runs = []
+    for _ in range(2):
+        with make_engine(window_configs3, keep_reduced_system=False) as e:
+            runs.append(e.solve(o))
+    a, b = runs
+    assert a["final_cost"] == b["final_cost"] and np.array_equal(a["cams"], b["cams"]) and np.array_equal(a["xyz"], b["xyz"])
+    cost = a["iterations"][0]["cost"]
+    for it in a["iterations"][1:]:
+        if it["step_is_successful"]:
+            assert it["cost"] < cost
+            cost = it["cost"]
+    assert a["final_cost"] == cost < a["initial_cost"]

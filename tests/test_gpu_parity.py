@@ -13,7 +13,7 @@ from oracle import oracle
 from photobundle_amd import synthetic
 from photobundle_amd.engine import default_solver_options
 
-from gpu_util import dense_system, make_engine, reference_step
+from gpu_util import check_obs_records, dense_system, make_engine, reference_step
 
 pytestmark = pytest.mark.gpu
 
@@ -35,15 +35,9 @@ def _check_records(p, e):
     rho = np.where((a > 0) & (s > a * a), 2 * a * np.sqrt(s) - a * a, s)
     assert np.allclose(rec[:, 5], 0.5 * rho, rtol=1e-12, atol=0)
     assert np.isclose(cost, lin["cost"], rtol=1e-12)
-    # structure tensors from the oracle's raw Jacobian rows: J_i = -w [gx gy] A  =>  M = sum w^2 g g^T
-    for o in range(0, p.n_obs, max(1, p.n_obs // 40)):
-        r, jc, jp = oracle.eval_block(p, o, autodiff=False)
-        k = 1.0 if not (a > 0 and s[o] > a * a) else a / np.sqrt(s[o])
-        # recover A from the translation columns (A[:,3:6] = d(u,v)/dt has full row rank 2)
-        # and check J^T J blocks instead: W = Ac^T M Ap is what the engine uses downstream
-        pt, slot = p.obs_point[o], p.obs_slot[o]
-        del pt, slot
-        assert np.isfinite(rec[o]).all()
+    # columns 0-4 (rho' M, rho' b): every block of J^T J and J^T r they generate, per observation, against the oracle's
+    # dual-number rows
+    check_obs_records(p, rec)
     return cost
 
 
@@ -141,6 +135,7 @@ def test_points_outside_the_image_take_the_clamped_path():
         rec = e.obs_records()
     assert np.isclose(cost, lin["cost"], rtol=1e-12)
     assert np.allclose(rec[:, 5], 0.5 * lin["block_sqnorm"], rtol=1e-12)
+    check_obs_records(p, rec)       # gradients of clamped / border taps included
 
 
 def test_run_to_run_determinism(small_window):
