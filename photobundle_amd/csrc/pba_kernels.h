@@ -1487,6 +1487,11 @@ __device__ __forceinline__ void solve_prologue(const SolveParams& p, int n, int 
                                                double* D2, double* gcs, double* gc, int tid) {
   const int nT = 36 * p.n_pairs;
   const double* src = p.packed;
+  // first batch of packed entries: issued before anything else so that the whole prologue is ONE global round trip for
+  // n <= 42 (the scale / damping vectors below are loaded at the same time, not ahead of the blocks)
+  double val0[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) { const int e = tid + u * T; val0[u] = (e < nT) ? src[e] : 0.0; }
   for (int i = tid; i < n; i += T) {
     const double du = src[nT + 2 * n + i];
     const double g = src[nT + n + i];
@@ -1511,7 +1516,7 @@ __device__ __forceinline__ void solve_prologue(const SolveParams& p, int n, int 
   for (int e0 = tid; e0 < nT; e0 += 4 * T) {
     double val[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { const int e = e0 + u * T; val[u] = (e < nT) ? src[e] : 0.0; }
+    for (int u = 0; u < 4; ++u) { const int e = e0 + u * T; val[u] = (e0 == tid) ? val0[u] : ((e < nT) ? src[e] : 0.0); }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int e = e0 + u * T;
@@ -1585,10 +1590,13 @@ __device__ __forceinline__ void solve_epilogue(const SolveParams& p, int n, cons
   }
 }
 
-// Fast path, n = 6 NF <= 60: lane r of wave 0 keeps row r of L in registers (compile-time indexed) and runs the
-// left-looking, software-pipelined factorisation described at k_solve_wave2 (same algorithm, one wave: the exchange
-// through LDS needs no barrier, only the compiler-level ordering of wave_lds_sync).  The right-hand side is folded in
-// one step behind; the backward sweep uses v_readlane.  The other three waves only help with the prologue / epilogue.
+// Fast path, n = 6 NF <= 60: lane r of wave 0 keeps row r of L in registers (compile-time indexed) and runs a
+// left-looking factorisation whose DEPENDENT chain never touches LDS: per column the newest entry L_j,j-1, the running
+// diagonal of the next pivot row and the right-hand side entry cross the wave with v_readlane (the values land in
+// SGPRs and feed the next FMA directly), and every lane derives the pivot's reciprocal square root itself.  LDS only
+// carries the OLDER entries of row j + 1 (written at least one column earlier, read as wave-uniform 16-byte broadcasts)
+// for the prefix sums, which are throughput work that fills the latency slots of the chain.  Arithmetic (operand order
+// of every sum) is that of k_solve_wave2.  The other three waves only help with the prologue / epilogue.
 template <int NF>
 __global__ __launch_bounds__(256) void k_solve_wave(SolveParams p_in) {
   SolveParams p = p_in;
@@ -1599,7 +1607,7 @@ __global__ __launch_bounds__(256) void k_solve_wave(SolveParams p_in) {
   constexpr int LE = N + (N & 1) + 2;       // even stride: 16-byte aligned pairs for the broadcast reads
   __shared__ double S[N * LD];
   __shared__ __attribute__((aligned(16))) double LT[N * LE];
-  __shared__ double y_s[N], sc[N], D2[N], gcs[N], gc[N], z_s[N], inv_s[N];
+  __shared__ double y_s[N], sc[N], D2[N], gcs[N], gc[N];
   __shared__ int s_ok;
   const int tid = threadIdx.x;
   unsigned long long t0 = (PBA_PHASE_TIMING ? __builtin_amdgcn_s_memtime() : 0ull), t1 = 0, t2 = 0, t3 = 0, t4 = 0;
@@ -1616,34 +1624,35 @@ __global__ __launch_bounds__(256) void k_solve_wave(SolveParams p_in) {
     double d_own = 1.0;              // 1 / L_rr of this lane's row
     double diag = S[r * LD + r];     // running A_rr - sum_k L_rk^2
     bool ok = true;
-    if (lane == 0) {
-      ok = (diag > 0.0) && isfinite(diag);
-      d_own = fast_rsqrt((diag > 0.0) ? diag : 1.0);
-      inv_s[0] = ok ? d_own : -1.0;  // a negative entry flags a non-positive pivot
+    double inv;                      // 1 / L_jj of the column being finished (wave-uniform)
+    {
+      const double d0 = readlane_f64(diag, 0);
+      ok = (d0 > 0.0) && isfinite(d0);
+      inv = fast_rsqrt(ok ? d0 : 1.0);
     }
     double pre0 = S[r * LD + 0], pre1 = 0.0;
-    wave_lds_sync();
+    double lr_prev = 0.0;            // this lane's entry of the previous column
 #pragma unroll
     for (int j = 0; j < N; ++j) {
-      const double inv = inv_s[j];
-      ok = ok && (inv > 0.0);
-      // finish column j: only the term with L_j,j-1 (written during the previous step) was still missing
+      // finish column j: only the term with L_j,j-1 (lane j's entry of the previous column) was still missing
       double v = pre0 + pre1;
-      if (j > 0) v = fma(-L[j - 1], LT[j * LE + j - 1], v);
-      if (j > 0 && lane >= j) y = fma(-L[j - 1], z_s[j - 1], y);   // rhs: one step behind, rows below j - 1 only
+      if (j > 0) v = fma(-lr_prev, readlane_f64(lr_prev, j), v);
       const double lrj = (lane > j) ? v * inv : 0.0;
       L[j] = lrj;
-      if (lane == j) { y *= inv; z_s[j] = y; }
+      lr_prev = lrj;
+      // right-hand side, column-oriented forward substitution: z_j = y_j / L_jj, then y_r -= L_rj z_j below
+      if (lane == j) { y *= inv; d_own = inv; }
+      const double zj = readlane_f64(y, j);
+      if (lane > j) y = fma(-lrj, zj, y);
       if (live && lane > j) LT[r * LE + j] = lrj;
       diag = fma(-lrj, lrj, diag);
-      if (j + 1 < N && lane == j + 1) {
-        // next pivot, one step ahead: derived from this row's running diagonal
-        const bool pd = (diag > 0.0) && isfinite(diag);
-        d_own = fast_rsqrt(pd ? diag : 1.0);
-        inv_s[j + 1] = pd ? d_own : -1.0;
-      }
       if (j + 1 < N) {
-        // prefix of column j + 1 from row j + 1 of L, entries k < j (published before the last sync)
+        // next pivot: every lane takes row j + 1's running diagonal and inverts it itself
+        const double dn = readlane_f64(diag, j + 1);
+        const bool pd = (dn > 0.0) && isfinite(dn);
+        ok = ok && pd;
+        inv = fast_rsqrt(pd ? dn : 1.0);
+        // prefix of column j + 1 from row j + 1 of L, entries k < j (in LDS since the previous column at the latest)
         pre0 = S[r * LD + j + 1]; pre1 = 0.0;
         double pre2 = 0.0, pre3 = 0.0;
 #pragma unroll
@@ -1662,19 +1671,19 @@ __global__ __launch_bounds__(256) void k_solve_wave(SolveParams p_in) {
       wave_lds_sync();
     }
     t2 = (PBA_PHASE_TIMING ? __builtin_amdgcn_s_memtime() : 0ull);
-    // backward substitution L^T x = z: lane r reads L[j][r] (row j, contiguous across lanes)
+    // backward substitution L^T x = z: lane r needs column r of L = L[j][r] for j > r; fetched up front (independent
+    // LDS reads, contiguous across lanes) so that the sweep itself is mul -> readlane -> fma per row
+    double lc[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) lc[j] = (lane < j) ? LT[j * LE + r] : 0.0;
 #pragma unroll
     for (int j = N - 1; j >= 0; --j) {
-      const double ljr = (lane < j) ? LT[j * LE + r] : 0.0;
       if (lane == j) y *= d_own;
       const double xj = readlane_f64(y, j);
-      if (lane < j) y = fma(-ljr, xj, y);
+      if (lane < j) y = fma(-lc[j], xj, y);
     }
     if (lane < N) y_s[lane] = y;
-    {
-      const unsigned long long okm = __ballot(ok);
-      if (lane == 0) s_ok = (okm == ~0ull) ? 1 : 0;
-    }
+    if (lane == 0) s_ok = ok ? 1 : 0;
     t3 = (PBA_PHASE_TIMING ? __builtin_amdgcn_s_memtime() : 0ull);
   }
   __syncthreads();
