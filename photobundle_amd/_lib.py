@@ -5,7 +5,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpba_hip.so")
+# PBA_LIB: diagnostics only (e.g. the TIMING=1 build with per-phase cycle stamps)
+LIB_PATH = os.environ.get("PBA_LIB") or os.path.join(_HERE, "libpba_hip.so")
 _LIB = None
 
 

@@ -155,15 +155,20 @@ int check_ready(pba_engine* e, const char* who) {
   return PBA_OK;
 }
 
+constexpr int kSampleWaves = 4;    // 256-thread workgroups at every patch radius (two 128-observation tiles when fused)
+
 template <int R, bool JAC, bool FUSED>
 void launch_sample_r(pba_engine* e, const SampleParams& sp) {
-  constexpr int WAVES = (R <= 2) ? 4 : (R == 3 ? 2 : 1);
-  if constexpr (FUSED && WAVES < 2) {
-    (void)e; (void)sp;   // unreachable: fused_capable() is false for these radii
+  const int grid = FUSED ? e->fused_grid : e->sample_grid;
+  const dim3 block(kSampleWaves * 64);
+  if constexpr (FUSED) {
+    // the reduced-precision sweep modes never take the fused path (fused_capable)
+    if (e->unit_weights) hipLaunchKernelGGL((k_sample<R, JAC, kSampleWaves, true, true, false>), dim3(grid), block, 0, e->stream, sp);
+    else hipLaunchKernelGGL((k_sample<R, JAC, kSampleWaves, true, false, false>), dim3(grid), block, 0, e->stream, sp);
   } else {
-    const int grid = FUSED ? e->fused_grid : e->sample_grid;
-    if (e->unit_weights) hipLaunchKernelGGL((k_sample<R, JAC, WAVES, FUSED, true>), dim3(grid), dim3(WAVES * 64), 0, e->stream, sp);
-    else hipLaunchKernelGGL((k_sample<R, JAC, WAVES, FUSED, false>), dim3(grid), dim3(WAVES * 64), 0, e->stream, sp);
+    if (e->unit_weights && sp.prec != 0) hipLaunchKernelGGL((k_sample<R, JAC, kSampleWaves, false, true, true>), dim3(grid), block, 0, e->stream, sp);
+    else if (e->unit_weights) hipLaunchKernelGGL((k_sample<R, JAC, kSampleWaves, false, true, false>), dim3(grid), block, 0, e->stream, sp);
+    else hipLaunchKernelGGL((k_sample<R, JAC, kSampleWaves, false, false, false>), dim3(grid), block, 0, e->stream, sp);
   }
 }
 template <bool JAC, bool FUSED = false>
@@ -176,8 +181,10 @@ void launch_sample(pba_engine* e, const SampleParams& sp) {
     default: launch_sample_r<5, JAC, FUSED>(e, sp); break;
   }
 }
-bool fused_capable(const pba_engine* e) { return e->cfg.radius <= 3 && e->fuse; }
-int sample_waves_for_radius(int R) { return (R <= 2) ? 4 : (R == 3 ? 2 : 1); }
+// one kernel for back-substitution + candidate pass + step finalisation, at every patch radius; the opt-in
+// reduced-precision sampler modes (pba_config.flags bits 1-2) keep the unfused kernels
+bool fused_capable(const pba_engine* e) { return e->fuse && ((e->cfg.flags >> 1) & 3) == 0; }
+int sample_waves_for_radius(int) { return kSampleWaves; }
 
 template <int NF>
 void launch_solve_wave(pba_engine* e, const SolveParams& so) {

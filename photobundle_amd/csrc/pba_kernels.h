@@ -18,6 +18,12 @@
 #define PBA_PHASE_TIMING 0
 #endif
 
+// Resident waves per SIMD the Jacobian-pass sampling kernel is compiled for at patch radius <= 2 (register budget
+// 512 / N VGPRs; 38.6 KB of LDS per 256-thread workgroup allows 4).
+#ifndef PBA_SAMPLE_WAVES_PER_SIMD
+#define PBA_SAMPLE_WAVES_PER_SIMD 3
+#endif
+
 namespace pba {
 
 // Agent-scope relaxed 8-byte store / load (gfx950: write-through `sc1` store, L1-bypassing `sc1` load).  Used for the
@@ -542,9 +548,21 @@ struct SampleParams {
 //   FUSED      : the workgroup first back-substitutes the step for its own (whole) points
 //                (SchurEliminator::BackSubstitute), samples at the candidate it just formed, and the last workgroup
 //                to finish reduces the per-block partials in a fixed order and publishes the step's scalar block.
-template <int R, bool JAC, int WAVES, bool FUSED, bool UNITW>
-__global__ __launch_bounds__(WAVES * 64, (R <= 2 ? (JAC ? 3 : 2) : 1)) void k_sample(SampleParams p_in) {
+//   FAST       : opt-in reduced-precision walk (SampleParams::prec = 1 | 2, unit weights only): NOT reference-exact.
+// Rows of the footprints go through LDS in batches of RB rows (the walk only ever needs ONE footprint row at a time: the
+// horizontal lerps of the previous row live in registers), so that a wave's LDS share stays ~10 KB at every patch radius
+// and 11x11 patches run at the same occupancy and in the same fused form as 5x5 ones.
+constexpr int sample_rows_per_batch(int R) { return R <= 2 ? 2 * R + 2 : (R == 4 ? 5 : 4); }
+constexpr int sample_stage_groups(int ng, int per_group) {
+  int best = 1;
+  for (int g = 1; g <= ng; ++g) if (ng % g == 0 && g * per_group <= 40) best = g;
+  return best;
+}
+
+template <int R, bool JAC, int WAVES, bool FUSED, bool UNITW, bool FAST>
+__global__ __launch_bounds__(WAVES * 64, (R <= 2 ? (JAC ? PBA_SAMPLE_WAVES_PER_SIMD : 2) : 2)) void k_sample(SampleParams p_in) {
   static_assert(!FUSED || (WAVES * 64) % 128 == 0, "fused tiles are 128 observations");
+  static_assert(!FAST || UNITW, "the reduced-precision walk assumes unit patch weights");
   SampleParams p = p_in;
   if (!PBA_PHASE_TIMING) p.dbg = nullptr;
   if (FUSED && p.lm) {
@@ -559,11 +577,14 @@ __global__ __launch_bounds__(WAVES * 64, (R <= 2 ? (JAC ? 3 : 2) : 1)) void k_sa
   }
   constexpr int W = 2 * R + 1;      // patch side
   constexpr int F = 2 * R + 2;      // footprint side
-  constexpr int FF = F * F;
+  constexpr int RB = sample_rows_per_batch(R);   // footprint rows staged per batch
+  constexpr int NB = (F + RB - 1) / RB;
+  constexpr int FF = RB * F;                      // texels of one batch
   // texel-major LDS layout [t][lane]: the walk reads stride-1 across lanes; the odd stride keeps the staging stores of
   // the vector row segments at the 2-way minimum (64 lanes on 32 banks) and four workgroups within 160 KB of LDS.
   constexpr int LSTRIDE = 65;
   constexpr size_t kTexBytes = sizeof(uint32_t) * WAVES * FF * LSTRIDE;
+  static_assert(kTexBytes >= sizeof(double) * 4 * WAVES * 64, "the finalisation reuses the texel region");
   constexpr size_t kPreBytes = sizeof(double) * 3 * WAVES * 64 + 2 * kMaxFrames * sizeof(CamGeom);
   __shared__ __attribute__((aligned(16))) char s_raw[kTexBytes > kPreBytes ? kTexBytes : kPreBytes];
   uint32_t (*s_tex)[FF * LSTRIDE] = reinterpret_cast<uint32_t (*)[FF * LSTRIDE]>(s_raw);
@@ -669,6 +690,8 @@ __global__ __launch_bounds__(WAVES * 64, (R <= 2 ? (JAC ? 3 : 2) : 1)) void k_sa
   // ---- phase 1: geometry, one lane per observation (fp64) ------------------------------------------------
   double u = 0.0, v = 0.0;
   float xf[W], yf[W];
+#pragma unroll
+  for (int j = 0; j < W; ++j) { xf[j] = 0.f; yf[j] = 0.f; }
   int bx = 0, by = 0;
   bool regular = false;
   if (active) {
@@ -693,188 +716,188 @@ __global__ __launch_bounds__(WAVES * 64, (R <= 2 ? (JAC ? 3 : 2) : 1)) void k_sa
   lds_barrier();
   PBA_STK(2);
 
-  // ---- phase 2: cooperative footprint staging global -> LDS ----------------------------------------------
-  // NCH consecutive lanes fetch one footprint row of one observation as CW-texel vectors, so one load instruction
-  // covers row r of OPI observations; the row offset r * cols is wave-uniform and the LDS destination of texel
-  // (r, c) is a compile-time offset from a per-lane base, which leaves almost no address arithmetic per load.
-  // All loads of a batch are issued before the first LDS store so that the L2 latency is paid once per batch.
+  // ---- phases 2 + 3, per batch of RB footprint rows: cooperative staging global -> LDS, then the per-lane walk -----
+  // Staging: NCH consecutive lanes fetch one footprint row of one observation as CW-texel vectors, so one load
+  // instruction covers row r of OPI observations; the row offset r * cols is wave-uniform and the LDS destination of
+  // texel (r, c) is a compile-time offset from a per-lane base, which leaves almost no address arithmetic per load.
+  // All loads of a group batch are issued before the first LDS store so that the L2 latency is paid once per batch.
+  // Walk: separable exact bilinear rule; the horizontal lerps of a footprint row are shared by the two pixel rows that
+  // touch it.  Every wave stages its OWN 64 footprints and walks only those: no workgroup barrier, the waves drift apart.
   constexpr int CW = (F % 4 == 0) ? 4 : (F % 3 == 0 ? 3 : 2);
   constexpr int NCH = F / CW;
   constexpr int OPI = 64 / NCH;
   constexpr int NG = (64 + OPI - 1) / OPI;
-  constexpr int GB0 = 40 / (F * CW);
-  constexpr int GB = GB0 < 1 ? 1 : (GB0 > NG ? NG : GB0);
-  static_assert(NG % GB == 0, "footprint batches");
-  {
-    const int ch = lane % NCH, oi = lane / NCH;
-    const char* fbytes = reinterpret_cast<const char*>(p.frames);
+  constexpr int GB = sample_stage_groups(NG, RB * CW);
+  constexpr int NPL = JAC ? 3 : 1;
+  double m11 = 0, m12 = 0, m22 = 0, b1 = 0, b2 = 0, cc = 0;
+  const bool walk = active && regular;
+  const float* p0 = p.desc + (size_t)pt * (W * W);
+  float dxs[W], dys[W];
+  double omdx[W];
+  double Hp[FAST ? 1 : NPL][W];
+  float fHp[FAST ? NPL : 1][W];
+  float fa11 = 0.f, fa12 = 0.f, fa22 = 0.f, fc1 = 0.f, fc2 = 0.f, fc0 = 0.f;
+  const bool bf16 = FAST && p.prec == 2;
+  auto rnd = [&](float v) {      // round-to-nearest-even to 8 significant bits (bf16), only in the sweep's third mode
+    if (!bf16) return v;
+    unsigned u = __float_as_uint(v);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return __uint_as_float(u & 0xffff0000u);
+  };
+#pragma unroll
+  for (int j = 0; j < W; ++j) {
+    dxs[j] = __fsub_rn((float)(bx + j + 1), xf[j]);
+    dys[j] = __fsub_rn((float)(by + j + 1), yf[j]);
+    omdx[j] = __dsub_rn(1.0, (double)dxs[j]);
+  }
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int r0 = b * RB;
+    const int nr = (F - r0 < RB) ? F - r0 : RB;
+    {
+      const int ch = lane % NCH, oi = lane / NCH;
+      const char* fbytes = reinterpret_cast<const char*>(p.frames);
 #pragma unroll 1
-    for (int g0 = 0; g0 < NG; g0 += GB) {
-      uint32_t tx[GB][F][CW];
-      int32_t bs[GB];
+      for (int g0 = 0; g0 < NG; g0 += GB) {
+        uint32_t tx[GB][RB][CW];
+        int32_t bs[GB];
 #pragma unroll
-      for (int gg = 0; gg < GB; ++gg) {
-        const int o = (g0 + gg) * OPI + oi;
-        bs[gg] = (oi < OPI && o < 64) ? s_base[wave][o & 63] : -1;
-        const uint32_t boff = ((uint32_t)bs[gg] + (uint32_t)(ch * CW)) * 4u;
+        for (int gg = 0; gg < GB; ++gg) {
+          const int o = (g0 + gg) * OPI + oi;
+          bs[gg] = (oi < OPI && o < 64) ? s_base[wave][o & 63] : -1;
+          const uint32_t boff = ((uint32_t)bs[gg] + (uint32_t)(ch * CW)) * 4u;
 #pragma unroll
-        for (int r = 0; r < F; ++r) {
+          for (int rr = 0; rr < RB; ++rr) {
+            if (rr >= nr) continue;
 #pragma unroll
-          for (int j = 0; j < CW; ++j) tx[gg][r][j] = 0;
-          if (bs[gg] >= 0) __builtin_memcpy(tx[gg][r], fbytes + (boff + (uint32_t)(r * p.cols) * 4u), sizeof(uint32_t) * CW);
+            for (int j = 0; j < CW; ++j) tx[gg][rr][j] = 0;
+            if (bs[gg] >= 0) __builtin_memcpy(tx[gg][rr], fbytes + (boff + (uint32_t)((r0 + rr) * p.cols) * 4u), sizeof(uint32_t) * CW);
+          }
         }
-      }
 #pragma unroll
-      for (int gg = 0; gg < GB; ++gg) {
-        const int o = (g0 + gg) * OPI + oi;
-        if (bs[gg] >= 0) {
-          uint32_t* dst = &s_tex[wave][(ch * CW) * LSTRIDE + o];
+        for (int gg = 0; gg < GB; ++gg) {
+          const int o = (g0 + gg) * OPI + oi;
+          if (bs[gg] >= 0) {
+            uint32_t* dst = &s_tex[wave][(ch * CW) * LSTRIDE + o];
 #pragma unroll
-          for (int r = 0; r < F; ++r)
+            for (int rr = 0; rr < RB; ++rr) {
+              if (rr >= nr) continue;
 #pragma unroll
-            for (int j = 0; j < CW; ++j) dst[(r * F + j) * LSTRIDE] = tx[gg][r][j];
+              for (int j = 0; j < CW; ++j) dst[(rr * F + j) * LSTRIDE] = tx[gg][rr][j];
+            }
+          }
         }
       }
     }
-  }
-  // every wave staged its OWN 64 footprints and walks only those: no workgroup barrier, the waves drift apart freely
-  wave_lds_sync();
-
-  PBA_STK(3);
-  // ---- phase 3: per-lane patch walk ------------------------------------------------------------------------
-  double m11 = 0, m12 = 0, m22 = 0, b1 = 0, b2 = 0, cc = 0;
-  if (active) {
-    const float* p0 = p.desc + (size_t)pt * (W * W);
-    if (regular && UNITW && p.prec != 0) {
-      // ---- reduced-precision walk (opt-in, BASELINE configs[4] tolerance sweep; NOT bit-compatible with the reference):
-      //   prec 1: fp32 interpolation and fp32 accumulation of M, b, c;  prec 2: additionally the residual and the
-      //   gradients are rounded to bf16 before they enter the (fp32) accumulation.
-      float dxs[W], dys[W];
+    wave_lds_sync();
+    if (b == 0) PBA_STK(3);
+    if (walk) {
 #pragma unroll
-      for (int j = 0; j < W; ++j) { dxs[j] = (float)(bx + j + 1) - xf[j]; dys[j] = (float)(by + j + 1) - yf[j]; }
-      constexpr int NPL = JAC ? 3 : 1;
-      float Hp[NPL][W], Hc[NPL][W];
-      float a11 = 0.f, a12 = 0.f, a22 = 0.f, c1 = 0.f, c2 = 0.f, c0 = 0.f;
-      const bool bf16 = p.prec == 2;
-      auto rnd = [&](float v) {      // round-to-nearest-even to 8 significant bits (bf16), only in the sweep's third mode
-        if (!bf16) return v;
-        unsigned u = __float_as_uint(v);
-        u += 0x7fffu + ((u >> 16) & 1u);
-        return __uint_as_float(u & 0xffff0000u);
-      };
-#pragma unroll
-      for (int r = 0; r < F; ++r) {
+      for (int rr = 0; rr < RB; ++rr) {
+        if (rr >= nr) continue;
+        const int r = r0 + rr;
         uint32_t t[F];
 #pragma unroll
-        for (int c = 0; c < F; ++c) t[c] = s_tex[wave][(r * F + c) * LSTRIDE + lane];
-#pragma unroll
-        for (int j = 0; j < W; ++j) {
-          const float om = 1.0f - dxs[j];
-          Hc[0][j] = fmaf(dxs[j], tex_I(t[j]), om * tex_I(t[j + 1]));
-          if (JAC) {
-            Hc[1][j] = fmaf(dxs[j], tex_gx2(t[j]), om * tex_gx2(t[j + 1]));
-            Hc[2][j] = fmaf(dxs[j], tex_gy2(t[j]), om * tex_gy2(t[j + 1]));
-          }
-        }
-        if (r >= 1) {
-          const int i = r - 1;
-          const float dy = dys[i], omdy = 1.0f - dy;
+        for (int c = 0; c < F; ++c) t[c] = s_tex[wave][(rr * F + c) * LSTRIDE + lane];
+        // column by column: the horizontal lerps of column j are consumed against the previous row's and then replace
+        // them, so only one row of lerps is ever live (the sums still run over j in ascending order)
+        const int i = r - 1;
+        if (FAST) {
+          // ---- reduced-precision walk (opt-in, BASELINE configs[4] tolerance sweep; NOT bit-compatible with the
+          //   reference): prec 1: fp32 interpolation and fp32 accumulation of M, b, c;  prec 2: additionally the
+          //   residual and the gradients are rounded to bf16 before they enter the (fp32) accumulation.
+          const float dy = dys[r >= 1 ? i : 0], omdy = 1.0f - dy;
 #pragma unroll
           for (int j = 0; j < W; ++j) {
-            const float sI = fmaf(dy, Hp[0][j], omdy * Hc[0][j]);
-            const float e = rnd(p0[i * W + j] - sI);
-            c0 = fmaf(e, e, c0);
+            const float om = 1.0f - dxs[j];
+            const float h0 = fmaf(dxs[j], tex_I(t[j]), om * tex_I(t[j + 1]));
+            float h1 = 0.f, h2 = 0.f;
             if (JAC) {
-              const float gx = rnd(fmaf(dy, Hp[1][j], omdy * Hc[1][j]));
-              const float gy = rnd(fmaf(dy, Hp[2][j], omdy * Hc[2][j]));
-              a11 = fmaf(gx, gx, a11); a12 = fmaf(gx, gy, a12); a22 = fmaf(gy, gy, a22);
-              c1 = fmaf(gx, e, c1); c2 = fmaf(gy, e, c2);
+              h1 = fmaf(dxs[j], tex_gx2(t[j]), om * tex_gx2(t[j + 1]));
+              h2 = fmaf(dxs[j], tex_gy2(t[j]), om * tex_gy2(t[j + 1]));
             }
+            if (r >= 1) {
+              const float sI = fmaf(dy, fHp[0][j], omdy * h0);
+              const float e = rnd(p0[i * W + j] - sI);
+              fc0 = fmaf(e, e, fc0);
+              if (JAC) {
+                const float gx = rnd(fmaf(dy, fHp[NPL > 1 ? 1 : 0][j], omdy * h1));
+                const float gy = rnd(fmaf(dy, fHp[NPL > 2 ? 2 : 0][j], omdy * h2));
+                fa11 = fmaf(gx, gx, fa11); fa12 = fmaf(gx, gy, fa12); fa22 = fmaf(gy, gy, fa22);
+                fc1 = fmaf(gx, e, fc1); fc2 = fmaf(gy, e, fc2);
+              }
+            }
+            fHp[0][j] = h0;
+            if (JAC) { fHp[NPL > 1 ? 1 : 0][j] = h1; fHp[NPL > 2 ? 2 : 0][j] = h2; }
           }
-        }
-#pragma unroll
-        for (int pl = 0; pl < NPL; ++pl)
-#pragma unroll
-          for (int j = 0; j < W; ++j) Hp[pl][j] = Hc[pl][j];
-      }
-      cc = (double)c0;
-      if (JAC) { m11 = 0.25 * (double)a11; m12 = 0.25 * (double)a12; m22 = 0.25 * (double)a22; b1 = 0.5 * (double)c1; b2 = 0.5 * (double)c2; }
-    } else if (regular) {
-      float dxs[W], dys[W];
-      double omdx[W];
-#pragma unroll
-      for (int j = 0; j < W; ++j) {
-        dxs[j] = __fsub_rn((float)(bx + j + 1), xf[j]);
-        dys[j] = __fsub_rn((float)(by + j + 1), yf[j]);
-        omdx[j] = __dsub_rn(1.0, (double)dxs[j]);
-      }
-      constexpr int NPL = JAC ? 3 : 1;
-      double Hp[NPL][W], Hc[NPL][W];
-#pragma unroll
-      for (int r = 0; r < F; ++r) {
-        uint32_t t[F];
-#pragma unroll
-        for (int c = 0; c < F; ++c) t[c] = s_tex[wave][(r * F + c) * LSTRIDE + lane];
-#pragma unroll
-        for (int j = 0; j < W; ++j) {
-          Hc[0][j] = hlerp_exact(dxs[j], omdx[j], tex_I(t[j]), tex_I(t[j + 1]));
-          if (JAC) {
-            Hc[1][j] = hlerp_exact(dxs[j], omdx[j], tex_gx2(t[j]), tex_gx2(t[j + 1]));
-            Hc[2][j] = hlerp_exact(dxs[j], omdx[j], tex_gy2(t[j]), tex_gy2(t[j + 1]));
-          }
-        }
-        if (r >= 1) {
-          const int i = r - 1;
-          const float dy = dys[i];
+        } else {
+          const float dy = dys[r >= 1 ? i : 0];
           const float omdy = __fsub_rn(1.0f, dy);
 #pragma unroll
           for (int j = 0; j < W; ++j) {
-            const float sI = vlerp_exact(dy, omdy, Hp[0][j], Hc[0][j]);
-            const double e = (double)p0[i * W + j] - (double)sI;   // photobundle.cc:720 (i0 - i1)
-            if (UNITW) {
-              cc = fma(e, e, cc);
-              if (JAC) {
-                // gradients stay in "2G" units here; the exact power-of-two scales are applied to the sums below
-                const double gx = (double)vlerp_exact(dy, omdy, Hp[1][j], Hc[1][j]);
-                const double gy = (double)vlerp_exact(dy, omdy, Hp[2][j], Hc[2][j]);
-                m11 = fma(gx, gx, m11); m12 = fma(gx, gy, m12); m22 = fma(gy, gy, m22);
-                b1 = fma(gx, e, b1); b2 = fma(gy, e, b2);
-              }
-            } else {
-              const double w2 = p.w2[i * W + j];
-              cc += w2 * e * e;
-              if (JAC) {
-                const double gx = (double)vlerp_exact(dy, omdy, Hp[1][j], Hc[1][j]);
-                const double gy = (double)vlerp_exact(dy, omdy, Hp[2][j], Hc[2][j]);
-                const double wgx = w2 * gx, wgy = w2 * gy;
-                m11 += wgx * gx; m12 += wgx * gy; m22 += wgy * gy;
-                b1 += wgx * e; b2 += wgy * e;
+            const double h0 = hlerp_exact(dxs[j], omdx[j], tex_I(t[j]), tex_I(t[j + 1]));
+            double h1 = 0.0, h2 = 0.0;
+            if (JAC) {
+              h1 = hlerp_exact(dxs[j], omdx[j], tex_gx2(t[j]), tex_gx2(t[j + 1]));
+              h2 = hlerp_exact(dxs[j], omdx[j], tex_gy2(t[j]), tex_gy2(t[j + 1]));
+            }
+            if (r >= 1) {
+              const float sI = vlerp_exact(dy, omdy, Hp[0][j], h0);
+              const double e = (double)p0[i * W + j] - (double)sI;   // photobundle.cc:720 (i0 - i1)
+              if (UNITW) {
+                cc = fma(e, e, cc);
+                if (JAC) {
+                  // gradients stay in "2G" units here; the exact power-of-two scales are applied to the sums below
+                  const double gx = (double)vlerp_exact(dy, omdy, Hp[NPL > 1 ? 1 : 0][j], h1);
+                  const double gy = (double)vlerp_exact(dy, omdy, Hp[NPL > 2 ? 2 : 0][j], h2);
+                  m11 = fma(gx, gx, m11); m12 = fma(gx, gy, m12); m22 = fma(gy, gy, m22);
+                  b1 = fma(gx, e, b1); b2 = fma(gy, e, b2);
+                }
+              } else {
+                const double w2 = p.w2[i * W + j];
+                cc += w2 * e * e;
+                if (JAC) {
+                  const double gx = (double)vlerp_exact(dy, omdy, Hp[NPL > 1 ? 1 : 0][j], h1);
+                  const double gy = (double)vlerp_exact(dy, omdy, Hp[NPL > 2 ? 2 : 0][j], h2);
+                  const double wgx = w2 * gx, wgy = w2 * gy;
+                  m11 += wgx * gx; m12 += wgx * gy; m22 += wgy * gy;
+                  b1 += wgx * e; b2 += wgy * e;
+                }
               }
             }
+            Hp[0][j] = h0;
+            if (JAC) { Hp[NPL > 1 ? 1 : 0][j] = h1; Hp[NPL > 2 ? 2 : 0][j] = h2; }
           }
         }
-#pragma unroll
-        for (int pl = 0; pl < NPL; ++pl)
-#pragma unroll
-          for (int j = 0; j < W; ++j) Hp[pl][j] = Hc[pl][j];
       }
-      if (JAC) { m11 *= 0.25; m12 *= 0.25; m22 *= 0.25; b1 *= 0.5; b2 *= 0.5; }   // (2G)^2 / 4, (2G) e / 2: exact
-    } else {
-      // border / clamped / rounding-irregular observation: per-pixel generic rule from global memory
-      const uint32_t* frame = p.frames + (size_t)slot * p.rows * p.cols;
-      for (int i = 0; i < W; ++i) {
-        for (int j = 0; j < W; ++j) {
-          float sI, sgx = 0.f, sgy = 0.f;
-          sample_generic<JAC>(frame, p.rows, p.cols, yf[i], xf[j], sI, sgx, sgy);
-          const double e = (double)p0[i * W + j] - (double)sI;
-          const double w2 = p.w2[i * W + j];
-          cc += w2 * e * e;
-          if (JAC) {
-            const double gx = (double)sgx, gy = (double)sgy;
-            const double wgx = w2 * gx, wgy = w2 * gy;
-            m11 += wgx * gx; m12 += wgx * gy; m22 += wgy * gy;
-            b1 += wgx * e; b2 += wgy * e;
-          }
+    }
+    if (b + 1 < NB) wave_lds_sync();   // the next batch overwrites the rows just read
+  }
+  if (walk) {
+    if (FAST) {
+      cc = (double)fc0;
+      if (JAC) { m11 = 0.25 * (double)fa11; m12 = 0.25 * (double)fa12; m22 = 0.25 * (double)fa22; b1 = 0.5 * (double)fc1; b2 = 0.5 * (double)fc2; }
+    } else if (JAC) {
+      m11 *= 0.25; m12 *= 0.25; m22 *= 0.25; b1 *= 0.5; b2 *= 0.5;   // (2G)^2 / 4, (2G) e / 2: exact
+    }
+  } else if (active) {
+    // border / clamped / rounding-irregular observation: per-pixel generic rule from global memory
+    const uint32_t* frame = p.frames + (size_t)slot * p.rows * p.cols;
+    // (pixel coordinates re-derived from (u, v) here, so that the xf / yf arrays are dead during the regular walk)
+    for (int i = 0; i < W; ++i) {
+      const float yfi = (float)(v + (double)(i - R));
+      for (int j = 0; j < W; ++j) {
+        const float xfj = (float)(u + (double)(j - R));
+        float sI, sgx = 0.f, sgy = 0.f;
+        sample_generic<JAC>(frame, p.rows, p.cols, yfi, xfj, sI, sgx, sgy);
+        const double e = (double)p0[i * W + j] - (double)sI;
+        const double w2 = p.w2[i * W + j];
+        cc += w2 * e * e;
+        if (JAC) {
+          const double gx = (double)sgx, gy = (double)sgy;
+          const double wgx = w2 * gx, wgy = w2 * gy;
+          m11 += wgx * gx; m12 += wgx * gy; m22 += wgy * gy;
+          b1 += wgx * e; b2 += wgy * e;
         }
       }
     }
@@ -1637,13 +1660,15 @@ __global__ __launch_bounds__(256) void k_solve_wave(SolveParams p_in) {
       // finish column j: only the term with L_j,j-1 (lane j's entry of the previous column) was still missing
       double v = pre0 + pre1;
       if (j > 0) v = fma(-lr_prev, readlane_f64(lr_prev, j), v);
-      const double lrj = (lane > j) ? v * inv : 0.0;
+      // rows <= j are complete: what they compute from here on is never read (their L entries are not published, their
+      // y is frozen by the select below), so the value is not masked to zero
+      const double lrj = v * inv;
       L[j] = lrj;
       lr_prev = lrj;
       // right-hand side, column-oriented forward substitution: z_j = y_j / L_jj, then y_r -= L_rj z_j below
-      if (lane == j) { y *= inv; d_own = inv; }
-      const double zj = readlane_f64(y, j);
-      if (lane > j) y = fma(-lrj, zj, y);
+      const double zj = readlane_f64(y, j) * inv;
+      if (lane == j) d_own = inv;
+      y = (lane > j) ? fma(-lrj, zj, y) : ((lane == j) ? zj : y);
       if (live && lane > j) LT[r * LE + j] = lrj;
       diag = fma(-lrj, lrj, diag);
       if (j + 1 < N) {
@@ -1678,9 +1703,11 @@ __global__ __launch_bounds__(256) void k_solve_wave(SolveParams p_in) {
     for (int j = 0; j < N; ++j) lc[j] = (lane < j) ? LT[j * LE + r] : 0.0;
 #pragma unroll
     for (int j = N - 1; j >= 0; --j) {
-      if (lane == j) y *= d_own;
-      const double xj = readlane_f64(y, j);
-      if (lane < j) y = fma(-lc[j], xj, y);
+      // x_j = y_j / L_jj on every lane (inv_j is not kept: d_own of lane j crosses with the value), lc[j] is zero for
+      // lanes >= j
+      const double xj = readlane_f64(y * d_own, j);
+      if (lane == j) y = xj;
+      y = fma(-lc[j], xj, y);
     }
     if (lane < N) y_s[lane] = y;
     if (lane == 0) s_ok = ok ? 1 : 0;
