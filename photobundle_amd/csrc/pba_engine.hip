@@ -630,7 +630,7 @@ int pba_internal_step(pba_engine* e, double radius, int32_t init_scale, const pb
     (void)hipStreamSynchronize(e->stream);
     double avg[8] = {0};
     for (int b = 0; b < e->schur_grid; ++b) for (int k = 0; k < 8; ++k) avg[k] += (double)h[8 * b + k] / e->schur_grid;
-    std::fprintf(stderr, "k_schur phase cycles/block (stage, P1, P2sum, P2, P3a, P3b-write, P3b-acc): %.0f %.0f %.0f %.0f %.0f %.0f %.0f  tiles/block %.2f\n",
+    std::fprintf(stderr, "k_schur phase cycles/block (stage, P1, point totals, P + camera record, camera sums, W|Y write, pair blocks): %.0f %.0f %.0f %.0f %.0f %.0f %.0f  tiles/block %.2f\n",
                  avg[0], avg[1], avg[2], avg[3], avg[4], avg[5], avg[6], (double)e->n_tiles / e->schur_grid);
     {
       const int rem = e->n_tiles % e->schur_grid;   // blocks [0, rem) run one tile more than the others

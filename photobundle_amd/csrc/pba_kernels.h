@@ -552,7 +552,7 @@ struct SampleParams {
 // Rows of the footprints go through LDS in batches of RB rows (the walk only ever needs ONE footprint row at a time: the
 // horizontal lerps of the previous row live in registers), so that a wave's LDS share stays ~10 KB at every patch radius
 // and 11x11 patches run at the same occupancy and in the same fused form as 5x5 ones.
-constexpr int sample_rows_per_batch(int R) { return R <= 2 ? 2 * R + 2 : (R == 4 ? 5 : 4); }
+constexpr int sample_rows_per_batch(int R) { return R <= 2 ? 2 * R + 2 : (R == 4 ? 5 : (R == 5 ? 3 : 4)); }
 constexpr int sample_stage_groups(int ng, int per_group) {
   int best = 1;
   for (int g = 1; g <= ng; ++g) if (ng % g == 0 && g * per_group <= 40) best = g;
@@ -754,6 +754,18 @@ __global__ __launch_bounds__(WAVES * 64, (R <= 2 ? (JAC ? PBA_SAMPLE_WAVES_PER_S
   for (int b = 0; b < NB; ++b) {
     const int r0 = b * RB;
     const int nr = (F - r0 < RB) ? F - r0 : RB;
+    // descriptor rows this batch compares against: issued AHEAD of the texel loads (and of the fences of the staging,
+    // which pin them here), so that they have landed by the time the texels have and the walk never waits on them
+    float pd[RB][W];
+#pragma unroll
+    for (int rr = 0; rr < RB; ++rr) {
+#pragma unroll
+      for (int j = 0; j < W; ++j) pd[rr][j] = 0.f;
+      if (rr < nr && r0 + rr >= 1 && walk) {
+#pragma unroll
+        for (int j = 0; j < W; ++j) pd[rr][j] = p0[(r0 + rr - 1) * W + j];
+      }
+    }
     {
       const int ch = lane % NCH, oi = lane / NCH;
       const char* fbytes = reinterpret_cast<const char*>(p.frames);
@@ -818,7 +830,7 @@ __global__ __launch_bounds__(WAVES * 64, (R <= 2 ? (JAC ? PBA_SAMPLE_WAVES_PER_S
             }
             if (r >= 1) {
               const float sI = fmaf(dy, fHp[0][j], omdy * h0);
-              const float e = rnd(p0[i * W + j] - sI);
+              const float e = rnd(pd[rr][j] - sI);
               fc0 = fmaf(e, e, fc0);
               if (JAC) {
                 const float gx = rnd(fmaf(dy, fHp[NPL > 1 ? 1 : 0][j], omdy * h1));
@@ -843,7 +855,7 @@ __global__ __launch_bounds__(WAVES * 64, (R <= 2 ? (JAC ? PBA_SAMPLE_WAVES_PER_S
             }
             if (r >= 1) {
               const float sI = vlerp_exact(dy, omdy, Hp[0][j], h0);
-              const double e = (double)p0[i * W + j] - (double)sI;   // photobundle.cc:720 (i0 - i1)
+              const double e = (double)pd[rr][j] - (double)sI;   // photobundle.cc:720 (i0 - i1)
               if (UNITW) {
                 cc = fma(e, e, cc);
                 if (JAC) {
@@ -1108,6 +1120,9 @@ __global__ __launch_bounds__(kTile, 2) void k_schur(SchurParams p_in) {
   // written): 40 KB per workgroup => 4 workgroups per CU instead of 3
   static_assert(1024 + kTile * 9 <= kTile * kObsStride && kMaxFrames * sizeof(CamGeom) <= 1024 * sizeof(double), "aliasing fits");
   double* s_vg = s_obs + 1024;                                           // [kTile][9]
+  double* s_tot = s_obs + 1024 + kTile * 9;                              // [<= kTile points][9] point totals
+  uint16_t* s_ptl = reinterpret_cast<uint16_t*>(s_obs + 1024 + 2 * kTile * 9);   // [<= kTile points] first lane | lanes << 8
+  static_assert(1024 + 2 * kTile * 9 + kTile / 4 <= kTile * kObsStride, "point totals fit before W | Y");
   double* s_red = s_obs + kTile * kObsStride;                            // [kTile]
   int8_t* s_lane_of = reinterpret_cast<int8_t*>(s_red + kTile);          // [kMaxFrames (FREE index)][kTile points]: a camera's lanes are contiguous bytes
 
@@ -1126,12 +1141,26 @@ __global__ __launch_bounds__(kTile, 2) void k_schur(SchurParams p_in) {
   double acc[36];
 #pragma unroll
   for (int k = 0; k < 36; ++k) acc[k] = 0.0;
-  // vector owners: thread tid < 6 nf owns entry (camera tid / 6, row tid % 6) of rhs, g_c and diag(U)
-  const int va = (tid < 6 * nf) ? tid / 6 : -1;
-  const int vi = tid % 6;
-  double acc_rhs = 0.0, acc_gc = 0.0, acc_du = 0.0;
+  // camera-side sums: entry e = tid + kTile u  <->  (free camera e / 33, value e % 33) of [U_a (21, packed upper
+  // triangle) | r_a (6) | g_c,a (6)]: every thread sums its (<= kCamAcc) entries over the tile's points
+  constexpr int kCamVals = 33;
+  constexpr int kCamAcc = (kCamVals * (kMaxFrames - 1) + kTile - 1) / kTile;
+  double acc_cam[kCamAcc];
+#pragma unroll
+  for (int u = 0; u < kCamAcc; ++u) acc_cam[u] = 0.0;
   double gmax = 0.0, gn2 = 0.0;
   int fail = 0;
+  // the camera table is the same for every tile but its LDS copy is overwritten by W | Y: kept in registers (one global
+  // read per kernel) and re-staged from there
+  static_assert(sizeof(CamGeom) % 8 == 0, "CamGeom is copied as 8-byte words");
+  constexpr int kGeomRegs = 4;       // covers 10 frames; the words beyond come from global memory (L2) per tile
+  const int n_geom_words = p.n_frames * (int)(sizeof(CamGeom) / 8);
+  unsigned long long greg[kGeomRegs];
+#pragma unroll
+  for (int u = 0; u < kGeomRegs; ++u) {
+    const int k = tid + u * kTile;
+    greg[u] = (k < n_geom_words) ? reinterpret_cast<const unsigned long long*>(p.geom)[k] : 0ull;
+  }
 
   unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tlast = p.dbg ? __builtin_amdgcn_s_memtime() : 0;
@@ -1147,7 +1176,13 @@ __global__ __launch_bounds__(kTile, 2) void k_schur(SchurParams p_in) {
 
     for (int k = tid; k < kMaxFrames * kTile / 4; k += kTile) reinterpret_cast<int32_t*>(s_lane_of)[k] = -1;
     CamGeom* s_geom = reinterpret_cast<CamGeom*>(s_obs);   // P1 only; P2 overwrites the region with W | Y
-    stage_geom<kTile>(p.geom, s_geom, p.n_frames, tid);
+#pragma unroll
+    for (int u = 0; u < kGeomRegs; ++u) {
+      const int k = tid + u * kTile;
+      if (k < n_geom_words) reinterpret_cast<unsigned long long*>(s_geom)[k] = greg[u];
+    }
+    for (int k = tid + kGeomRegs * kTile; k < n_geom_words; k += kTile)
+      reinterpret_cast<unsigned long long*>(s_geom)[k] = reinterpret_cast<const unsigned long long*>(p.geom)[k];
     lds_barrier();
     PBA_TICK(0);
 
@@ -1182,24 +1217,45 @@ __global__ __launch_bounds__(kTile, 2) void k_schur(SchurParams p_in) {
 #pragma unroll
       for (int k = 0; k < 3; ++k) vg[6 + k] = -(Ap[0][k] * b[0] + Ap[1][k] * b[1]);
       if (fa >= 0) s_lane_of[fa * kTile + (pt - pt0)] = (int8_t)tid;
+      if (tid == l0) s_ptl[pt - pt0] = (uint16_t)(l0 | ((l1 - l0) << 8));
     }
     lds_barrier();
     PBA_TICK(1);
 
     // ---- P2: point totals, damping, effective inverse, per-observation Schur factors -------------------
-    double rl[6] = {0, 0, 0, 0, 0, 0}, gcl[6] = {0, 0, 0, 0, 0, 0};
     double V[6] = {0, 0, 0, 0, 0, 0}, gp[3] = {0, 0, 0};
-    if (active) {
-      for (int l = l0; l < l1; ++l) {
-        const double* vg = s_vg + l * 9;
+    // point totals, transposed: thread k <-> (point k / 9, component k % 9) adds that component over the point's
+    // observations in lane order (<= kMaxFrames independent LDS reads), then every lane picks up its point's nine sums
+    for (int k = tid; k < 9 * n_pts; k += kTile) {
+      const int q = k / 9, c = k - 9 * q;
+      const unsigned lc = s_ptl[q];
+      const int ql0 = (int)(lc & 0xffu), qcnt = (int)(lc >> 8);
+      const double* src = s_vg + ql0 * 9 + c;
+      double a = 0.0;
+      double x[8];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) V[k] += vg[k];
+      for (int l = 0; l < 8; ++l) x[l] = src[9 * (l < qcnt ? l : qcnt - 1)];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) gp[k] += vg[6 + k];
+      for (int l = 0; l < 8; ++l) a += (l < qcnt) ? x[l] : 0.0;
+      if (qcnt > 8) {
+#pragma unroll
+        for (int l = 8; l < kMaxFrames; ++l) x[l - 8] = src[9 * (l < qcnt ? l : qcnt - 1)];
+#pragma unroll
+        for (int l = 8; l < kMaxFrames; ++l) a += (l < qcnt) ? x[l - 8] : 0.0;
       }
+      s_tot[k] = a;
+    }
+    lds_barrier();
+    if (active) {
+      const double* tot = s_tot + (pt - pt0) * 9;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) V[k] = tot[k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) gp[k] = tot[6 + k];
     }
     lds_barrier();     // every lane has its point totals: the region may now be overwritten with W | Y
     PBA_TICK(2);
+    double Pm[6] = {0, 0, 0, 0, 0, 0};
     if (active) {
       const bool head = (tid == l0);
       double s[3];
@@ -1229,7 +1285,6 @@ __global__ __launch_bounds__(kTile, 2) void k_schur(SchurParams p_in) {
       const double d2 = a22 - l20 * l20 - l21 * l21;
       pd = pd && d2 > 0.0;
       const double i22 = fast_rsqrt(d2);
-      double Pm[6] = {0, 0, 0, 0, 0, 0};
       if (pd) {
         const double i10 = -l10 * i00 * i11;
         const double i21 = -l21 * i11 * i22;
@@ -1254,26 +1309,79 @@ __global__ __launch_bounds__(kTile, 2) void k_schur(SchurParams p_in) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) { gmax = fmax(gmax, fabs(gp[k])); gn2 += gp[k] * gp[k]; }
       }
-      // W_l = Ac^T M Ap (6x3), Y_l = W_l P (6x3), r_l = g_c,l - Y_l g_p, g_c,l = -Ac^T b
-      if (fa >= 0) {
-        double* so = s_obs + tid * kObsStride;
+    }
+    // camera-side record [U_l | r_l | g_c,l] first; W_l = Ac^T M Ap (6x3) is only formed row by row here (r_l = g_c,l -
+    // W_l (P g_p)) and again, together with Y_l = W_l P, when the pair goes to LDS after the camera-side sums: Ac, M Ap
+    // and P are what stays in registers in between, and nothing of it survives into the pair-block phase, where the
+    // register pressure peaks
+    if (active && fa >= 0) {
+      double* so = s_obs + tid * kObsStride;
+      const double Pg[3] = {Pm[0] * gp[0] + Pm[1] * gp[1] + Pm[2] * gp[2], Pm[1] * gp[0] + Pm[3] * gp[1] + Pm[4] * gp[2],
+                            Pm[2] * gp[0] + Pm[4] * gp[1] + Pm[5] * gp[2]};
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
-          const double w0 = Ac[0][j] * MAp[0][0] + Ac[1][j] * MAp[1][0];
-          const double w1 = Ac[0][j] * MAp[0][1] + Ac[1][j] * MAp[1][1];
-          const double w2 = Ac[0][j] * MAp[0][2] + Ac[1][j] * MAp[1][2];
-          const double y0 = w0 * Pm[0] + w1 * Pm[1] + w2 * Pm[2];
-          const double y1 = w0 * Pm[1] + w1 * Pm[3] + w2 * Pm[4];
-          const double y2 = w0 * Pm[2] + w1 * Pm[4] + w2 * Pm[5];
-          so[3 * j] = w0; so[3 * j + 1] = w1; so[3 * j + 2] = w2;
-          so[18 + 3 * j] = y0; so[18 + 3 * j + 1] = y1; so[18 + 3 * j + 2] = y2;
-          gcl[j] = -(Ac[0][j] * b[0] + Ac[1][j] * b[1]);
-          rl[j] = gcl[j] - (y0 * gp[0] + y1 * gp[1] + y2 * gp[2]);
+      for (int j = 0; j < 6; ++j) {
+        const double w0 = Ac[0][j] * MAp[0][0] + Ac[1][j] * MAp[1][0];
+        const double w1 = Ac[0][j] * MAp[0][1] + Ac[1][j] * MAp[1][1];
+        const double w2 = Ac[0][j] * MAp[0][2] + Ac[1][j] * MAp[1][2];
+        const double gcl = -(Ac[0][j] * b[0] + Ac[1][j] * b[1]);     // g_c,l = -Ac^T b
+        so[27 + j] = gcl;
+        so[21 + j] = gcl - (w0 * Pg[0] + w1 * Pg[1] + w2 * Pg[2]);
+      }
+      // U_l = Ac^T M Ac (packed upper triangle)
+      double MAc[2][6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) { MAc[0][j] = M[0] * Ac[0][j] + M[1] * Ac[1][j]; MAc[1][j] = M[1] * Ac[0][j] + M[2] * Ac[1][j]; }
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = i; j < 6; ++j) so[sym6(i, j)] = Ac[0][i] * MAc[0][j] + Ac[1][i] * MAc[1][j];
+    }
+    lds_barrier();
+    PBA_TICK(3);
+
+    // ---- P3b: camera-side sums of [U_l | r_l | g_c,l] by camera -------------------------------------------------
+#pragma unroll
+    for (int u = 0; u < kCamAcc; ++u) {
+      const int e = tid + u * kTile;
+      if (e < kCamVals * nf) {
+        const int a = e / kCamVals, v = e - a * kCamVals;
+        for (int q0 = 0; q0 < n_pts; q0 += 16) {
+          // 16 lane indices of camera a in one 128-bit read, then independent loads, then the adds in point order
+          const int4 l4 = *reinterpret_cast<const int4*>(s_lane_of + a * kTile + q0);
+          const int lw[4] = {l4.x, l4.y, l4.z, l4.w};
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            double x[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              const int la = (int)(int8_t)((lw[2 * h + (k >> 2)] >> (8 * (k & 3))) & 0xff);
+              const bool ok = (q0 + 8 * h + k < n_pts) && la >= 0;
+              const double val = s_obs[(ok ? la : 0) * kObsStride + v];
+              x[k] = ok ? val : 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc_cam[u] += x[k];
+          }
         }
       }
     }
     lds_barrier();
-    PBA_TICK(3);
+    PBA_TICK(4);
+    if (active && fa >= 0) {
+      double* so = s_obs + tid * kObsStride;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const double w0 = Ac[0][j] * MAp[0][0] + Ac[1][j] * MAp[1][0];
+        const double w1 = Ac[0][j] * MAp[0][1] + Ac[1][j] * MAp[1][1];
+        const double w2 = Ac[0][j] * MAp[0][2] + Ac[1][j] * MAp[1][2];
+        so[3 * j] = w0; so[3 * j + 1] = w1; so[3 * j + 2] = w2;
+        so[18 + 3 * j] = w0 * Pm[0] + w1 * Pm[1] + w2 * Pm[2];
+        so[18 + 3 * j + 1] = w0 * Pm[1] + w1 * Pm[3] + w2 * Pm[4];
+        so[18 + 3 * j + 2] = w0 * Pm[2] + w1 * Pm[4] + w2 * Pm[5];
+      }
+    }
+    lds_barrier();
+    PBA_TICK(5);
 
     // ---- P3a: block owners: T(a, b) -= Y_la W_lb^T over this group's points ----------------------------------
     if (owner) {
@@ -1293,59 +1401,6 @@ __global__ __launch_bounds__(kTile, 2) void k_schur(SchurParams p_in) {
           for (int j = 0; j < 6; ++j)
             acc[6 * i + j] -= yy[3 * i] * wb[3 * j] + yy[3 * i + 1] * wb[3 * j + 1] + yy[3 * i + 2] * wb[3 * j + 2];
         }
-      }
-    }
-    lds_barrier();
-    PBA_TICK(4);
-
-    // ---- P3b: camera-side sums: U_l = Ac^T M Ac into the diagonal blocks, rhs, g_c, diag(U) ---------------
-    if (active && fa >= 0) {
-      double* so = s_obs + tid * kObsStride;
-      double MAc[2][6];
-#pragma unroll
-      for (int j = 0; j < 6; ++j) { MAc[0][j] = M[0] * Ac[0][j] + M[1] * Ac[1][j]; MAc[1][j] = M[1] * Ac[0][j] + M[2] * Ac[1][j]; }
-#pragma unroll
-      for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int j = i; j < 6; ++j) so[sym6(i, j)] = Ac[0][i] * MAc[0][j] + Ac[1][i] * MAc[1][j];
-#pragma unroll
-      for (int j = 0; j < 6; ++j) { so[21 + j] = rl[j]; so[27 + j] = gcl[j]; }
-    }
-    lds_barrier();
-    PBA_TICK(5);
-    if (owner && pa == pb) {
-      const int8_t* la_row = s_lane_of + pa * kTile;
-      for (int q = grp; q < n_pts; q += n_groups) {
-        const int la = la_row[q];
-        if (la < 0) continue;
-        const double* U = s_obs + la * kObsStride;
-        double u[21];
-#pragma unroll
-        for (int k = 0; k < 21; ++k) u[k] = U[k];
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-#pragma unroll
-          for (int j = 0; j < 6; ++j) acc[6 * i + j] += u[sym6(i, j)];
-      }
-    }
-    if (va >= 0) {
-      const int du_idx = sym6(vi, vi);
-      for (int q0 = 0; q0 < n_pts; q0 += 8) {
-        // 8 lane indices of camera va in one 64-bit read, then independent loads, then the adds in point order
-        const int2 l2 = *reinterpret_cast<const int2*>(s_lane_of + va * kTile + q0);
-        const int lw[2] = {l2.x, l2.y};
-        double r[8], g[8], d[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const int la = (int)(int8_t)((lw[k >> 2] >> (8 * (k & 3))) & 0xff);
-          const bool ok = (q0 + k < n_pts) && la >= 0;
-          const double* so = s_obs + (ok ? la : 0) * kObsStride;
-          r[k] = ok ? so[21 + vi] : 0.0;
-          g[k] = ok ? so[27 + vi] : 0.0;
-          d[k] = ok ? so[du_idx] : 0.0;
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { acc_rhs += r[k]; acc_gc += g[k]; acc_du += d[k]; }
       }
     }
     lds_barrier();
@@ -1369,14 +1424,37 @@ __global__ __launch_bounds__(kTile, 2) void k_schur(SchurParams p_in) {
 #pragma unroll
       for (int k = 0; k < 36; ++k) acc[k] += src[k];
     }
+  }
+  lds_barrier();
+  // camera-side sums -> LDS: the owners of the diagonal blocks add U_a, the vector entries go out directly
+  const int n = 6 * nf;
+  double* s_cam = s_obs;                                                   // [nf][kCamVals]
+#pragma unroll
+  for (int u = 0; u < kCamAcc; ++u) {
+    const int e = tid + u * kTile;
+    if (e < kCamVals * nf) {
+      s_cam[e] = acc_cam[u];
+      const int a = e / kCamVals, v = e - a * kCamVals;
+      if (v >= 27) out[36 * p.n_pairs + n + 6 * a + (v - 27)] = acc_cam[u];            // g_c
+      else if (v >= 21) out[36 * p.n_pairs + 6 * a + (v - 21)] = acc_cam[u];          // rhs
+      else {
+        // packed upper triangle: entry v is a diagonal (i, i) iff v == sym6(i, i) = 6 i - i (i - 1) / 2
+#pragma unroll
+        for (int i = 0; i < 6; ++i) if (v == 6 * i - (i * (i - 1)) / 2) out[36 * p.n_pairs + 2 * n + 6 * a + i] = acc_cam[u];   // diag(U)
+      }
+    }
+  }
+  lds_barrier();
+  if (owner && grp == 0) {
+    if (pa == pb) {
+      const double* U = s_cam + pa * kCamVals;
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) acc[6 * i + j] += U[sym6(i, j)];
+    }
 #pragma unroll
     for (int k = 0; k < 36; ++k) out[pair * 36 + k] = acc[k];
-  }
-  const int n = 6 * nf;
-  if (va >= 0) {
-    out[36 * p.n_pairs + tid] = acc_rhs;
-    out[36 * p.n_pairs + n + tid] = acc_gc;
-    out[36 * p.n_pairs + 2 * n + tid] = acc_du;
   }
   lds_barrier();
   // block reductions of the point-gradient statistics (butterfly per wave, then the two waves in order)
