@@ -123,3 +123,76 @@ def test_rccl_collectives_on_the_device_stream(tmp_path):
     assert int(outs["plain"]["conv_type"]) == 0 and len(outs["plain"]["conv_costs"]) < 200
     assert np.array_equal(outs["multi_async"]["conv_costs"], outs["plain"]["conv_costs"])
     assert int(outs["multi_async"]["conv_type"]) == 0
+
+
+# ---- two DISTINCT devices over RCCL with the asynchronous driver (runs wherever >= 2 GPUs are visible) -------------
+def _worker_rccl(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["PBA_WAIT_TIMEOUT_S"] = "60"          # a mismatch in enqueued collectives becomes PBA_ERR_COMM, not a hang
+    import torch
+    import torch.distributed as dist
+    from photobundle_amd.engine import Engine, default_solver_options
+    from gpu_util import make_engine
+    torch.cuda.set_device(rank)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    uid = [Engine.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(uid, src=0)
+    p = _make()
+    sh = p.shard(rank, world)
+    e = make_engine(sh, device=rank, keep_reduced_system=True)
+    e.comm_init_rccl(uid[0], rank, world)
+    out = {}
+    # (1) fixed iteration count, (2) tolerance-terminated (every rank must stop after the same number of enqueued steps)
+    res = e.solve(default_solver_options(max_num_iterations=8))
+    out.update(cams=res["cams"], xyz=res["xyz"], costs=np.array([i["cost"] for i in res["iterations"]]),
+               ok=np.array([i["step_is_successful"] for i in res["iterations"]]), nres=res["num_residuals"])
+    e.load(sh)
+    conv = e.solve(default_solver_options(max_num_iterations=200, function_tolerance=1e-4))
+    out.update(conv_costs=np.array([i["cost"] for i in conv["iterations"]]), conv_type=conv["termination_type"],
+               conv_cams=conv["cams"])
+    np.savez(os.path.join(out_dir, "rccl_rank%d.npz" % rank), **out)
+    e.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_devices_over_rccl_async_driver(tmp_path):
+    """Two processes, two distinct GPUs, device-direct ncclAllReduce on the engines' streams, asynchronous driver (the
+    default at world > 1): fixed-length and tolerance-terminated solves against the single-rank run."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL refuses two ranks on one device)")
+    import torch.multiprocessing as mp
+    from photobundle_amd.engine import default_solver_options
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from gpu_util import make_engine
+    world = 2
+    port = 29500 + ((os.getpid() + 31) % 2000)
+    mp.spawn(_worker_rccl, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    p = _make()
+    with make_engine(p) as e:
+        ref = e.solve(default_solver_options(max_num_iterations=8))
+        e.load(p)
+        ref_conv = e.solve(default_solver_options(max_num_iterations=200, function_tolerance=1e-4))
+    r0 = np.load(tmp_path / "rccl_rank0.npz")
+    r1 = np.load(tmp_path / "rccl_rank1.npz")
+    assert np.array_equal(r0["cams"], r1["cams"]) and np.array_equal(r0["costs"], r1["costs"]) and np.array_equal(r0["ok"], r1["ok"])
+    ref_costs = np.array([i["cost"] for i in ref["iterations"]])
+    assert len(ref_costs) == len(r0["costs"]) and np.allclose(r0["costs"], ref_costs, rtol=1e-9)
+    assert np.abs(r0["cams"] - ref["cams"]).max() <= 1e-8
+    assert np.abs(np.concatenate([r0["xyz"], r1["xyz"]]) - ref["xyz"]).max() <= 1e-6
+    assert int(r0["nres"]) == ref["num_residuals"]
+    # tolerance-terminated: same trace on both ranks and as the single-rank driver
+    assert np.array_equal(r0["conv_costs"], r1["conv_costs"]) and int(r0["conv_type"]) == int(r1["conv_type"]) == 0
+    rc = np.array([i["cost"] for i in ref_conv["iterations"]])
+    # (the shards sum in a different order than one rank does: a tolerance test within 1e-12 of its threshold may fire
+    # one iteration apart)
+    n = min(len(rc), len(r0["conv_costs"]))
+    assert abs(len(rc) - len(r0["conv_costs"])) <= 1 and np.allclose(r0["conv_costs"][:n], rc[:n], rtol=1e-8)
+    if len(rc) == len(r0["conv_costs"]):
+        assert np.abs(r0["conv_cams"] - ref_conv["cams"]).max() <= 1e-6
