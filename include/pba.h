@@ -18,7 +18,7 @@
  *   cameras  : 6 doubles per window slot = angle-axis (3) + translation (3) of the WORLD->CAMERA
  *              transform (photobundle.cc:646-656 PoseToParams of the inverted pose, :774-778)
  *   points   : 3 doubles, world XYZ (photobundle.cc:795)
- *   desc     : (2R+1)^2 doubles per point, row-major patch of channel 0 (photobundle.cc:466-479,
+ *   desc     : C (2R+1)^2 doubles per point: the row-major patch of every channel, channel-major (photobundle.cc:466-479,
  *              :597-603); values are float casts of pixels, stored as fp32 on the device
  *   obs      : one residual block per (point, slot) entry, grouped by point (photobundle.cc:791-804)
  *   weights  : (2R+1)^2 doubles (photobundle.cc:617-644)
@@ -34,6 +34,7 @@ extern "C" {
 
 #define PBA_MAX_FRAMES 16
 #define PBA_MAX_RADIUS 5
+#define PBA_MAX_CHANNELS 8
 
 typedef struct pba_engine pba_engine;
 
@@ -62,6 +63,11 @@ typedef struct pba_config {
                               * restatement of sample_eigen.h:82-101 (default, the only mode with reference parity),
                               * 1 = fp32 interpolation and accumulation, 2 = fp32 with bf16-rounded residual/gradient
                               * operands.  Modes 1-2 need unit patch weights. */
+  int32_t channels;          /* descriptor channels C (Options::descriptorType, photobundle.cc:229-245): 0 or 1 =
+                              * Intensity (frames arrive as u8 through pba_set_frame_u8); 2..PBA_MAX_CHANNELS = float
+                              * channel images through pba_set_frame_channels_f32 (IntensityAndGradient: 3, BitPlanes: 8).
+                              * Descriptors then hold C patches per point, channel-major (photobundle.cc:597-603). */
+  int32_t reserved;
 } pba_config;
 
 /* ceres::Solver::Options as configured by GetSolverOptions (photobundle.cc:738-761) + the Ceres defaults
@@ -157,6 +163,10 @@ void pba_destroy(pba_engine* e);
  * `image` is the dense row-major rows x cols u8 frame addFrame() receives (photobundle.h:160).  The engine
  * builds its device plane (I, Gx, Gy bit-exactly as imgproc.cc:27-95) and keeps it in window slot `slot`. */
 int pba_set_frame_u8(pba_engine* e, int slot, const uint8_t* image);
+/* Multi-channel descriptors (pba_config.channels = C > 1): `channels` holds the C float channel images DescriptorFrame::
+ * Create produces (photobundle.cc:225-248), [C][rows*cols] row-major; the engine adds every channel's own gradient
+ * images (DescriptorFrame ctor :172-175, imgproc.cc:27-95). */
+int pba_set_frame_channels_f32(pba_engine* e, int slot, int32_t n_channels, const float* channels);
 /* Debug/test readback of the device planes as float I, Gx, Gy (each rows*cols). */
 int pba_get_frame_planes(pba_engine* e, int slot, float* I, float* Gx, float* Gy);
 

@@ -25,7 +25,7 @@ class _Problem(C.Structure):
         ("rows", C.c_int32), ("cols", C.c_int32),
         ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
         ("n_frames", C.c_int32), ("radius", C.c_int32), ("n_points", C.c_int32), ("n_obs", C.c_int32),
-        ("fixed_slot", C.c_int32), ("_pad", C.c_int32),
+        ("fixed_slot", C.c_int32), ("n_channels", C.c_int32),
         ("huber", C.c_double),
         ("planes", C.c_void_p), ("desc", C.c_void_p), ("weights", C.c_void_p),
         ("obs_point", C.c_void_p), ("obs_slot", C.c_void_p),
@@ -104,11 +104,13 @@ class Holder:
         self.cams = _f64(prob.cams if cams is None else cams).copy()
         self.xyz = _f64(prob.xyz if xyz is None else xyz).copy()
         n_frames, three, rows, cols = self.planes.shape
-        assert three == 3
+        n_ch = int(getattr(prob, "channels", 1) or 1)
+        assert three == 3 * n_ch                       # per channel: I, Gx, Gy
         R = int(prob.radius)
-        P = (2 * R + 1) ** 2
+        Ppix = (2 * R + 1) ** 2
+        P = n_ch * Ppix                                # residuals of one block
         assert self.desc.shape == (self.xyz.shape[0], P)
-        assert self.weights.shape == (P,)
+        assert self.weights.shape == (Ppix,)
         assert self.cams.shape == (n_frames, 6)
         assert np.all(np.diff(self.obs_point) >= 0), "observations must be grouped by point"
         s = _Problem()
@@ -117,6 +119,7 @@ class Holder:
         s.n_frames, s.radius = n_frames, R
         s.n_points, s.n_obs = self.xyz.shape[0], self.obs_point.shape[0]
         s.fixed_slot = int(prob.fixed_slot)
+        s.n_channels = n_ch
         s.huber = float(prob.huber)
         s.planes, s.desc, s.weights = _ptr(self.planes), _ptr(self.desc), _ptr(self.weights)
         s.obs_point, s.obs_slot = _ptr(self.obs_point), _ptr(self.obs_slot)
@@ -150,6 +153,50 @@ def imgradient_f32(img):
     gy = np.empty_like(img)
     lib().oracle_imgradient_f32(_ptr(img), rows, cols, _ptr(gx), _ptr(gy))
     return gx, gy
+
+
+DESCRIPTOR_TYPES = {"Intensity": 0, "IntensityAndGradient": 1, "BitPlanes": 2}
+
+
+def descriptor_channels(img, descriptor_type):
+    """u8 frame -> float channel images [C, rows, cols] (DescriptorFrame::Create, photobundle.cc:225-248)."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    rows, cols = img.shape
+    t = DESCRIPTOR_TYPES[descriptor_type] if isinstance(descriptor_type, str) else int(descriptor_type)
+    n = lib().oracle_num_channels(t)
+    out = np.empty((n, rows, cols), np.float32)
+    lib().oracle_descriptor_channels(_ptr(img), rows, cols, t, _ptr(out))
+    return out
+
+
+def channel_planes(channels):
+    """[C, rows, cols] channel images -> [3C, rows, cols]: every channel followed by its own Gx, Gy."""
+    channels = np.ascontiguousarray(channels, dtype=np.float32)
+    n, rows, cols = channels.shape
+    out = np.empty((3 * n, rows, cols), np.float32)
+    lib().oracle_channel_planes(_ptr(channels), n, rows, cols, _ptr(out))
+    return out
+
+
+def census(img):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    out = np.empty_like(img)
+    lib().oracle_census(_ptr(img), img.shape[0], img.shape[1], _ptr(out))
+    return out
+
+
+def gaussian_blur_u8_3x3(img, sigma):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    out = np.empty_like(img)
+    lib().oracle_gaussian_blur_u8_3x3(_ptr(img), img.shape[0], img.shape[1], C.c_double(float(sigma)), _ptr(out))
+    return out
+
+
+def gaussian_blur_f32_5x5(img, sigma):
+    img = np.ascontiguousarray(img, dtype=np.float32)
+    out = np.empty_like(img)
+    lib().oracle_gaussian_blur_f32_5x5(_ptr(img), img.shape[0], img.shape[1], C.c_double(float(sigma)), _ptr(out))
+    return out
 
 
 def sample_linear(planes, y, x):

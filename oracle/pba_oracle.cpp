@@ -219,8 +219,13 @@ inline Dual SampleWithDerivative(const float* I, const float* Gx, const float* G
   return f;
 }
 
+inline int NumChannels(const oracle_problem* p) { return p->n_channels > 0 ? p->n_channels : 1; }
+// residuals of one block: channels x patch pixels (photobundle.cc:692 AutoDiffCostFunction(..., p0.size()))
+inline int BlockRows(const oracle_problem* p) { return NumChannels(p) * (2 * p->radius + 1) * (2 * p->radius + 1); }
+
 // ---------------------------------------------------------------------------------------------
-// DescriptorError::operator() (photobundle.cc:696-727), single channel planes.
+// DescriptorError::operator() (photobundle.cc:696-727): channel-major residuals, the patch weights restart with
+// every channel (the index j of :714 is declared in the row loop's initialiser).
 // ---------------------------------------------------------------------------------------------
 template <class T>
 inline void DescriptorError(const oracle_problem* p, int slot, const double* p0, const T* camera, const T* point,
@@ -235,18 +240,20 @@ inline void DescriptorError(const oracle_problem* p, int slot, const double* p0,
   const T v_w = ((xw[1] * T(p->fy)) / xw[2]) + T(p->cy);
 
   const size_t npix = (size_t)p->rows * p->cols;
-  const float* I = p->planes + (size_t)slot * 3 * npix;
-  const float* Gx = I + npix;
-  const float* Gy = Gx + npix;
-  const int R = p->radius;
+  const int R = p->radius, C = NumChannels(p);
   int i = 0;
-  for (int y = -R, j = 0; y <= R; ++y) {
-    const T v = v_w + T((double)y);
-    for (int x = -R; x <= R; ++x, ++i, ++j) {
-      const T u = u_w + T((double)x);
-      const T i0 = T(p0[i]);
-      const T i1 = SampleWithDerivative(I, Gx, Gy, p->rows, p->cols, u, v);
-      residuals[i] = p->weights[j] * (i0 - i1);
+  for (int k = 0; k < C; ++k) {
+    const float* I = p->planes + ((size_t)slot * C + k) * 3 * npix;   // getChannel(k), getChannelGradient(k)
+    const float* Gx = I + npix;
+    const float* Gy = Gx + npix;
+    for (int y = -R, j = 0; y <= R; ++y) {
+      const T v = v_w + T((double)y);
+      for (int x = -R; x <= R; ++x, ++i, ++j) {
+        const T u = u_w + T((double)x);
+        const T i0 = T(p0[i]);
+        const T i1 = SampleWithDerivative(I, Gx, Gy, p->rows, p->cols, u, v);
+        residuals[i] = p->weights[j] * (i0 - i1);
+      }
     }
   }
 }
@@ -301,7 +308,7 @@ void ProjectionJacobian(const oracle_problem* p, const double* cam, const double
 
 // One block; raw residuals and (optionally) raw Jacobians, row-major P x 6 and P x 3.
 void EvalBlock(const oracle_problem* p, int obs, bool autodiff, double* r, double* Jc, double* Jp) {
-  const int P = (2 * p->radius + 1) * (2 * p->radius + 1);
+  const int P = BlockRows(p);
   const int pt = p->obs_point[obs], slot = p->obs_slot[obs];
   const double* cam = p->cams + 6 * slot;
   const double* X = p->xyz + 3 * (size_t)pt;
@@ -329,22 +336,25 @@ void EvalBlock(const oracle_problem* p, int obs, bool autodiff, double* r, doubl
     double u, v, A[2][9];
     ProjectionJacobian(p, cam, X, &u, &v, A);
     const size_t npix = (size_t)p->rows * p->cols;
-    const float* I = p->planes + (size_t)slot * 3 * npix;
-    const float* Gx = I + npix;
-    const float* Gy = Gx + npix;
-    const int R = p->radius;
+    const int R = p->radius, C = NumChannels(p);
     int i = 0;
-    for (int y = -R; y <= R; ++y) {
-      const double vv = v + (double)y;
-      for (int x = -R; x <= R; ++x, ++i) {
-        const double uu = u + (double)x;
-        float s[3];
-        SampleLinear(I, Gx, Gy, p->rows, p->cols, static_cast<float>(vv), static_cast<float>(uu), s);
-        const double w = p->weights[i];
-        r[i] = w * (p0[i] - (double)s[0]);
-        const double gx = (double)s[1], gy = (double)s[2];
-        if (Jc) for (int k = 0; k < 6; ++k) Jc[6 * i + k] = -w * (gx * A[0][k] + gy * A[1][k]);
-        if (Jp) for (int k = 0; k < 3; ++k) Jp[3 * i + k] = -w * (gx * A[0][6 + k] + gy * A[1][6 + k]);
+    for (int ch = 0; ch < C; ++ch) {
+      const float* I = p->planes + ((size_t)slot * C + ch) * 3 * npix;
+      const float* Gx = I + npix;
+      const float* Gy = Gx + npix;
+      int j = 0;
+      for (int y = -R; y <= R; ++y) {
+        const double vv = v + (double)y;
+        for (int x = -R; x <= R; ++x, ++i, ++j) {
+          const double uu = u + (double)x;
+          float s[3];
+          SampleLinear(I, Gx, Gy, p->rows, p->cols, static_cast<float>(vv), static_cast<float>(uu), s);
+          const double w = p->weights[j];
+          r[i] = w * (p0[i] - (double)s[0]);
+          const double gx = (double)s[1], gy = (double)s[2];
+          if (Jc) for (int k = 0; k < 6; ++k) Jc[6 * i + k] = -w * (gx * A[0][k] + gy * A[1][k]);
+          if (Jp) for (int k = 0; k < 3; ++k) Jp[3 * i + k] = -w * (gx * A[0][6 + k] + gy * A[1][6 + k]);
+        }
       }
     }
   }
@@ -385,7 +395,7 @@ struct Program {
 
   void init(const oracle_problem* prob, bool ad, int nthreads) {
     p = prob; autodiff = ad; threads = std::max(1, nthreads);
-    P = (2 * p->radius + 1) * (2 * p->radius + 1);
+    P = BlockRows(p);
     n_c = p->n_frames; n_p = p->n_points; n_obs = p->n_obs;
     cam_col.assign(n_c, -1);
     int col = 0;
@@ -742,6 +752,132 @@ void oracle_planes_from_u8(const uint8_t* img, int rows, int cols, float* I, flo
   oracle_imgradient_f32(I, rows, cols, Gx, Gy);
 }
 
+// ---- multi-channel descriptors (DescriptorFrame::Create, photobundle.cc:225-248) -----------------------------------
+namespace {
+inline int Reflect101(int i, int n) {
+  if (n == 1) return 0;
+  while (i < 0 || i >= n) { if (i < 0) i = -i; if (i >= n) i = 2 * n - 2 - i; }
+  return i;
+}
+// cv::getGaussianKernel(n, sigma, CV_32F) for sigma > 0: exp(-x^2 / (2 sigma^2)) in double, stored as float, normalised
+// by the (double) sum of the stored floats.
+void GaussianKernelF32(int n, double sigma, float* k) {
+  const double scale2x = -0.5 / (sigma * sigma);
+  double sum = 0.0;
+  for (int i = 0; i < n; ++i) {
+    const double x = i - (n - 1) * 0.5;
+    k[i] = (float)std::exp(scale2x * x * x);
+    sum += k[i];
+  }
+  sum = 1.0 / sum;
+  for (int i = 0; i < n; ++i) k[i] = (float)(k[i] * sum);
+}
+}  // namespace
+
+void oracle_census(const uint8_t* src, int rows, int cols, uint8_t* dst) {
+  // imgproc.cc:126-197: bit b is set when the b-th neighbour (row-major 3x3 order without the centre) >= centre;
+  // first / last row and column are zero
+  std::memset(dst, 0, (size_t)rows * cols);
+  for (int y = 1; y < rows - 1; ++y)
+    for (int x = 1; x < cols - 1; ++x) {
+      const uint8_t* s = src + (size_t)y * cols + x;
+      const uint8_t c = *s;
+      dst[(size_t)y * cols + x] = (uint8_t)(((s[-cols - 1] >= c) ? 0x01 : 0) | ((s[-cols] >= c) ? 0x02 : 0) | ((s[-cols + 1] >= c) ? 0x04 : 0) |
+                                            ((s[-1] >= c) ? 0x08 : 0) | ((s[1] >= c) ? 0x10 : 0) | ((s[cols - 1] >= c) ? 0x20 : 0) |
+                                            ((s[cols] >= c) ? 0x40 : 0) | ((s[cols + 1] >= c) ? 0x80 : 0));
+    }
+}
+
+void oracle_gaussian_blur_u8_3x3(const uint8_t* src, int rows, int cols, double sigma, uint8_t* dst) {
+  // cv::GaussianBlur(8U, Size(3,3), sigma) as OpenCV 2.4 / 3.x run it: the float kernel in 8-bit fixed point
+  // (coefficients cvRound(k * 256)), integer row pass, integer column pass, (sum + 2^15) >> 16, BORDER_REFLECT_101.
+  // (OpenCV is an absent dependency: restated from its documented behaviour, not pinned.)
+  float kf[3];
+  GaussianKernelF32(3, sigma, kf);
+  int k[3];
+  for (int i = 0; i < 3; ++i) k[i] = (int)std::nearbyint((double)kf[i] * 256.0);
+  std::vector<int> tmp((size_t)rows * cols);
+  for (int y = 0; y < rows; ++y)
+    for (int x = 0; x < cols; ++x) {
+      const uint8_t* s = src + (size_t)y * cols;
+      tmp[(size_t)y * cols + x] = k[0] * s[Reflect101(x - 1, cols)] + k[1] * s[x] + k[2] * s[Reflect101(x + 1, cols)];
+    }
+  for (int y = 0; y < rows; ++y)
+    for (int x = 0; x < cols; ++x) {
+      const int v = k[0] * tmp[(size_t)Reflect101(y - 1, rows) * cols + x] + k[1] * tmp[(size_t)y * cols + x] +
+                    k[2] * tmp[(size_t)Reflect101(y + 1, rows) * cols + x];
+      const int r = (v + (1 << 15)) >> 16;
+      dst[(size_t)y * cols + x] = (uint8_t)std::min(255, std::max(0, r));
+    }
+}
+
+void oracle_gaussian_blur_f32_5x5(const float* src, int rows, int cols, double sigma, float* dst) {
+  // cv::GaussianBlur(32F, Size(5,5), sigma): separable, symmetric form k0 c + k1 (l1 + r1) + k2 (l2 + r2) in float,
+  // BORDER_REFLECT_101 (restated, not pinned: OpenCV's vector and scalar paths associate the sum differently)
+  float k[5];
+  GaussianKernelF32(5, sigma, k);
+  std::vector<float> tmp((size_t)rows * cols);
+  for (int y = 0; y < rows; ++y) {
+    const float* s = src + (size_t)y * cols;
+    for (int x = 0; x < cols; ++x) {
+      float v = s[x] * k[2];
+      v += (s[Reflect101(x - 1, cols)] + s[Reflect101(x + 1, cols)]) * k[1];
+      v += (s[Reflect101(x - 2, cols)] + s[Reflect101(x + 2, cols)]) * k[0];
+      tmp[(size_t)y * cols + x] = v;
+    }
+  }
+  for (int y = 0; y < rows; ++y)
+    for (int x = 0; x < cols; ++x) {
+      float v = tmp[(size_t)y * cols + x] * k[2];
+      v += (tmp[(size_t)Reflect101(y - 1, rows) * cols + x] + tmp[(size_t)Reflect101(y + 1, rows) * cols + x]) * k[1];
+      v += (tmp[(size_t)Reflect101(y - 2, rows) * cols + x] + tmp[(size_t)Reflect101(y + 2, rows) * cols + x]) * k[0];
+      dst[(size_t)y * cols + x] = v;
+    }
+}
+
+int oracle_num_channels(int descriptor_type) { return descriptor_type == 1 ? 3 : (descriptor_type == 2 ? 8 : 1); }
+
+void oracle_descriptor_channels(const uint8_t* img, int rows, int cols, int descriptor_type, float* channels) {
+  // DescriptorFrame::Create (photobundle.cc:225-248); descriptor_type: 0 Intensity, 1 IntensityAndGradient, 2 BitPlanes
+  const size_t npix = (size_t)rows * cols;
+  if (descriptor_type == 2) {
+    // computeBitPlanes (imgproc.cc:219-245) with its defaults sigma_ct = 1, sigma_bp = 1.5 (imgproc.h:44-46)
+    std::vector<uint8_t> smooth(npix), census(npix);
+    oracle_gaussian_blur_u8_3x3(img, rows, cols, 1.0, smooth.data());
+    oracle_census(smooth.data(), rows, cols, census.data());
+    std::vector<float> plane(npix);
+    for (int b = 0; b < 8; ++b) {
+      for (size_t i = 0; i < npix; ++i) plane[i] = (float)((census[i] & (1 << b)) >> b);
+      oracle_gaussian_blur_f32_5x5(plane.data(), rows, cols, 1.5, channels + (size_t)b * npix);
+    }
+    return;
+  }
+  for (size_t i = 0; i < npix; ++i) channels[i] = (float)img[i];
+  if (descriptor_type == 1) {
+    // imgradient(u8 image) -> channels 1, 2 (:236-237); destination float => scale 0.5 (imgproc.h:54-58)
+    float* gx = channels + npix;
+    float* gy = channels + 2 * npix;
+    std::memset(gx, 0, sizeof(float) * npix);
+    std::memset(gy, 0, sizeof(float) * npix);
+    for (int y = 1; y < rows - 1; ++y)
+      for (int x = 1; x < cols - 1; ++x) {
+        const uint8_t* s = img + (size_t)y * cols + x;
+        gx[(size_t)y * cols + x] = 0.5f * ((float)s[1] - (float)s[-1]);
+        gy[(size_t)y * cols + x] = 0.5f * ((float)s[cols] - (float)s[-cols]);
+      }
+  }
+}
+
+void oracle_channel_planes(const float* channels, int n_channels, int rows, int cols, float* planes) {
+  // DescriptorFrame ctor (photobundle.cc:172-175): every channel gets its own gradient images
+  const size_t npix = (size_t)rows * cols;
+  for (int k = 0; k < n_channels; ++k) {
+    float* I = planes + (size_t)k * 3 * npix;
+    std::memcpy(I, channels + (size_t)k * npix, sizeof(float) * npix);
+    oracle_imgradient_f32(I, rows, cols, I + npix, I + 2 * npix);
+  }
+}
+
 void oracle_sample_linear(const float* I, const float* Gx, const float* Gy, int rows, int cols, float y, float x,
                           float out[3]) {
   SampleLinear(I, Gx, Gy, rows, cols, y, x, out);
@@ -820,7 +956,7 @@ void oracle_linearize(const oracle_problem* p, int use_autodiff, int num_threads
 
 void oracle_block_products(const oracle_problem* p, int use_autodiff, int num_threads, double* out) {
   // test hook: what one residual block contributes to J^T J and J^T r (ResidualBlock::Evaluate + Corrector applied)
-  const int P = (2 * p->radius + 1) * (2 * p->radius + 1);
+  const int P = BlockRows(p);
 #pragma omp parallel for num_threads(std::max(1, num_threads)) schedule(static)
   for (int o = 0; o < p->n_obs; ++o) {
     std::vector<double> r(P), jc((size_t)P * 6), jp((size_t)P * 3);

@@ -36,10 +36,10 @@ typedef struct oracle_problem {
   int32_t n_points;
   int32_t n_obs;
   int32_t fixed_slot;        /* constant camera (photobundle.cc:809-813), -1 none */
-  int32_t _pad;
+  int32_t n_channels;        /* descriptor channels C (photobundle.cc:229-245); 0 means 1 */
   double huber;              /* HuberLoss(a) if > 0 (photobundle.cc:797-798) */
-  const float* planes;       /* [n_frames][3][rows*cols]: I, Gx, Gy          */
-  const double* desc;        /* [n_points][P] reference descriptors (double) */
+  const float* planes;       /* [n_frames][C][3][rows*cols]: per channel I, Gx, Gy */
+  const double* desc;        /* [n_points][C][P] reference descriptors (double), channel-major */
   const double* weights;     /* [P] patch weights (photobundle.cc:617-644)   */
   const int32_t* obs_point;  /* [n_obs] point index, grouped by point        */
   const int32_t* obs_slot;   /* [n_obs] frame slot                           */
@@ -110,6 +110,18 @@ void oracle_default_options(oracle_options* o);
 /* imgproc.cc:27-95: u8 -> float cast (photobundle.cc:231) + central differences * 0.5, zero border. */
 void oracle_planes_from_u8(const uint8_t* img, int rows, int cols, float* I, float* Gx, float* Gy);
 void oracle_imgradient_f32(const float* img, int rows, int cols, float* Gx, float* Gy);
+
+/* Multi-channel descriptors: DescriptorFrame::Create (photobundle.cc:225-248).  descriptor_type 0 Intensity (1 channel),
+ * 1 IntensityAndGradient (3), 2 BitPlanes (8: census transform of the 3x3-smoothed image, imgproc.cc:126-245, every bit
+ * plane smoothed 5x5).  The two cv::GaussianBlur calls are restated from OpenCV's documented behaviour (absent
+ * dependency, version unpinned): fixed-point 8-bit kernel for the u8 image, symmetric float form for the planes. */
+int oracle_num_channels(int descriptor_type);
+void oracle_descriptor_channels(const uint8_t* img, int rows, int cols, int descriptor_type, float* channels /* [C][rows*cols] */);
+/* [C][3][rows*cols]: every channel followed by ITS gradient images (DescriptorFrame ctor, photobundle.cc:172-175) */
+void oracle_channel_planes(const float* channels, int n_channels, int rows, int cols, float* planes);
+void oracle_census(const uint8_t* src, int rows, int cols, uint8_t* dst);
+void oracle_gaussian_blur_u8_3x3(const uint8_t* src, int rows, int cols, double sigma, uint8_t* dst);
+void oracle_gaussian_blur_f32_5x5(const float* src, int rows, int cols, double sigma, float* dst);
 
 /* sample_eigen.h:56-102 with :34-52 index rule; (y, x) already rounded to float. out = {I, Gx, Gy}. */
 void oracle_sample_linear(const float* I, const float* Gx, const float* Gy, int rows, int cols,

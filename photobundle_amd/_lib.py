@@ -17,7 +17,8 @@ class EngineUnavailable(RuntimeError):
 class Config(C.Structure):
     _fields_ = [("rows", C.c_int32), ("cols", C.c_int32), ("max_frames", C.c_int32), ("radius", C.c_int32),
                 ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
-                ("huber", C.c_double), ("device", C.c_int32), ("flags", C.c_int32)]
+                ("huber", C.c_double), ("device", C.c_int32), ("flags", C.c_int32), ("channels", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 class SolverOptions(C.Structure):
@@ -67,7 +68,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int64, C.c_int32,
 # every symbol include/pba.h declares (tests check the library exports all of them)
 SYMBOLS = [
     "pba_status_string", "pba_last_error", "pba_default_solver_options", "pba_create", "pba_destroy",
-    "pba_set_frame_u8", "pba_get_frame_planes", "pba_set_problem", "pba_set_cameras", "pba_get_state",
+    "pba_set_frame_u8", "pba_set_frame_channels_f32", "pba_get_frame_planes", "pba_set_problem", "pba_set_cameras", "pba_get_state",
     "pba_linearize", "pba_step", "pba_accept", "pba_get_reduced_system", "pba_get_obs_records", "pba_solve",
     "pba_comm_unique_id", "pba_comm_init_rccl", "pba_comm_init_callback", "pba_get_counters", "pba_reset_counters",
 ]
@@ -95,6 +96,7 @@ def lib():
     L.pba_destroy.argtypes = [C.c_void_p]
     L.pba_destroy.restype = None
     L.pba_set_frame_u8.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.pba_set_frame_channels_f32.argtypes = [C.c_void_p, C.c_int, C.c_int32, C.c_void_p]
     L.pba_get_frame_planes.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.pba_set_problem.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.pba_set_cameras.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]

@@ -28,6 +28,9 @@ struct pba_engine {
 
   // frames
   uint32_t* d_frames = nullptr;     // [max_frames][rows*cols] packed texels
+  float4* d_frames_mc = nullptr;    // channels > 1: [max_frames][channels][rows*cols] {value, Gx, Gy, 0}
+  float* d_ch_stage = nullptr;      // [rows*cols] one channel image on its way to d_frames_mc
+  int channels = 1;
   uint8_t* d_img_stage = nullptr;   // [rows*cols]
   uint8_t* h_img_stage = nullptr;   // pinned host copy of the frame being uploaded
   hipEvent_t ev_img_stage = nullptr;
@@ -171,8 +174,25 @@ void launch_sample_r(pba_engine* e, const SampleParams& sp) {
     else hipLaunchKernelGGL((k_sample<R, JAC, kSampleWaves, false, false, false>), dim3(grid), block, 0, e->stream, sp);
   }
 }
+template <int R, bool JAC>
+void launch_sample_mc_r(pba_engine* e, const SampleParams& sp) {
+  hipLaunchKernelGGL((k_sample_mc<R, JAC, kSampleWaves>), dim3(e->sample_grid), dim3(kSampleWaves * 64), 0, e->stream, sp,
+                     (const float4*)e->d_frames_mc, e->channels);
+}
 template <bool JAC, bool FUSED = false>
 void launch_sample(pba_engine* e, const SampleParams& sp) {
+  if (e->channels > 1) {
+    if constexpr (!FUSED) {
+      switch (e->cfg.radius) {
+        case 1: launch_sample_mc_r<1, JAC>(e, sp); break;
+        case 2: launch_sample_mc_r<2, JAC>(e, sp); break;
+        case 3: launch_sample_mc_r<3, JAC>(e, sp); break;
+        case 4: launch_sample_mc_r<4, JAC>(e, sp); break;
+        default: launch_sample_mc_r<5, JAC>(e, sp); break;
+      }
+    }
+    return;
+  }
   switch (e->cfg.radius) {
     case 1: launch_sample_r<1, JAC, FUSED>(e, sp); break;
     case 2: launch_sample_r<2, JAC, FUSED>(e, sp); break;
@@ -183,7 +203,7 @@ void launch_sample(pba_engine* e, const SampleParams& sp) {
 }
 // one kernel for back-substitution + candidate pass + step finalisation, at every patch radius; the opt-in
 // reduced-precision sampler modes (pba_config.flags bits 1-2) keep the unfused kernels
-bool fused_capable(const pba_engine* e) { return e->fuse && ((e->cfg.flags >> 1) & 3) == 0; }
+bool fused_capable(const pba_engine* e) { return e->fuse && ((e->cfg.flags >> 1) & 3) == 0 && e->channels == 1; }
 int sample_waves_for_radius(int) { return kSampleWaves; }
 
 template <int NF>
@@ -317,6 +337,10 @@ int pba_create(const pba_config* cfg, pba_engine** out) {
   if (cfg->rows < 8 || cfg->cols < 8 || cfg->max_frames < 2 || cfg->max_frames > kMaxFrames || cfg->radius < 1 ||
       cfg->radius > kMaxRadius || (int64_t)cfg->rows * cfg->cols * cfg->max_frames >= (1ll << 31))
     return PBA_ERR_INVALID;
+  if (cfg->channels < 0 || cfg->channels > PBA_MAX_CHANNELS ||
+      (int64_t)cfg->rows * cfg->cols * cfg->max_frames * std::max(1, cfg->channels) >= (1ll << 31))
+    return PBA_ERR_INVALID;
+  if (cfg->channels > 1 && ((cfg->flags >> 1) & 3) != 0) return PBA_ERR_INVALID;   // the sweep modes are single-channel
   int n_dev = 0;
   if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0 || cfg->device < 0 || cfg->device >= n_dev) {
     (void)hipGetLastError();
@@ -335,6 +359,12 @@ int pba_create(const pba_config* cfg, pba_engine** out) {
   if (hipHostMalloc(reinterpret_cast<void**>(&e->h_img_stage), npix, hipHostMallocDefault) != hipSuccess) return bail(PBA_ERR_HIP);
   if (hipEventCreateWithFlags(&e->ev_img_stage, hipEventDisableTiming) != hipSuccess) return bail(PBA_ERR_HIP);
   if (hipMemsetAsync(e->d_frames, 0, npix * cfg->max_frames * sizeof(uint32_t), e->stream) != hipSuccess) return bail(PBA_ERR_HIP);
+  e->channels = std::max(1, cfg->channels);
+  if (e->channels > 1) {
+    if ((rc = dev_alloc(e, &e->d_frames_mc, npix * cfg->max_frames * e->channels))) return bail(rc);
+    if ((rc = dev_alloc(e, &e->d_ch_stage, npix))) return bail(rc);
+    if (hipMemsetAsync(e->d_frames_mc, 0, npix * cfg->max_frames * e->channels * sizeof(float4), e->stream) != hipSuccess) return bail(PBA_ERR_HIP);
+  }
   e->frame_set.assign(cfg->max_frames, 0);
   for (int k = 0; k < 2; ++k) {
     if ((rc = dev_alloc(e, &e->d_cams[k], 6 * kMaxFrames))) return bail(rc);
@@ -378,7 +408,7 @@ void pba_destroy(pba_engine* e) {
   (void)hipSetDevice(e->cfg.device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   e->comm.shutdown();
-  dev_free(&e->d_frames); dev_free(&e->d_img_stage);
+  dev_free(&e->d_frames); dev_free(&e->d_img_stage); dev_free(&e->d_frames_mc); dev_free(&e->d_ch_stage);
   for (int k = 0; k < 2; ++k) { dev_free(&e->d_xyz[k]); dev_free(&e->d_cams[k]); dev_free(&e->d_geom[k]); dev_free(&e->d_block_cost[k]); dev_free(&e->d_block_fail[k]); }
   dev_free(&e->d_desc); dev_free(&e->d_w2); dev_free(&e->d_obs_point); dev_free(&e->d_obs_slot); dev_free(&e->d_pt_begin);
   dev_free(&e->d_tile_info); dev_free(&e->d_obs_l0); dev_free(&e->d_obs_cnt); dev_free(&e->d_rec[0]); dev_free(&e->d_rec[1]); dev_free(&e->d_sp); dev_free(&e->d_ptrec); dev_free(&e->d_sc);
@@ -396,8 +426,28 @@ void pba_destroy(pba_engine* e) {
   delete e;
 }
 
+int pba_set_frame_channels_f32(pba_engine* e, int slot, int32_t n_channels, const float* channels) {
+  if (!e || !channels || slot < 0 || slot >= e->cfg.max_frames) return PBA_ERR_INVALID;
+  if (e->channels <= 1 || n_channels != e->channels)
+    return fail(e, PBA_ERR_INVALID, "pba_set_frame_channels_f32: the engine was created for %d channel(s), got %d", e->channels, n_channels);
+  HIP_TRY(e, hipSetDevice(e->cfg.device));
+  const size_t npix = (size_t)e->cfg.rows * e->cfg.cols;
+  dim3 grid((e->cfg.cols + 255) / 256, e->cfg.rows);
+  for (int k = 0; k < n_channels; ++k) {
+    // synchronous per channel (one staging buffer): this is the wide-descriptor path, not the headline one
+    HIP_TRY(e, hipMemcpyAsync(e->d_ch_stage, channels + (size_t)k * npix, npix * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    hipLaunchKernelGGL(k_pack_channel, grid, dim3(256), 0, e->stream, (const float*)e->d_ch_stage,
+                       e->d_frames_mc + ((size_t)slot * n_channels + k) * npix, e->cfg.rows, e->cfg.cols);
+    HIP_TRY(e, hipGetLastError());
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+  }
+  e->frame_set[slot] = 1;
+  return PBA_OK;
+}
+
 int pba_set_frame_u8(pba_engine* e, int slot, const uint8_t* image) {
   if (!e || !image || slot < 0 || slot >= e->cfg.max_frames) return PBA_ERR_INVALID;
+  if (e->channels > 1) return fail(e, PBA_ERR_INVALID, "pba_set_frame_u8: the engine was created for %d channels (pba_set_frame_channels_f32)", e->channels);
   HIP_TRY(e, hipSetDevice(e->cfg.device));
   const size_t npix = (size_t)e->cfg.rows * e->cfg.cols;
   // The caller's buffer is only borrowed for the call: it is copied into a pinned staging buffer here, and the upload +
@@ -418,6 +468,7 @@ int pba_set_frame_u8(pba_engine* e, int slot, const uint8_t* image) {
 
 int pba_get_frame_planes(pba_engine* e, int slot, float* I, float* Gx, float* Gy) {
   if (!e || slot < 0 || slot >= e->cfg.max_frames || !I || !Gx || !Gy) return PBA_ERR_INVALID;
+  if (e->channels > 1) return fail(e, PBA_ERR_INVALID, "pba_get_frame_planes reads the single-channel planes");
   HIP_TRY(e, hipSetDevice(e->cfg.device));
   const size_t npix = (size_t)e->cfg.rows * e->cfg.cols;
   float* d = nullptr;
@@ -437,7 +488,8 @@ int pba_set_problem(pba_engine* e, int32_t n_points, const double* xyz, const do
                     const int32_t* obs_point, const int32_t* obs_slot, const double* weights) {
   if (!e || n_points <= 0 || n_obs <= 0 || !xyz || !desc || !obs_point || !obs_slot || !weights) return PBA_ERR_INVALID;
   HIP_TRY(e, hipSetDevice(e->cfg.device));
-  const int P = (2 * e->cfg.radius + 1) * (2 * e->cfg.radius + 1);
+  const int P = (2 * e->cfg.radius + 1) * (2 * e->cfg.radius + 1);     // pixels of one patch (weights)
+  const int PD = P * e->channels;                                       // descriptor entries per point
   // validate + CSR + tiles (whole points per tile of <= kTile observations)
   std::vector<int32_t> pt_begin(n_points + 1, 0);
   std::vector<uint8_t> slot8(n_obs);
@@ -477,7 +529,7 @@ int pba_set_problem(pba_engine* e, int32_t n_points, const double* xyz, const do
   e->n_obs = n_obs;
   e->ctr.n_obs = n_obs; e->ctr.n_points = n_points;
 
-  std::vector<float> descf((size_t)n_points * P);
+  std::vector<float> descf((size_t)n_points * PD);
   for (size_t i = 0; i < descf.size(); ++i) descf[i] = (float)desc[i];
   std::vector<double> w2(P);
   e->unit_weights = true;
@@ -879,7 +931,7 @@ int pba_internal_world(const pba_engine* e) { return e->comm.world; }
 int pba_internal_rank(const pba_engine* e) { return e->comm.rank; }
 int pba_internal_is_multi(const pba_engine* e) { return e->comm.multi() ? 1 : 0; }
 int64_t pba_internal_local_blocks(const pba_engine* e) { return e->n_obs; }
-int pba_internal_patch_len(const pba_engine* e) { return (2 * e->cfg.radius + 1) * (2 * e->cfg.radius + 1); }
+int pba_internal_patch_len(const pba_engine* e) { return e->channels * (2 * e->cfg.radius + 1) * (2 * e->cfg.radius + 1); }
 // ---- asynchronous driver ----------------------------------------------------------------------------------------
 int pba_internal_async_capable(const pba_engine* e, const pba_solver_options* o) {
   return e->use_async && fused_capable(e) && e->comm.kind != 2 && o->max_num_iterations < pba_engine::kMaxLog - 2 && !e->profile;

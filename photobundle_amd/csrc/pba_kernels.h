@@ -23,6 +23,10 @@
 #ifndef PBA_SAMPLE_WAVES_PER_SIMD
 #define PBA_SAMPLE_WAVES_PER_SIMD 3
 #endif
+// Order of the exact patch walk inside one footprint row (see k_sample): experiment switch
+#ifndef PBA_WALK_ROWWISE
+#define PBA_WALK_ROWWISE 0
+#endif
 
 namespace pba {
 
@@ -552,15 +556,18 @@ struct SampleParams {
 // Rows of the footprints go through LDS in batches of RB rows (the walk only ever needs ONE footprint row at a time: the
 // horizontal lerps of the previous row live in registers), so that a wave's LDS share stays ~10 KB at every patch radius
 // and 11x11 patches run at the same occupancy and in the same fused form as 5x5 ones.
-constexpr int sample_rows_per_batch(int R) { return R <= 2 ? 2 * R + 2 : (R == 4 ? 5 : (R == 5 ? 3 : 4)); }
+constexpr int sample_rows_per_batch(int R) { return R <= 2 ? 2 * R + 2 : (R == 4 ? 5 : 4); }
 constexpr int sample_stage_groups(int ng, int per_group) {
   int best = 1;
   for (int g = 1; g <= ng; ++g) if (ng % g == 0 && g * per_group <= 40) best = g;
   return best;
 }
 
+// amdgpu_waves_per_eu(N, N): the register allocator / scheduler works for exactly N resident waves per SIMD (with only a
+// lower bound it trades instruction-level parallelism for an occupancy the kernel does not profit from: measured).
 template <int R, bool JAC, int WAVES, bool FUSED, bool UNITW, bool FAST>
-__global__ __launch_bounds__(WAVES * 64, (R <= 2 ? (JAC ? PBA_SAMPLE_WAVES_PER_SIMD : 2) : 2)) void k_sample(SampleParams p_in) {
+__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu((R <= 2 ? (JAC ? PBA_SAMPLE_WAVES_PER_SIMD : 2) : 2), (R <= 2 ? (JAC ? PBA_SAMPLE_WAVES_PER_SIMD : 2) : 2))))
+void k_sample(SampleParams p_in) {
   static_assert(!FUSED || (WAVES * 64) % 128 == 0, "fused tiles are 128 observations");
   static_assert(!FAST || UNITW, "the reduced-precision walk assumes unit patch weights");
   SampleParams p = p_in;
@@ -754,18 +761,6 @@ __global__ __launch_bounds__(WAVES * 64, (R <= 2 ? (JAC ? PBA_SAMPLE_WAVES_PER_S
   for (int b = 0; b < NB; ++b) {
     const int r0 = b * RB;
     const int nr = (F - r0 < RB) ? F - r0 : RB;
-    // descriptor rows this batch compares against: issued AHEAD of the texel loads (and of the fences of the staging,
-    // which pin them here), so that they have landed by the time the texels have and the walk never waits on them
-    float pd[RB][W];
-#pragma unroll
-    for (int rr = 0; rr < RB; ++rr) {
-#pragma unroll
-      for (int j = 0; j < W; ++j) pd[rr][j] = 0.f;
-      if (rr < nr && r0 + rr >= 1 && walk) {
-#pragma unroll
-        for (int j = 0; j < W; ++j) pd[rr][j] = p0[(r0 + rr - 1) * W + j];
-      }
-    }
     {
       const int ch = lane % NCH, oi = lane / NCH;
       const char* fbytes = reinterpret_cast<const char*>(p.frames);
@@ -830,7 +825,7 @@ __global__ __launch_bounds__(WAVES * 64, (R <= 2 ? (JAC ? PBA_SAMPLE_WAVES_PER_S
             }
             if (r >= 1) {
               const float sI = fmaf(dy, fHp[0][j], omdy * h0);
-              const float e = rnd(pd[rr][j] - sI);
+              const float e = rnd(p0[i * W + j] - sI);
               fc0 = fmaf(e, e, fc0);
               if (JAC) {
                 const float gx = rnd(fmaf(dy, fHp[NPL > 1 ? 1 : 0][j], omdy * h1));
@@ -845,17 +840,35 @@ __global__ __launch_bounds__(WAVES * 64, (R <= 2 ? (JAC ? PBA_SAMPLE_WAVES_PER_S
         } else {
           const float dy = dys[r >= 1 ? i : 0];
           const float omdy = __fsub_rn(1.0f, dy);
+          // PBA_WALK_ROWWISE: all horizontal lerps of the row first (independent work for the scheduler), then the
+          // pixels; otherwise column by column (a third fewer live registers).  Same sums in the same order.
+          double Hc[PBA_WALK_ROWWISE ? NPL : 1][W];
+          if (PBA_WALK_ROWWISE) {
+#pragma unroll
+            for (int j = 0; j < W; ++j) {
+              Hc[0][j] = hlerp_exact(dxs[j], omdx[j], tex_I(t[j]), tex_I(t[j + 1]));
+              if (JAC) {
+                Hc[PBA_WALK_ROWWISE && NPL > 1 ? 1 : 0][j] = hlerp_exact(dxs[j], omdx[j], tex_gx2(t[j]), tex_gx2(t[j + 1]));
+                Hc[PBA_WALK_ROWWISE && NPL > 2 ? 2 : 0][j] = hlerp_exact(dxs[j], omdx[j], tex_gy2(t[j]), tex_gy2(t[j + 1]));
+              }
+            }
+          }
 #pragma unroll
           for (int j = 0; j < W; ++j) {
-            const double h0 = hlerp_exact(dxs[j], omdx[j], tex_I(t[j]), tex_I(t[j + 1]));
-            double h1 = 0.0, h2 = 0.0;
-            if (JAC) {
-              h1 = hlerp_exact(dxs[j], omdx[j], tex_gx2(t[j]), tex_gx2(t[j + 1]));
-              h2 = hlerp_exact(dxs[j], omdx[j], tex_gy2(t[j]), tex_gy2(t[j + 1]));
+            double h0, h1 = 0.0, h2 = 0.0;
+            if (PBA_WALK_ROWWISE) {
+              h0 = Hc[0][j];
+              if (JAC) { h1 = Hc[PBA_WALK_ROWWISE && NPL > 1 ? 1 : 0][j]; h2 = Hc[PBA_WALK_ROWWISE && NPL > 2 ? 2 : 0][j]; }
+            } else {
+              h0 = hlerp_exact(dxs[j], omdx[j], tex_I(t[j]), tex_I(t[j + 1]));
+              if (JAC) {
+                h1 = hlerp_exact(dxs[j], omdx[j], tex_gx2(t[j]), tex_gx2(t[j + 1]));
+                h2 = hlerp_exact(dxs[j], omdx[j], tex_gy2(t[j]), tex_gy2(t[j + 1]));
+              }
             }
             if (r >= 1) {
               const float sI = vlerp_exact(dy, omdy, Hp[0][j], h0);
-              const double e = (double)pd[rr][j] - (double)sI;   // photobundle.cc:720 (i0 - i1)
+              const double e = (double)p0[i * W + j] - (double)sI;   // photobundle.cc:720 (i0 - i1)
               if (UNITW) {
                 cc = fma(e, e, cc);
                 if (JAC) {
@@ -877,8 +890,17 @@ __global__ __launch_bounds__(WAVES * 64, (R <= 2 ? (JAC ? PBA_SAMPLE_WAVES_PER_S
                 }
               }
             }
-            Hp[0][j] = h0;
-            if (JAC) { Hp[NPL > 1 ? 1 : 0][j] = h1; Hp[NPL > 2 ? 2 : 0][j] = h2; }
+            if (!PBA_WALK_ROWWISE) {
+              Hp[0][j] = h0;
+              if (JAC) { Hp[NPL > 1 ? 1 : 0][j] = h1; Hp[NPL > 2 ? 2 : 0][j] = h2; }
+            }
+          }
+          if (PBA_WALK_ROWWISE) {
+#pragma unroll
+            for (int j = 0; j < W; ++j) {
+              Hp[0][j] = Hc[0][j];
+              if (JAC) { Hp[NPL > 1 ? 1 : 0][j] = Hc[PBA_WALK_ROWWISE && NPL > 1 ? 1 : 0][j]; Hp[NPL > 2 ? 2 : 0][j] = Hc[PBA_WALK_ROWWISE && NPL > 2 ? 2 : 0][j]; }
+            }
           }
         }
       }
@@ -1044,6 +1066,236 @@ __global__ __launch_bounds__(WAVES * 64, (R <= 2 ? (JAC ? PBA_SAMPLE_WAVES_PER_S
         p.dbg[(size_t)gridDim.x * 8 + 4] = t_fin3 - t_fin2;      // decision
       }
     }
+  }
+}
+
+// =====================================================================================================
+// multi-channel descriptors (reference photobundle.cc:229-245: IntensityAndGradient = 3 channels, BitPlanes = 8)
+// =====================================================================================================
+// One float4 texel per pixel and channel: {value, Gx, Gy, 0} with the gradients of the CHANNEL image
+// (DescriptorFrame ctor, photobundle.cc:172-175 -> imgradient on the float channel, imgproc.cc:27-95: 0.5 * central
+// difference, zero one-pixel border).
+__global__ void k_pack_channel(const float* __restrict__ ch, float4* __restrict__ tex, int rows, int cols) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y;
+  if (x >= cols) return;
+  const size_t i = (size_t)y * cols + x;
+  float gx = 0.f, gy = 0.f;
+  if (y >= 1 && y < rows - 1 && x >= 1 && x < cols - 1) {
+    gx = 0.5f * __fsub_rn(ch[i + 1], ch[i - 1]);
+    gy = 0.5f * __fsub_rn(ch[i + cols], ch[i - cols]);
+  }
+  tex[i] = make_float4(ch[i], gx, gy, 0.f);
+}
+
+// Generic tap of one channel, any position (clamped / irregular observations).
+template <bool JAC>
+__device__ __forceinline__ void sample_generic_mc(const float4* __restrict__ frame, int rows, int cols, float yf, float xf,
+                                                  float& sI, float& sgx, float& sgy) {
+  int x1, x2, y1, y2; float dx, dy;
+  linear_init_axis(yf, rows, y1, y2, dy);
+  linear_init_axis(xf, cols, x1, x2, dx);
+  const float4 t11 = frame[(size_t)y1 * cols + x1], t12 = frame[(size_t)y1 * cols + x2];
+  const float4 t21 = frame[(size_t)y2 * cols + x1], t22 = frame[(size_t)y2 * cols + x2];
+  const double omdx = __dsub_rn(1.0, (double)dx);
+  const float omdy = __fsub_rn(1.0f, dy);
+  sI = vlerp_exact(dy, omdy, hlerp_exact(dx, omdx, t11.x, t12.x), hlerp_exact(dx, omdx, t21.x, t22.x));
+  if (JAC) {
+    sgx = vlerp_exact(dy, omdy, hlerp_exact(dx, omdx, t11.y, t12.y), hlerp_exact(dx, omdx, t21.y, t22.y));
+    sgy = vlerp_exact(dy, omdy, hlerp_exact(dx, omdx, t11.z, t12.z), hlerp_exact(dx, omdx, t21.z, t22.z));
+  }
+}
+
+// The sampling pass over C channels: one lane per observation like k_sample; the channel loop is the outer (run time)
+// loop, inside it the footprint rows of that channel stream through LDS in batches and the lane accumulates the SAME six
+// sums across all channels in the reference's residual order (channel-major, photobundle.cc:708-722), because every
+// pixel of every channel shares the projection Jacobian A: M = sum_k sum_pix w^2 g g^T etc.  Unfused (host-driven LM
+// steps): this is the wide-descriptor path, not the headline one.
+constexpr int sample_mc_rows_per_batch(int R) { return (12 / (2 * R + 2)) > 0 ? 12 / (2 * R + 2) : 1; }
+
+template <int R, bool JAC, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, 2) void k_sample_mc(SampleParams p, const float4* __restrict__ frames_mc, int n_channels) {
+  constexpr int W = 2 * R + 1, F = 2 * R + 2;
+  constexpr int RB = sample_mc_rows_per_batch(R);
+  constexpr int NB = (F + RB - 1) / RB;
+  constexpr int FF = RB * F;
+  constexpr int LSTRIDE = 65;
+  constexpr int NPL = JAC ? 3 : 1;
+  constexpr size_t kTexBytes = sizeof(uint32_t) * WAVES * NPL * FF * LSTRIDE;
+  constexpr size_t kPreBytes = kMaxFrames * sizeof(CamGeom);
+  __shared__ __attribute__((aligned(16))) char s_raw[kTexBytes > kPreBytes ? kTexBytes : kPreBytes];
+  float (*s_tex)[NPL * FF * LSTRIDE] = reinterpret_cast<float (*)[NPL * FF * LSTRIDE]>(s_raw);
+  __shared__ int32_t s_base[WAVES][64];
+  __shared__ double s_red[WAVES];
+  __shared__ int32_t s_fail;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int obs = blockIdx.x * (WAVES * 64) + threadIdx.x;
+  const bool active = obs < p.n_obs;
+  if (threadIdx.x == 0) s_fail = 0;
+  CamGeom* s_geom = reinterpret_cast<CamGeom*>(s_raw);
+  stage_geom<WAVES * 64>(p.geom, s_geom, p.n_frames, threadIdx.x);
+  lds_barrier();
+
+  int pt = 0, slot = 0;
+  double u = 0.0, v = 0.0;
+  int bx = 0, by = 0;
+  bool regular = false;
+  float dxs[W], dys[W];
+  double omdx[W];
+#pragma unroll
+  for (int j = 0; j < W; ++j) { dxs[j] = 1.f; dys[j] = 1.f; omdx[j] = 0.0; }
+  const size_t npix = (size_t)p.rows * p.cols;
+  if (active) {
+    pt = p.obs_point[obs];
+    slot = p.obs_slot[obs];
+    const double X[3] = {p.xyz[3 * (size_t)pt], p.xyz[3 * (size_t)pt + 1], p.xyz[3 * (size_t)pt + 2]};
+    double xw[3];
+    transform_point(s_geom[slot], X, xw);
+    project_point(xw, p.fx, p.fy, p.cx, p.cy, u, v);
+    float xf[W], yf[W];
+#pragma unroll
+    for (int j = 0; j < W; ++j) { xf[j] = (float)(u + (double)(j - R)); yf[j] = (float)(v + (double)(j - R)); }
+    bx = trunc_x86(xf[0]);
+    by = trunc_x86(yf[0]);
+    bool reg = (bx >= 0) && (bx + W - 1 <= p.cols - 2) && (by >= 0) && (by + W - 1 <= p.rows - 2);
+#pragma unroll
+    for (int j = 1; j < W; ++j) reg = reg && (trunc_x86(xf[j]) == bx + j) && (trunc_x86(yf[j]) == by + j);
+    regular = reg;
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+      dxs[j] = __fsub_rn((float)(bx + j + 1), xf[j]);
+      dys[j] = __fsub_rn((float)(by + j + 1), yf[j]);
+      omdx[j] = __dsub_rn(1.0, (double)dxs[j]);
+    }
+  }
+  // texel index of the footprint's first pixel in channel 0 of the observation's frame (-1: not staged)
+  s_base[wave][lane] = (active && regular) ? (int32_t)((size_t)slot * n_channels * npix + (size_t)by * p.cols + bx) : -1;
+  lds_barrier();      // the camera table is dead from here on: its LDS is reused by the texel batches
+
+  const bool walk = active && regular;
+  double m11 = 0, m12 = 0, m22 = 0, b1 = 0, b2 = 0, cc = 0;
+  constexpr int OPI = 64 / F;                       // observations per staging pass: lane = (observation, texel column)
+  constexpr int NG = (64 + OPI - 1) / OPI;
+  const int oi = lane / F, tc = lane - oi * F;
+  for (int k = 0; k < n_channels; ++k) {
+    const float* p0 = p.desc + ((size_t)pt * n_channels + k) * (W * W);
+    double Hp[NPL][W];
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+      for (int j = 0; j < W; ++j) Hp[pl][j] = 0.0;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int r0 = b * RB;
+      const int nr = (F - r0 < RB) ? F - r0 : RB;
+      wave_lds_sync();                              // the previous batch (or channel) has been walked
+#pragma unroll 1
+      for (int g = 0; g < NG; ++g) {
+        const int o = g * OPI + oi;
+        const int32_t bs = (oi < OPI && o < 64) ? s_base[wave][o & 63] : -1;
+        if (bs >= 0) {
+          const float4* src = frames_mc + (size_t)bs + (size_t)k * npix + tc;
+#pragma unroll
+          for (int rr = 0; rr < RB; ++rr) {
+            if (rr >= nr) continue;
+            const float4 t = src[(size_t)(r0 + rr) * p.cols];
+            float* dst = &s_tex[wave][(rr * F + tc) * LSTRIDE + o];
+            dst[0] = t.x;
+            if (JAC) { dst[(NPL > 1 ? 1 : 0) * FF * LSTRIDE] = t.y; dst[(NPL > 2 ? 2 : 0) * FF * LSTRIDE] = t.z; }
+          }
+        }
+      }
+      wave_lds_sync();
+      if (walk) {
+#pragma unroll
+        for (int rr = 0; rr < RB; ++rr) {
+          if (rr >= nr) continue;
+          const int r = r0 + rr, i = r - 1;
+          const float dy = dys[r >= 1 ? i : 0];
+          const float omdy = __fsub_rn(1.0f, dy);
+          float t[NPL][F];
+#pragma unroll
+          for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+            for (int c = 0; c < F; ++c) t[pl][c] = s_tex[wave][pl * FF * LSTRIDE + (rr * F + c) * LSTRIDE + lane];
+#pragma unroll
+          for (int j = 0; j < W; ++j) {
+            const double h0 = hlerp_exact(dxs[j], omdx[j], t[0][j], t[0][j + 1]);
+            double h1 = 0.0, h2 = 0.0;
+            if (JAC) {
+              h1 = hlerp_exact(dxs[j], omdx[j], t[NPL > 1 ? 1 : 0][j], t[NPL > 1 ? 1 : 0][j + 1]);
+              h2 = hlerp_exact(dxs[j], omdx[j], t[NPL > 2 ? 2 : 0][j], t[NPL > 2 ? 2 : 0][j + 1]);
+            }
+            if (r >= 1) {
+              const float sI = vlerp_exact(dy, omdy, Hp[0][j], h0);
+              const double e = (double)p0[i * W + j] - (double)sI;
+              const double w2 = p.w2[i * W + j];
+              cc += w2 * e * e;
+              if (JAC) {
+                const double gx = (double)vlerp_exact(dy, omdy, Hp[NPL > 1 ? 1 : 0][j], h1);
+                const double gy = (double)vlerp_exact(dy, omdy, Hp[NPL > 2 ? 2 : 0][j], h2);
+                const double wgx = w2 * gx, wgy = w2 * gy;
+                m11 += wgx * gx; m12 += wgx * gy; m22 += wgy * gy;
+                b1 += wgx * e; b2 += wgy * e;
+              }
+            }
+            Hp[0][j] = h0;
+            if (JAC) { Hp[NPL > 1 ? 1 : 0][j] = h1; Hp[NPL > 2 ? 2 : 0][j] = h2; }
+          }
+        }
+      }
+    }
+    if (active && !regular) {
+      const float4* frame = frames_mc + ((size_t)slot * n_channels + k) * npix;
+      for (int i = 0; i < W; ++i) {
+        const float yfi = (float)(v + (double)(i - R));
+        for (int j = 0; j < W; ++j) {
+          const float xfj = (float)(u + (double)(j - R));
+          float sI, sgx = 0.f, sgy = 0.f;
+          sample_generic_mc<JAC>(frame, p.rows, p.cols, yfi, xfj, sI, sgx, sgy);
+          const double e = (double)p0[i * W + j] - (double)sI;
+          const double w2 = p.w2[i * W + j];
+          cc += w2 * e * e;
+          if (JAC) {
+            const double gx = (double)sgx, gy = (double)sgy;
+            const double wgx = w2 * gx, wgy = w2 * gy;
+            m11 += wgx * gx; m12 += wgx * gy; m22 += wgy * gy;
+            b1 += wgx * e; b2 += wgy * e;
+          }
+        }
+      }
+    }
+  }
+
+  // loss (HuberLoss::Evaluate + Corrector with rho'' <= 0) over the WHOLE block (all channels), record, block cost
+  double cost_obs = 0.0;
+  if (active) {
+    double rho0 = cc, rho1 = 1.0;
+    if (p.huber > 0.0 && cc > p.huber * p.huber) {
+      const double r = sqrt(cc);
+      rho0 = 2.0 * p.huber * r - p.huber * p.huber;
+      rho1 = fmax(DBL_MIN, p.huber / r);
+    }
+    cost_obs = 0.5 * rho0;
+    if (!isfinite(cc)) atomicOr(&s_fail, 1);
+    if (JAC) {
+      p.rec[0 * p.rec_stride + obs] = rho1 * m11;
+      p.rec[1 * p.rec_stride + obs] = rho1 * m12;
+      p.rec[2 * p.rec_stride + obs] = rho1 * m22;
+      p.rec[3 * p.rec_stride + obs] = rho1 * b1;
+      p.rec[4 * p.rec_stride + obs] = rho1 * b2;
+      p.rec[5 * p.rec_stride + obs] = cost_obs;
+    }
+  }
+  const double ws = wave_sum(cost_obs);
+  if (lane == 0) s_red[wave] = ws;
+  lds_barrier();
+  if (threadIdx.x == 0) {
+    double a = 0.0;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) a += s_red[w];
+    p.block_cost[blockIdx.x] = a;
+    p.block_fail[blockIdx.x] = s_fail;
   }
 }
 

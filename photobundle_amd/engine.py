@@ -29,7 +29,8 @@ def _ptr(a):
 class Engine:
     """One engine = one GPU = one shard of points (all cameras and frames replicated)."""
 
-    def __init__(self, rows, cols, K, radius, max_frames, huber=0.0, device=0, keep_reduced_system=False, precision="exact"):
+    def __init__(self, rows, cols, K, radius, max_frames, huber=0.0, device=0, keep_reduced_system=False, precision="exact",
+                 channels=1):
         self._L = _lib.lib()
         cfg = _lib.Config()
         cfg.rows, cfg.cols, cfg.max_frames, cfg.radius = int(rows), int(cols), int(max_frames), int(radius)
@@ -38,6 +39,7 @@ class Engine:
         cfg.device = int(device)
         # precision: "exact" (reference-exact sampler, default) | "fp32" | "bf16" (configs[4] tolerance sweep, include/pba.h)
         cfg.flags = (1 if keep_reduced_system else 0) | ({"exact": 0, "fp32": 1, "bf16": 2}[precision] << 1)
+        cfg.channels = int(channels)        # descriptor channels (include/pba.h): > 1 takes float channel images per frame
         self._h = C.c_void_p()
         rc = self._L.pba_create(C.byref(cfg), C.byref(self._h))
         if rc != 0:
@@ -75,6 +77,11 @@ class Engine:
         assert img.shape == (self.cfg.rows, self.cfg.cols)
         self._check(self._L.pba_set_frame_u8(self._h, int(slot), _ptr(img)), "pba_set_frame_u8")
 
+    def set_frame_channels(self, slot, channels_f32):
+        ch = np.ascontiguousarray(channels_f32, dtype=np.float32)
+        assert ch.shape == (self.cfg.channels, self.cfg.rows, self.cfg.cols)
+        self._check(self._L.pba_set_frame_channels_f32(self._h, int(slot), ch.shape[0], _ptr(ch)), "pba_set_frame_channels_f32")
+
     def get_frame_planes(self, slot):
         out = np.empty((3, self.cfg.rows, self.cfg.cols), np.float32)
         self._check(self._L.pba_get_frame_planes(self._h, int(slot), _ptr(out[0]), _ptr(out[1]), _ptr(out[2])),
@@ -99,9 +106,14 @@ class Engine:
 
     def load(self, prob):
         """Uploads a WindowProblem (frames from prob.images)."""
-        assert prob.images is not None, "the engine consumes u8 frames (addFrame's input), not float planes"
-        for s in range(prob.n_frames):
-            self.set_frame(s, prob.images[s])
+        if self.cfg.channels > 1:
+            assert prob.channel_images is not None and prob.channels == self.cfg.channels
+            for s in range(prob.n_frames):
+                self.set_frame_channels(s, prob.channel_images[s])
+        else:
+            assert prob.images is not None, "the engine consumes u8 frames (addFrame's input), not float planes"
+            for s in range(prob.n_frames):
+                self.set_frame(s, prob.images[s])
         self.set_problem(prob.xyz, prob.desc, prob.obs_point, prob.obs_slot, prob.weights)
         self.set_cameras(prob.cams, prob.fixed_slot)
         return self

@@ -16,6 +16,7 @@
 #include <stdexcept>
 
 #include "../../include/pba.h"
+#include "imgproc.h"
 #include "utils.h"
 
 namespace {
@@ -175,26 +176,48 @@ PhotometricBundleAdjustment::Result PhotometricBundleAdjustment::Result::FromFil
   throw std::runtime_error("Result::FromFile needs cereal (dead code in the reference's default build too)");
 }
 
-// reference photobundle.cc:151-257: one float channel (Intensity) + its gradient magnitude for the saliency map.
+// reference photobundle.cc:151-257: the descriptor channels of one frame (DescriptorFrame::Create :225-248) and the
+// saliency map summed over every channel's gradient magnitude (:213-221).  The per-channel gradient images the
+// residuals sample (:172-175) are built by the engine on the device.
 struct PhotometricBundleAdjustment::DescriptorFrame {
   uint32_t id;
-  Image_<float> I;
-  DescriptorFrame(uint32_t frame_id, const uint8_t* img, int rows, int cols, int nt) : id(frame_id), I(rows, cols) {
+  std::vector<Image_<float>> channels;
+  Image_<float>& I;              // channel 0
+  static std::vector<Image_<float>> MakeChannels(const uint8_t* img, int rows, int cols, DescriptorType type, int nt) {
+    std::vector<Image_<float>> ch;
     const long n = (long)rows * cols;
+    if (type == DescriptorType::BitPlanes) {
+      imgproc::computeBitPlanes(img, rows, cols, ch);
+      return ch;
+    }
+    ch.resize(type == DescriptorType::IntensityAndGradient ? 3 : 1);
+    ch[0].resize(rows, cols);
 #pragma omp parallel for schedule(static) num_threads(nt)
-    for (long i = 0; i < n; ++i) I.d[i] = (float)img[i];
+    for (long i = 0; i < n; ++i) ch[0].d[i] = (float)img[i];
+    if (type == DescriptorType::IntensityAndGradient) {
+      ch[1].resize(rows, cols);
+      ch[2].resize(rows, cols);
+      imgproc::imgradient(img, rows, cols, ch[1].data(), ch[2].data());     // :236-237, from the u8 frame
+    }
+    return ch;
   }
-  // computeSaliencyMap (:213-221) = |Ix| + |Iy| with imgradient semantics (imgproc.cc:27-95)
+  DescriptorFrame(uint32_t frame_id, const uint8_t* img, int rows, int cols, DescriptorType type, int nt)
+      : id(frame_id), channels(MakeChannels(img, rows, cols, type, nt)), I(channels[0]) {}
+  size_t numChannels() const { return channels.size(); }
   void computeSaliencyMap(Image_<float>& smap, int nt) const {
     const int rows = I.rows(), cols = I.cols();
     std::fill(smap.d.begin(), smap.d.end(), 0.0f);
+    for (size_t k = 0; k < channels.size(); ++k) {
+      const Image_<float>& C = channels[k];
 #pragma omp parallel for schedule(static) num_threads(nt)
-    for (int y = 1; y < rows - 1; ++y)
-      for (int x = 1; x < cols - 1; ++x) {
-        const float ix = 0.5f * (I(y, x + 1) - I(y, x - 1));
-        const float iy = 0.5f * (I(y + 1, x) - I(y - 1, x));
-        smap(y, x) = std::fabs(ix) + std::fabs(iy);
-      }
+      for (int y = 1; y < rows - 1; ++y)
+        for (int x = 1; x < cols - 1; ++x) {
+          const float ix = 0.5f * (C(y, x + 1) - C(y, x - 1));
+          const float iy = 0.5f * (C(y + 1, x) - C(y - 1, x));
+          const float mag = std::fabs(ix) + std::fabs(iy);
+          smap(y, x) = (k == 0) ? mag : smap(y, x) + mag;
+        }
+    }
   }
 };
 
@@ -219,9 +242,9 @@ PhotometricBundleAdjustment::PhotometricBundleAdjustment(const Calibration& cali
 PhotometricBundleAdjustment::PhotometricBundleAdjustment(const Calibration& calib, const ImageSize& image_size,
                                                          const Options& options)
     : _calib(calib), _image_size(image_size), _options_ptr(new Options(options)) {
-  if (options.descriptorType != Options::DescriptorType::Intensity)
-    throw std::runtime_error("only DescriptorType::Intensity is implemented (the reference's multi-channel path asserts, "
-                             "photobundle.cc:684)");
+  // Multi-channel descriptor types: the reference's debug builds stop at `assert(p0.size() == w.size())`
+  // (photobundle.cc:684: C P descriptor entries against P patch weights); its release builds run, with the weights
+  // restarting per channel (:714-721), and that is what is built here.
   _mask.resize(_image_size.rows, _image_size.cols);
   _saliency_map.resize(_image_size.rows, _image_size.cols);
   _K_inv = calib.K().inverse();
@@ -231,6 +254,7 @@ PhotometricBundleAdjustment::PhotometricBundleAdjustment(const Calibration& cali
   cfg.max_frames = options.slidingWindowSize; cfg.radius = options.patchRadius;
   cfg.fx = calib.fx(); cfg.fy = calib.fy(); cfg.cx = calib.cx(); cfg.cy = calib.cy();
   cfg.huber = options.robustThreshold; cfg.device = options.device; cfg.flags = 0;
+  cfg.channels = options.descriptorType == DescriptorType::BitPlanes ? 8 : (options.descriptorType == DescriptorType::IntensityAndGradient ? 3 : 1);
   check(nullptr, pba_create(&cfg, &_engine), "pba_create");
 }
 
@@ -257,11 +281,19 @@ void PhotometricBundleAdjustment::addFrame(const uint8_t* I_ptr, const float* Z_
   double t_ph[6] = {0, 0, 0, 0, 0, 0};
   double t_last = wall_ms();
   auto lap = [&](int k) { const double t = wall_ms(); t_ph[k] += t - t_last; t_last = t; };
-  UniquePointer<DescriptorFrame> frame(new DescriptorFrame(_frame_id, I_ptr, rows, cols, nt));
+  UniquePointer<DescriptorFrame> frame(new DescriptorFrame(_frame_id, I_ptr, rows, cols, _options_ptr->descriptorType, nt));
   lap(5);
-  // the engine keeps its own device plane of this frame in the ring slot id % window
+  // the engine keeps its own device plane(s) of this frame in the ring slot id % window
   const int window = _options_ptr->slidingWindowSize;
-  check(_engine, pba_set_frame_u8(_engine, (int)(_frame_id % window), I_ptr), "pba_set_frame_u8");
+  const int num_channels = (int)frame->numChannels();
+  if (num_channels == 1) {
+    check(_engine, pba_set_frame_u8(_engine, (int)(_frame_id % window), I_ptr), "pba_set_frame_u8");
+  } else {
+    std::vector<float> flat((size_t)num_channels * rows * cols);
+    for (int k = 0; k < num_channels; ++k)
+      std::copy(frame->channels[k].d.begin(), frame->channels[k].d.end(), flat.begin() + (size_t)k * rows * cols);
+    check(_engine, pba_set_frame_channels_f32(_engine, (int)(_frame_id % window), num_channels, flat.data()), "pba_set_frame_channels_f32");
+  }
 
   const int B = std::max(_options_ptr->maskBlockRadius, std::max(2, _options_ptr->patchRadius));
   const int max_rows = rows - B - 1, max_cols = cols - B - 1;
@@ -357,7 +389,7 @@ void PhotometricBundleAdjustment::addFrame(const uint8_t* I_ptr, const float* Z_
     const Vec3 X = TransformPoint(T_w, MakeVec3((double)z * ray[0], (double)z * ray[1], (double)z * ray[2]));
     ScenePointPointer p(new ScenePoint(X, _frame_id));
     p->patch.set(I, (double)x, (double)y);
-    p->descriptor.resize(patch_length);
+    p->descriptor.resize((size_t)num_channels * patch_length);
     p->saliency = cands[k].saliency;
     p->x0 = x; p->y0 = y;
     new_points[k] = std::move(p);
@@ -368,13 +400,16 @@ void PhotometricBundleAdjustment::addFrame(const uint8_t* I_ptr, const float* Z_
   // ---- descriptors (reference :466-479, :597-603): integer-pixel patch, indices clamped ------------------------
   {
     const int mc = cols - radius - 1, mr = rows - radius - 1;
-    for (auto& p : new_points) {
-      int i = 0;
-      for (int r = -radius; r <= radius; ++r) {
-        const int r_i = std::max(radius, std::min(p->y0 + r, mr));
-        for (int c = -radius; c <= radius; ++c, ++i) {
-          const int c_i = std::max(radius, std::min(p->x0 + c, mc));
-          p->descriptor[i] = (double)frame->I(r_i, c_i);
+    for (int k = 0; k < num_channels; ++k) {
+      const Image_<float>& channel = frame->channels[k];
+      for (auto& p : new_points) {
+        int i = k * patch_length;
+        for (int r = -radius; r <= radius; ++r) {
+          const int r_i = std::max(radius, std::min(p->y0 + r, mr));
+          for (int c = -radius; c <= radius; ++c, ++i) {
+            const int c_i = std::max(radius, std::min(p->x0 + c, mc));
+            p->descriptor[i] = (double)channel(r_i, c_i);
+          }
         }
       }
     }
@@ -400,7 +435,7 @@ void PhotometricBundleAdjustment::optimize(Result* result) {
   const uint32_t frame_id_start = _frame_buffer.front()->id, frame_id_end = _frame_buffer.back()->id;
   const int window = _options_ptr->slidingWindowSize;
   const std::vector<double> patch_weights = MakePatchWeights(_options_ptr->patchRadius, _options_ptr->doGaussianWeighting);
-  const int P = (int)patch_weights.size();
+  const int P = (int)patch_weights.size() * (int)_frame_buffer.front()->numChannels();   // descriptor entries per point
 
   // cameras: INVERTED world poses as angle-axis + t (reference :774-778), stored by ring slot id % window
   std::vector<double> cams(6 * (size_t)window, 0.0);

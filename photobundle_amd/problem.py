@@ -33,6 +33,8 @@ class WindowProblem:
     fixed_slot: int = 0
     images: np.ndarray = None
     meta: dict = field(default_factory=dict)
+    channels: int = 1            # descriptor channels C: planes is [n_frames, 3C, rows, cols], desc [n_points, C P]
+    channel_images: np.ndarray = None   # [n_frames, C, rows, cols] f32, what pba_set_frame_channels_f32 consumes (C > 1)
 
     @property
     def n_frames(self):
@@ -60,7 +62,8 @@ class WindowProblem:
             K=self.K, radius=self.radius, planes=self.planes, cams=self.cams.copy(),
             xyz=self.xyz[lo:hi].copy(), desc=self.desc[lo:hi], obs_point=(self.obs_point[o_lo:o_hi] - lo).astype(np.int32),
             obs_slot=self.obs_slot[o_lo:o_hi], weights=self.weights, huber=self.huber, fixed_slot=self.fixed_slot,
-            images=self.images, meta=dict(self.meta, shard=(rank, world), point_range=(lo, hi)))
+            images=self.images, meta=dict(self.meta, shard=(rank, world), point_range=(lo, hi)), channels=self.channels,
+            channel_images=self.channel_images)
 
 
 def shard_bounds(obs_point, n_points, rank, world):

@@ -111,7 +111,7 @@ def project(K, T_cw, X):
 
 def make_window(n_frames=8, n_points=50000, radius=2, size=KITTI_SIZE, K=KITTI_K, visibility="dense",
                 huber=0.0, gaussian=False, depth_noise=0.01, rot_deg=0.1, trans=0.02, seed_offset=0,
-                point_seed_offset=0, dense_births=(0,)):
+                point_seed_offset=0, dense_births=(0,), channel_fn=None):
     """Builds a WindowProblem of the named shape.
 
     visibility = "dense": every point is born in frame 0 and observed in every frame (sites whose ground-truth
@@ -119,6 +119,8 @@ def make_window(n_frames=8, n_points=50000, radius=2, size=KITTI_SIZE, K=KITTI_K
                  "causal": points are born uniformly over frames 0..n_frames-3 and observed from birth on while
                           inside the margin (mirrors the selection rule of reference photobundle.cc:789).
     point_seed_offset only changes the drawn points (multi-GPU shards share frames and cameras).
+    channel_fn: None (Intensity) or a callable u8 frame -> (float channel images [C, rows, cols], planes [3C, rows, cols])
+                of a multi-channel descriptor (reference photobundle.cc:229-245); tests pass the oracle's producers.
     dense_births: frames the "dense" sites (and their descriptors) are taken from; every point is still observed in ALL
                   frames.  One frame does not hold 200k sites that stay inside a 16-frame window (BASELINE configs[3]):
                   that shape uses (0, 8).
@@ -134,6 +136,12 @@ def make_window(n_frames=8, n_points=50000, radius=2, size=KITTI_SIZE, K=KITTI_K
         depths.append(z)
     images = np.stack(images)
     planes = np.stack([imgproc.planes_from_u8(im) for im in images])
+    n_ch, channel_images, planes_mc = 1, None, None
+    if channel_fn is not None:
+        both = [channel_fn(im) for im in images]
+        channel_images = np.stack([b[0] for b in both])
+        planes_mc = np.stack([b[1] for b in both])
+        n_ch = channel_images.shape[1]
 
     rng = np.random.default_rng(SEED_POINTS + seed_offset + 1000 * point_seed_offset)
     margin = radius + 2
@@ -174,7 +182,11 @@ def make_window(n_frames=8, n_points=50000, radius=2, size=KITTI_SIZE, K=KITTI_K
         # photobundle.cc:560: X = T_w * (z * K^-1 * [x y 1]) with the CURRENT (initial) estimate of the birth pose
         Xw = Xc @ T_init[b][:3, :3].T + T_init[b][:3, 3]
         xyz_all.append(Xw)
-        desc_all.append(imgproc.extract_patches(planes[b, 0], np.stack([xs, ys], 1), radius))
+        if n_ch == 1:
+            desc_all.append(imgproc.extract_patches(planes[b, 0], np.stack([xs, ys], 1), radius))
+        else:     # one patch per channel, channel-major (photobundle.cc:597-603)
+            desc_all.append(np.concatenate([imgproc.extract_patches(channel_images[b, k], np.stack([xs, ys], 1), radius)
+                                            for k in range(n_ch)], axis=1))
         pi, fi = np.nonzero(vis)
         obs_p.append(pi + base)
         obs_s.append(fi)
@@ -186,7 +198,8 @@ def make_window(n_frames=8, n_points=50000, radius=2, size=KITTI_SIZE, K=KITTI_K
     cams = np.stack([se3.pose_to_params(np.linalg.inv(T)) for T in T_init])     # photobundle.cc:774-778
     cams_gt = np.stack([se3.pose_to_params(np.linalg.inv(T)) for T in T_gt])
     return WindowProblem(
-        K=tuple(K), radius=radius, planes=planes, cams=cams, xyz=np.concatenate(xyz_all),
+        channels=n_ch, channel_images=channel_images,
+        K=tuple(K), radius=radius, planes=planes if n_ch == 1 else planes_mc, cams=cams, xyz=np.concatenate(xyz_all),
         desc=np.concatenate(desc_all), obs_point=obs_point[order], obs_slot=obs_slot[order],
         weights=imgproc.make_patch_weights(radius, gaussian), huber=huber, fixed_slot=0, images=images,
         meta=dict(cams_gt=cams_gt, T_gt=T_gt, T_init=T_init, local_init=local_init, depths=np.stack(depths),

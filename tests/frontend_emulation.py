@@ -69,7 +69,9 @@ class Point:
 
 class Emulator:
     def __init__(self, K, size, window, radius, max_points, min_score=0.75, huber=0.05, mask_radius=1,
-                 max_frame_distance=1, nms=1, min_depth=0.01, max_depth=1000.0, max_iterations=500):
+                 max_frame_distance=1, nms=1, min_depth=0.01, max_depth=1000.0, max_iterations=500,
+                 descriptor_type="Intensity"):
+        self.descriptor_type = descriptor_type
         self.K, self.size = K, size
         self.window, self.radius, self.max_points = window, radius, max_points
         self.min_score, self.huber, self.mask_radius = min_score, huber, mask_radius
@@ -90,7 +92,10 @@ class Emulator:
         T_w = self.T_w[-1]
         T_c = np.linalg.inv(T_w)
         I = img
-        planes = imgproc.planes_from_u8(img)
+        # DescriptorFrame::Create (photobundle.cc:225-248) + the per-channel gradients (:172-175)
+        channels = oracle.descriptor_channels(img, self.descriptor_type)
+        planes_mc = oracle.channel_planes(channels)
+        planes = planes_mc[:3]
         B = max(self.mask_radius, max(2, self.radius))
         max_rows, max_cols = rows - B - 1, cols - B - 1
         mask = np.ones((rows, cols), np.uint16)
@@ -107,7 +112,9 @@ class Emulator:
                     if pt.patch.score(Zncc(I, uv[0], uv[1])) > self.min_score:
                         pt.f.append(self.frame_id)
                         mask[r - self.mask_radius:r + self.mask_radius + 1, c - self.mask_radius:c + self.mask_radius + 1] = 0
-        sal = (np.abs(planes[1]) + np.abs(planes[2])).astype(np.float32)
+        sal = (np.abs(planes_mc[1]) + np.abs(planes_mc[2])).astype(np.float32)      # computeSaliencyMap (:213-221)
+        for k in range(1, channels.shape[0]):
+            sal = (sal + (np.abs(planes_mc[3 * k + 1]) + np.abs(planes_mc[3 * k + 2])).astype(np.float32)).astype(np.float32)
         new = []
         Kinv = np.linalg.inv(Kmat)
         n = self.nms
@@ -136,11 +143,12 @@ class Emulator:
             new.sort(key=lambda q: -q.saliency)
             new = new[:self.max_points]
         if new:
-            d = imgproc.extract_patches(planes[0], np.array([q.xy for q in new]), self.radius)
+            xy = np.array([q.xy for q in new])
+            d = np.concatenate([imgproc.extract_patches(channels[k], xy, self.radius) for k in range(channels.shape[0])], axis=1)
             for q, dd in zip(new, d):
                 q.desc = dd
         self.points.extend(new)
-        self.frames.append((self.frame_id, img))
+        self.frames.append((self.frame_id, img, channels, planes_mc))
         if len(self.frames) > self.window:
             self.frames.pop(0)
         if len(self.frames) == self.window:
@@ -152,9 +160,12 @@ class Emulator:
         W = self.window
         cams = np.zeros((W, 6))
         images = np.zeros((W,) + tuple(self.size), np.uint8)
-        for fid, img in self.frames:
+        n_ch = self.frames[0][2].shape[0]
+        planes = np.zeros((W, 3 * n_ch) + tuple(self.size), np.float32)
+        for fid, img, _, pl in self.frames:
             cams[fid % W] = se3.pose_to_params(np.linalg.inv(self.T_w[fid]))
             images[fid % W] = img
+            planes[fid % W] = pl
         sel = [p for p in self.points if len(p.f) >= 3 and p.f[0] >= start]
         obs_p, obs_s = [], []
         for i, p in enumerate(sel):
@@ -162,7 +173,7 @@ class Emulator:
                 obs_p.append(i)
                 obs_s.append(s)
         if sel:
-            prob = WindowProblem(K=self.K, radius=self.radius, planes=np.stack([imgproc.planes_from_u8(im) for im in images]),
+            prob = WindowProblem(K=self.K, radius=self.radius, planes=planes, channels=n_ch,
                                  cams=cams, xyz=np.stack([p.X for p in sel]), desc=np.stack([p.desc for p in sel]),
                                  obs_point=np.array(obs_p, np.int32), obs_slot=np.array(obs_s, np.int32),
                                  weights=imgproc.make_patch_weights(self.radius), huber=self.huber,
@@ -171,7 +182,7 @@ class Emulator:
             res = oracle.solve(prob, oracle.default_options(max_num_iterations=self.max_iterations))
             for p, X in zip(sel, res["xyz"]):
                 p.X = X.copy()
-            for fid, _ in self.frames:
+            for fid in [f[0] for f in self.frames]:
                 self.T_w[fid] = np.linalg.inv(se3.params_to_pose(res["cams"][fid % W]))
             # Result write-back, photobundle.cc:857-875: the points that leave the window (refFrameId <= frame_id_start)
             gone = [p for p in self.points if p.f[0] <= start]

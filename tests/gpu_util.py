@@ -8,14 +8,14 @@ from photobundle_amd.engine import Engine
 def make_engine(prob, device=0, keep_reduced_system=True):
     _, _, rows, cols = prob.planes.shape
     e = Engine(rows, cols, prob.K, prob.radius, prob.n_frames, huber=prob.huber, device=device,
-               keep_reduced_system=keep_reduced_system)
+               keep_reduced_system=keep_reduced_system, channels=getattr(prob, "channels", 1))
     e.load(prob)
     return e
 
 
 def dense_system(p, cams=None, xyz=None):
     """Dense loss-corrected Jacobian / residual from per-block oracle evaluations (free columns only)."""
-    P = p.patch_len
+    P = p.patch_len * getattr(p, "channels", 1)       # residuals of one block
     n_c, n_p = p.n_frames, p.n_points
     free = [c for c in range(n_c) if c != p.fixed_slot]
     cols_c = {c: 6 * i for i, c in enumerate(free)}

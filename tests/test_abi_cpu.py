@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_header_sizes():
     # sizes the C compiler gives the ABI structs (computed from the header field lists)
     import ctypes as C
-    assert C.sizeof(_lib.Config) == 4 * 4 + 5 * 8 + 2 * 4
+    assert C.sizeof(_lib.Config) == 4 * 4 + 5 * 8 + 4 * 4
     assert C.sizeof(_lib.StepInfo) == 7 * 8 + 2 * 4
     assert C.sizeof(_lib.IterationSummary) == 4 * 4 + 9 * 8 + 4 * 4 + 5 * 8
     assert C.sizeof(_lib.SolverOptions) == 2 * 4 + 9 * 8 + 2 * 4

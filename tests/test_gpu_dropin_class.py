@@ -228,3 +228,38 @@ def test_configs2_full_size_three_level_pyramid(tmp_path):
     r_ini, t_ini = _pose_errors(chained, T_gt)
     print("configs[2]: mean rotation error %.3e -> %.3e rad, mean translation error %.3e -> %.3e m" % (r_ini.mean(), r_ref.mean(), t_ini.mean(), t_ref.mean()))
     assert r_ref.mean() < 0.5 * r_ini.mean() and t_ref.mean() < 0.5 * t_ini.mean()
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("descriptor", ["IntensityAndGradient", "BitPlanes"])
+def test_multichannel_descriptor_types_match_emulation(tmp_path, descriptor):
+    """Options::descriptorType = IntensityAndGradient / BitPlanes (reference photobundle.cc:225-248) through the class and
+    run_kitti: channel images, saliency over all channels, C patches per descriptor, C (2R+1)^2 residuals per block."""
+    from frontend_emulation import Emulator
+    size, K = (120, 160), (200.0, 200.0, 80.0, 60.0)
+    n_frames, window, radius, max_points = 6, 4, 1, 4096
+    tmp = str(tmp_path)
+    imgs, depths, local = _write_sequence(tmp, n_frames, size, K)
+    cfg = os.path.join(tmp, "mc.cfg")
+    with open(cfg, "w") as f:
+        f.write("DataDirectory = %s\nTrajectory = %s/init.txt\ndescriptorType = %s\n" % (tmp, tmp, descriptor))
+        f.write("maxNumPoints = %d\nslidingWindowSize = %d\npatchRadius = %d\nminScore = 0.65\nrobustThreshold = 0.05\nverbose = 0\n"
+                % (max_points, window, radius))
+    out, dump = os.path.join(tmp, "refined.txt"), os.path.join(tmp, "results.txt")
+    r = subprocess.run([RUN, "-c", cfg, "-o", out, "-r", dump], capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-2000:]
+    refined = np.loadtxt(out).reshape(-1, 3, 4)
+    emu = Emulator(K, size, window, radius, max_points, min_score=0.65, huber=0.05, descriptor_type=descriptor)
+    for im, z, T in zip(imgs, depths, local):
+        emu.add_frame(im, z, T)
+    import re
+    used = [tuple(int(t) for t in m.groups()) for m in re.finditer(r"Using (\d+) points \((\d+) residual blocks\)", r.stderr)]
+    assert used == [(r_["n_points"], r_["n_obs"]) for r_ in emu.results], (used, [(r_["n_points"], r_["n_obs"]) for r_ in emu.results])
+    assert all(r_["n_points"] > 20 for r_ in emu.results)
+    C = {"IntensityAndGradient": 3, "BitPlanes": 8}[descriptor]
+    got = _read_results(dump)
+    for g, e in zip(got, emu.results):
+        assert g["residuals"] == e["num_residuals"] == e["n_obs"] * C * (2 * radius + 1) ** 2
+        assert np.isclose(g["initial"], e["initial_cost"], rtol=1e-12) and np.isclose(g["final"], e["final_cost"], rtol=1e-8)
+    ref = np.stack([T[:3, :] for T in emu.T_w])
+    assert np.abs(refined - ref).max() <= 1e-5, np.abs(refined - ref).max()
