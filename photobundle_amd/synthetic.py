@@ -120,7 +120,7 @@ def make_window(n_frames=8, n_points=50000, radius=2, size=KITTI_SIZE, K=KITTI_K
                           inside the margin (mirrors the selection rule of reference photobundle.cc:789).
     point_seed_offset only changes the drawn points (multi-GPU shards share frames and cameras).
     channel_fn: None (Intensity) or a callable u8 frame -> (float channel images [C, rows, cols], planes [3C, rows, cols])
-                of a multi-channel descriptor (reference photobundle.cc:229-245); tests pass the oracle's producers.
+                of a multi-channel descriptor (reference photobundle.cc:229-245), supplied by the caller.
     dense_births: frames the "dense" sites (and their descriptors) are taken from; every point is still observed in ALL
                   frames.  One frame does not hold 200k sites that stay inside a 16-frame window (BASELINE configs[3]):
                   that shape uses (0, 8).
