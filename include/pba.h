@@ -180,6 +180,14 @@ int pba_set_problem(pba_engine* e, int32_t n_points, const double* xyz, const do
                     int32_t n_obs, const int32_t* obs_point, const int32_t* obs_slot, const double* weights);
 /* cams6: [n_frames][6]; fixed_slot: SetParameterBlockConstant (photobundle.cc:809-813), -1 for none. */
 int pba_set_cameras(pba_engine* e, const double* cams6, int32_t n_frames, int32_t fixed_slot);
+/* Inverse-depth variant of the point parameterisation (named by the project's north star; the REFERENCE optimises free
+ * world points, photobundle.cc:692/:795, so this mode has no reference counterpart and is outside every parity claim).
+ * Call after pba_set_problem: point i then lives on the fixed world ray rays6[i] = {origin (3), direction (3)} with the
+ * single free parameter rho[i] > 0, X_i = origin + direction / rho_i.  pba_get_state afterwards returns the parameters
+ * (rho, 0, 0) in `xyz`; pba_get_points_world returns world coordinates in either mode.  pba_set_problem switches the
+ * mode off again. */
+int pba_set_inverse_depth(pba_engine* e, const double* rays6, const double* rho);
+int pba_get_points_world(pba_engine* e, double* xyz);
 /* Current (best) state; either pointer may be NULL. */
 int pba_get_state(pba_engine* e, double* cams6, double* xyz);
 

@@ -728,7 +728,7 @@ void oracle_default_options(oracle_options* o) {
   o->max_num_consecutive_invalid_steps = 5;
   o->jacobi_scaling = 1;
   o->use_autodiff = 1;
-  o->legacy_tolerance_order = 0;
+  o->reserved = 0;
 }
 
 void oracle_imgradient_f32(const float* src, int rows, int cols, float* Ix, float* Iy) {

@@ -49,6 +49,9 @@ struct pba_engine {
   CamGeom* d_geom[2] = {nullptr, nullptr};
   float* d_desc = nullptr;
   double* d_w2 = nullptr;
+  double* d_rays = nullptr;         // inverse-depth variant: [n_points][6] fixed world rays (null pointer passed otherwise)
+  bool inverse_depth = false;
+  std::vector<double> h_rays;       // host copy for pba_get_points_world
   int32_t* d_obs_point = nullptr;
   uint8_t* d_obs_slot = nullptr;
   int32_t* d_pt_begin = nullptr;
@@ -244,6 +247,7 @@ SampleParams make_sample_params(pba_engine* e, int which_point) {
   sp.frames = e->d_frames;
   sp.geom = e->d_geom[which_point];
   sp.xyz = e->d_xyz[which_point];
+  sp.rays = e->inverse_depth ? e->d_rays : nullptr;
   sp.desc = e->d_desc;
   sp.w2 = e->d_w2;
   sp.obs_point = e->d_obs_point;
@@ -410,6 +414,7 @@ void pba_destroy(pba_engine* e) {
   e->comm.shutdown();
   dev_free(&e->d_frames); dev_free(&e->d_img_stage); dev_free(&e->d_frames_mc); dev_free(&e->d_ch_stage);
   for (int k = 0; k < 2; ++k) { dev_free(&e->d_xyz[k]); dev_free(&e->d_cams[k]); dev_free(&e->d_geom[k]); dev_free(&e->d_block_cost[k]); dev_free(&e->d_block_fail[k]); }
+  dev_free(&e->d_rays);
   dev_free(&e->d_desc); dev_free(&e->d_w2); dev_free(&e->d_obs_point); dev_free(&e->d_obs_slot); dev_free(&e->d_pt_begin);
   dev_free(&e->d_tile_info); dev_free(&e->d_obs_l0); dev_free(&e->d_obs_cnt); dev_free(&e->d_rec[0]); dev_free(&e->d_rec[1]); dev_free(&e->d_sp); dev_free(&e->d_ptrec); dev_free(&e->d_sc);
   dev_free(&e->d_delta_c); dev_free(&e->d_partial); dev_free(&e->d_red); dev_free(&e->d_packed); dev_free(&e->d_S);
@@ -579,6 +584,7 @@ int pba_set_problem(pba_engine* e, int32_t n_points, const double* xyz, const do
   e->slot_mask = 0;
   for (int o = 0; o < n_obs; ++o) e->slot_mask |= 1u << slot8[o];
   e->have_problem = true;
+  e->inverse_depth = false;         // back to the reference's free world points until pba_set_inverse_depth says otherwise
   e->have_lin = false;
   e->lin_valid[0] = e->lin_valid[1] = false;
   return PBA_OK;
@@ -614,6 +620,44 @@ int pba_get_state(pba_engine* e, double* cams6, double* xyz) {
   if (cams6) HIP_TRY(e, hipMemcpyAsync(cams6, e->d_cams[e->cur], sizeof(double) * 6 * e->n_frames, hipMemcpyDeviceToHost, e->stream));
   if (xyz) HIP_TRY(e, hipMemcpyAsync(xyz, e->d_xyz[e->cur], sizeof(double) * 3 * e->n_points, hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(e, hipStreamSynchronize(e->stream));
+  return PBA_OK;
+}
+
+int pba_set_inverse_depth(pba_engine* e, const double* rays6, const double* rho) {
+  if (!e || !rays6 || !rho) return PBA_ERR_INVALID;
+  if (!e->have_problem) return fail(e, PBA_ERR_STATE, "call order violated: pba_set_inverse_depth before pba_set_problem");
+  HIP_TRY(e, hipSetDevice(e->cfg.device));
+  const int n = e->n_points;
+  std::vector<double> prm((size_t)3 * n, 0.0);
+  for (int i = 0; i < n; ++i) {
+    if (!(rho[i] > 0.0) || !std::isfinite(rho[i])) return fail(e, PBA_ERR_INVALID, "inverse depth of point %d is not positive", i);
+    prm[3 * (size_t)i] = rho[i];
+  }
+  int rc = dev_alloc(e, &e->d_rays, (size_t)6 * n);
+  if (rc) return rc;
+  e->h_rays.assign(rays6, rays6 + (size_t)6 * n);
+  HIP_TRY(e, hipMemcpyAsync(e->d_rays, rays6, sizeof(double) * 6 * n, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(e, hipMemcpyAsync(e->d_xyz[e->cur], prm.data(), sizeof(double) * 3 * n, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  e->inverse_depth = true;
+  e->have_lin = false;
+  e->lin_valid[0] = e->lin_valid[1] = false;
+  return PBA_OK;
+}
+
+int pba_get_points_world(pba_engine* e, double* xyz) {
+  if (!e || !xyz) return PBA_ERR_INVALID;
+  if (!e->have_problem) return fail(e, PBA_ERR_STATE, "call order violated: pba_get_points_world before pba_set_problem");
+  HIP_TRY(e, hipSetDevice(e->cfg.device));
+  HIP_TRY(e, hipMemcpyAsync(xyz, e->d_xyz[e->cur], sizeof(double) * 3 * e->n_points, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  if (e->inverse_depth) {
+    for (int i = 0; i < e->n_points; ++i) {
+      const double inv = 1.0 / xyz[3 * (size_t)i];
+      const double* r = e->h_rays.data() + 6 * (size_t)i;
+      for (int k = 0; k < 3; ++k) xyz[3 * (size_t)i + k] = r[k] + r[3 + k] * inv;
+    }
+  }
   return PBA_OK;
 }
 
@@ -662,7 +706,7 @@ int pba_internal_step(pba_engine* e, double radius, int32_t init_scale, const pb
   const bool multi = e->comm.multi();
 
   SchurParams sc{};
-  sc.xyz = e->d_xyz[cur]; sc.geom = e->d_geom[cur]; sc.rec = e->d_rec[cur]; sc.obs_point = e->d_obs_point;
+  sc.xyz = e->d_xyz[cur]; sc.rays = e->inverse_depth ? e->d_rays : nullptr; sc.geom = e->d_geom[cur]; sc.rec = e->d_rec[cur]; sc.obs_point = e->d_obs_point;
   sc.obs_slot = e->d_obs_slot; sc.tile_info = e->d_tile_info; sc.obs_l0 = e->d_obs_l0; sc.obs_cnt = e->d_obs_cnt; sc.sp = e->d_sp;
   sc.ptrec = e->d_ptrec; sc.partial = e->d_partial; sc.rec_stride = e->rec_stride; sc.n_tiles = e->n_tiles; sc.n_frames = e->n_frames;
   sc.n_free = e->n_free; sc.n_pairs = e->n_pairs; sc.part_stride = e->part_stride; sc.init_scale = init_scale;
@@ -789,7 +833,7 @@ int pba_internal_step(pba_engine* e, double radius, int32_t init_scale, const pb
     }
   } else if (!grad_only) {
     BacksubParams bs{};
-    bs.xyz = e->d_xyz[cur]; bs.xyz_cand = e->d_xyz[cand]; bs.geom = e->d_geom[cur]; bs.rec = e->d_rec[cur];
+    bs.xyz = e->d_xyz[cur]; bs.rays = e->inverse_depth ? e->d_rays : nullptr; bs.xyz_cand = e->d_xyz[cand]; bs.geom = e->d_geom[cur]; bs.rec = e->d_rec[cur];
     bs.pt_begin = e->d_pt_begin; bs.obs_slot = e->d_obs_slot; bs.sp = e->d_sp; bs.ptrec = e->d_ptrec;
     bs.delta_c = e->d_delta_c; bs.block_out = e->d_bs_out; bs.rec_stride = e->rec_stride; bs.n_points = e->n_points;
     bs.fx = e->cfg.fx; bs.fy = e->cfg.fy;
@@ -996,7 +1040,7 @@ int pba_internal_async_enqueue(pba_engine* e, int kind, int init_scale, const pb
     return PBA_OK;
   }
   SchurParams sc{};
-  sc.xyz = e->d_xyz[cur]; sc.geom = e->d_geom[cur]; sc.rec = e->d_rec[cur]; sc.obs_point = e->d_obs_point;
+  sc.xyz = e->d_xyz[cur]; sc.rays = e->inverse_depth ? e->d_rays : nullptr; sc.geom = e->d_geom[cur]; sc.rec = e->d_rec[cur]; sc.obs_point = e->d_obs_point;
   sc.obs_slot = e->d_obs_slot; sc.tile_info = e->d_tile_info; sc.obs_l0 = e->d_obs_l0; sc.obs_cnt = e->d_obs_cnt; sc.sp = e->d_sp;
   sc.ptrec = e->d_ptrec; sc.partial = e->d_partial; sc.rec_stride = e->rec_stride; sc.n_tiles = e->n_tiles; sc.n_frames = e->n_frames;
   sc.n_free = e->n_free; sc.n_pairs = e->n_pairs; sc.part_stride = e->part_stride; sc.init_scale = init_scale;

@@ -252,6 +252,33 @@ __device__ __forceinline__ void projection_jacobians(const CamGeom& g, const dou
 }
 
 
+// Point parameterisation.  rays == nullptr: the reference's free world point (photobundle.cc:692, :795: the three
+// parameters ARE X).  rays != nullptr: the inverse-depth variant named by the north star (no reference counterpart,
+// never parity-graded): the point lives on the fixed world ray rays[pt] = {origin o, direction d} and its parameters are
+// (rho, 0, 0), X = o + d / rho.  Only the first parameter is free: d(u, v)/d(params) = [Ap (-d / rho^2) | 0 | 0], so the
+// 3x3 point blocks degenerate to the scalar rho block plus two parameters that nothing ever moves (zero gradient, zero
+// coupling; their LM diagonal is the min_lm_diagonal floor) -- every kernel downstream runs unchanged.
+__device__ __forceinline__ void point_world(const double* __restrict__ rays, int pt, const double prm[3], double X[3], double q[3]) {
+  if (!rays) {
+    X[0] = prm[0]; X[1] = prm[1]; X[2] = prm[2];
+    q[0] = q[1] = q[2] = 0.0;
+  } else {
+    const double* r = rays + 6 * (size_t)pt;
+    const double inv = 1.0 / prm[0];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { X[k] = r[k] + r[3 + k] * inv; q[k] = -r[3 + k] * inv * inv; }
+  }
+}
+__device__ __forceinline__ void point_jacobian(const double* __restrict__ rays, const double q[3], double Ap[2][3]) {
+  if (rays) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const double a = Ap[r][0] * q[0] + Ap[r][1] * q[1] + Ap[r][2] * q[2];
+      Ap[r][0] = a; Ap[r][1] = 0.0; Ap[r][2] = 0.0;
+    }
+  }
+}
+
 // =====================================================================================================
 // device-side trust-region bookkeeping (asynchronous driver): the decisions of pba_lm.cpp for ONE step
 // =====================================================================================================
@@ -496,7 +523,8 @@ __device__ __forceinline__ void sample_generic(const uint32_t* __restrict__ fram
 struct SampleParams {
   const uint32_t* frames;     // [n_frames][rows*cols] packed texels
   const CamGeom* geom;        // [n_frames]
-  const double* xyz;          // [n_points][3]
+  const double* xyz;          // [n_points][3] point parameters (world XYZ, or (rho, 0, 0) in the inverse-depth variant)
+  const double* rays;         // null, or [n_points][6] fixed world rays of the inverse-depth variant (point_world)
   const float* desc;          // [n_points][P]
   const double* w2;           // [P] squared patch weights
   const int32_t* obs_point;   // [n_obs]
@@ -651,9 +679,11 @@ void k_sample(SampleParams p_in) {
       }
       const CamGeom& g = s_geom_prev[slot];
       if (!p.skip_backsub && g.free_index >= 0) {
-        double xw[3], Ac[2][6], Ap[2][3];
-        transform_point(g, X, xw);
-        projection_jacobians(g, X, xw, p.fx, p.fy, Ac, Ap);
+        double xw[3], Ac[2][6], Ap[2][3], Xw[3], qd[3];
+        point_world(p.rays, pt, X, Xw, qd);
+        transform_point(g, Xw, xw);
+        projection_jacobians(g, Xw, xw, p.fx, p.fy, Ac, Ap);
+        point_jacobian(p.rays, qd, Ap);
         const double* dc = p.delta_c + 6 * slot;
         double t0 = 0.0, t1 = 0.0;
 #pragma unroll
@@ -693,6 +723,11 @@ void k_sample(SampleParams p_in) {
     X[0] = p.xyz[3 * (size_t)pt]; X[1] = p.xyz[3 * (size_t)pt + 1]; X[2] = p.xyz[3 * (size_t)pt + 2];
   }
 
+  if (p.rays && active) {        // inverse-depth variant: parameters -> world point
+    double Xw[3], qd[3];
+    point_world(p.rays, pt, X, Xw, qd);
+    X[0] = Xw[0]; X[1] = Xw[1]; X[2] = Xw[2];
+  }
   PBA_STK(1);
   // ---- phase 1: geometry, one lane per observation (fp64) ------------------------------------------------
   double u = 0.0, v = 0.0;
@@ -917,18 +952,37 @@ void k_sample(SampleParams p_in) {
   } else if (active) {
     // border / clamped / rounding-irregular observation: per-pixel generic rule from global memory
     const uint32_t* frame = p.frames + (size_t)slot * p.rows * p.cols;
-    // (pixel coordinates re-derived from (u, v) here, so that the xf / yf arrays are dead during the regular walk)
+    // (pixel coordinates re-derived from (u, v) here, so that the xf / yf arrays are dead during the regular walk).
+    // One patch row at a time with all of the row's 4 W texel loads in flight together: a wave that holds a single
+    // irregular lane executes this path for everybody, so its latency (not its throughput) is what matters.
+#pragma unroll 1
     for (int i = 0; i < W; ++i) {
       const float yfi = (float)(v + (double)(i - R));
+      int y1, y2; float dy;
+      linear_init_axis(yfi, p.rows, y1, y2, dy);
+      const float omdy = __fsub_rn(1.0f, dy);
+      uint32_t t11[W], t12[W], t21[W], t22[W];
+      float dxj[W];
+#pragma unroll
       for (int j = 0; j < W; ++j) {
         const float xfj = (float)(u + (double)(j - R));
-        float sI, sgx = 0.f, sgy = 0.f;
-        sample_generic<JAC>(frame, p.rows, p.cols, yfi, xfj, sI, sgx, sgy);
+        int x1, x2;
+        linear_init_axis(xfj, p.cols, x1, x2, dxj[j]);
+        t11[j] = frame[(size_t)y1 * p.cols + x1]; t12[j] = frame[(size_t)y1 * p.cols + x2];
+        t21[j] = frame[(size_t)y2 * p.cols + x1]; t22[j] = frame[(size_t)y2 * p.cols + x2];
+      }
+#pragma unroll
+      for (int j = 0; j < W; ++j) {
+        const float dx = dxj[j];
+        const double omdxj = __dsub_rn(1.0, (double)dx);
+        const float sI = vlerp_exact(dy, omdy, hlerp_exact(dx, omdxj, tex_I(t11[j]), tex_I(t12[j])), hlerp_exact(dx, omdxj, tex_I(t21[j]), tex_I(t22[j])));
         const double e = (double)p0[i * W + j] - (double)sI;
         const double w2 = p.w2[i * W + j];
         cc += w2 * e * e;
         if (JAC) {
-          const double gx = (double)sgx, gy = (double)sgy;
+          // 2*G is blended and the exact power-of-two scale is applied at the end (as in sample_generic)
+          const double gx = (double)(0.5f * vlerp_exact(dy, omdy, hlerp_exact(dx, omdxj, tex_gx2(t11[j]), tex_gx2(t12[j])), hlerp_exact(dx, omdxj, tex_gx2(t21[j]), tex_gx2(t22[j]))));
+          const double gy = (double)(0.5f * vlerp_exact(dy, omdy, hlerp_exact(dx, omdxj, tex_gy2(t11[j]), tex_gy2(t12[j])), hlerp_exact(dx, omdxj, tex_gy2(t21[j]), tex_gy2(t22[j]))));
           const double wgx = w2 * gx, wgy = w2 * gy;
           m11 += wgx * gx; m12 += wgx * gy; m22 += wgy * gy;
           b1 += wgx * e; b2 += wgy * e;
@@ -1148,7 +1202,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_sample_mc(SampleParams p, con
   if (active) {
     pt = p.obs_point[obs];
     slot = p.obs_slot[obs];
-    const double X[3] = {p.xyz[3 * (size_t)pt], p.xyz[3 * (size_t)pt + 1], p.xyz[3 * (size_t)pt + 2]};
+    const double prm[3] = {p.xyz[3 * (size_t)pt], p.xyz[3 * (size_t)pt + 1], p.xyz[3 * (size_t)pt + 2]};
+    double X[3], qd[3];
+    point_world(p.rays, pt, prm, X, qd);
     double xw[3];
     transform_point(s_geom[slot], X, xw);
     project_point(xw, p.fx, p.fy, p.cx, p.cy, u, v);
@@ -1313,6 +1369,7 @@ constexpr size_t kSchurSmemBytes = sizeof(double) * (kTile * kObsStride + kTile)
 
 struct SchurParams {
   const double* xyz;
+  const double* rays;           // inverse-depth variant (point_world), else null
   const CamGeom* geom;
   const double* rec;            // SoA [6][rec_stride]
   const int32_t* obs_point;
@@ -1450,10 +1507,13 @@ __global__ __launch_bounds__(kTile, 2) void k_schur(SchurParams p_in) {
       if (!p.init_scale) { s_pt[0] = p.sp[3 * (size_t)pt]; s_pt[1] = p.sp[3 * (size_t)pt + 1]; s_pt[2] = p.sp[3 * (size_t)pt + 2]; }
       const CamGeom& g = s_geom[slot];
       fa = g.free_index;
-      const double X[3] = {p.xyz[3 * (size_t)pt], p.xyz[3 * (size_t)pt + 1], p.xyz[3 * (size_t)pt + 2]};
+      const double prm[3] = {p.xyz[3 * (size_t)pt], p.xyz[3 * (size_t)pt + 1], p.xyz[3 * (size_t)pt + 2]};
+      double X[3], qd[3];
+      point_world(p.rays, pt, prm, X, qd);
       double xw[3];
       transform_point(g, X, xw);
       projection_jacobians(g, X, xw, p.fx, p.fy, Ac, Ap);
+      point_jacobian(p.rays, qd, Ap);
       M[0] = p.rec[0 * p.rec_stride + obs]; M[1] = p.rec[1 * p.rec_stride + obs]; M[2] = p.rec[2 * p.rec_stride + obs];
       b[0] = p.rec[3 * p.rec_stride + obs]; b[1] = p.rec[4 * p.rec_stride + obs];
       // MAp = M Ap (2x3);  V_l = Ap^T M Ap;  g_l = -Ap^T b   (J = -w g A  =>  J^T r = -A^T b)
@@ -2230,6 +2290,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve_generic(SolveParams p_i
 // =====================================================================================================
 struct BacksubParams {
   const double* xyz;
+  const double* rays;        // inverse-depth variant (point_world), else null
   double* xyz_cand;
   const CamGeom* geom;
   const double* rec;
@@ -2253,15 +2314,18 @@ __global__ __launch_bounds__(256) void k_backsub(BacksubParams p) {
   if (p.geom_cand && blockIdx.x == gridDim.x - 1 && tid >= 256 - p.n_frames) cam_geom_one(p.cams_cand, p.geom_cand, 255 - tid, p.fixed_slot);
   double mcc = 0.0, st2 = 0.0, x2 = 0.0;
   if (pt < p.n_points) {
-    const double X[3] = {p.xyz[3 * (size_t)pt], p.xyz[3 * (size_t)pt + 1], p.xyz[3 * (size_t)pt + 2]};
+    const double X[3] = {p.xyz[3 * (size_t)pt], p.xyz[3 * (size_t)pt + 1], p.xyz[3 * (size_t)pt + 2]};   // parameters
+    double Xw[3], qd[3];
+    point_world(p.rays, pt, X, Xw, qd);
     double acc[3] = {0, 0, 0};
     for (int o = p.pt_begin[pt]; o < p.pt_begin[pt + 1]; ++o) {
       const int slot = p.obs_slot[o];
       const CamGeom& g = p.geom[slot];
       if (g.free_index < 0) continue;
       double xw[3], Ac[2][6], Ap[2][3];
-      transform_point(g, X, xw);
-      projection_jacobians(g, X, xw, p.fx, p.fy, Ac, Ap);
+      transform_point(g, Xw, xw);
+      projection_jacobians(g, Xw, xw, p.fx, p.fy, Ac, Ap);
+      point_jacobian(p.rays, qd, Ap);
       const double* dc = p.delta_c + 6 * slot;
       double t0 = 0.0, t1 = 0.0;
 #pragma unroll

@@ -118,6 +118,18 @@ class Engine:
         self.set_cameras(prob.cams, prob.fixed_slot)
         return self
 
+    def set_inverse_depth(self, rays, rho):
+        """Inverse-depth variant (include/pba.h): rays [n_points, 6] = world origin + direction, rho [n_points] > 0."""
+        rays = np.ascontiguousarray(rays, np.float64)
+        rho = np.ascontiguousarray(rho, np.float64)
+        assert rays.shape == (self.n_points, 6) and rho.shape == (self.n_points,)
+        self._check(self._L.pba_set_inverse_depth(self._h, _ptr(rays), _ptr(rho)), "pba_set_inverse_depth")
+
+    def get_points_world(self):
+        xyz = np.zeros((self.n_points, 3))
+        self._check(self._L.pba_get_points_world(self._h, _ptr(xyz)), "pba_get_points_world")
+        return xyz
+
     def get_state(self):
         cams = np.zeros((self.n_frames, 6))
         xyz = np.zeros((self.n_points, 3))

