@@ -252,16 +252,23 @@ def main():
     ms, launches, bytes_per_obs = kern[dom]
     avg_s = (ms / max(1, launches)) * 1e-3
     achieved = n_obs_local * bytes_per_obs / avg_s if avg_s > 0 else 0.0
-    traffic = None
+    # counter-based figures of the same kernel from the committed PMC passes (profiles/traffic.json, tools/collect_profiles.py):
+    # HBM-side bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, calibration in profiles/r02/fetch_calibration.txt) and the
+    # VALU instruction count, which gives the issue floor: wave instructions x 4 cycles / (1024 SIMDs x 2.4 GHz)
+    traffic = valu_insts = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
+    if os.path.exists(tpath) and default_shape and args.config == 1:
         try:
-            traffic = json.load(open(tpath)).get(dom.split(" ")[0])
+            tj = json.load(open(tpath))
+            traffic = tj.get(dom.split(" ")[0])
+            valu_insts = tj.get(dom.split(" ")[0] + "_valu_insts")
         except Exception:
-            traffic = None
+            traffic = valu_insts = None
     roofline = {
         "bound": "hbm", "kernel": dom, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
         "frac": achieved / HBM_PEAK, "traffic": traffic,
+        "traffic_frac": (traffic / avg_s / HBM_PEAK) if (traffic and avg_s > 0) else None,
+        "valu_floor_us": (valu_insts * 4.0 / (1024 * 2.4e9) * 1e6) if valu_insts else None,
         "avg_launch_us": avg_s * 1e6, "algorithmic_bytes_per_obs": bytes_per_obs,
         "whole_iteration_frac": (run_bytes / elapsed) / (HBM_PEAK * world),
         "kernels_ms_per_launch": {k: (v[0] / max(1, v[1])) for k, v in kern.items()},

@@ -206,7 +206,7 @@ void launch_sample(pba_engine* e, const SampleParams& sp) {
 }
 // one kernel for back-substitution + candidate pass + step finalisation, at every patch radius; the opt-in
 // reduced-precision sampler modes (pba_config.flags bits 1-2) keep the unfused kernels
-bool fused_capable(const pba_engine* e) { return e->fuse && ((e->cfg.flags >> 1) & 3) == 0 && e->channels == 1; }
+bool fused_capable(const pba_engine* e) { return e->fuse && ((e->cfg.flags >> 1) & 3) == 0 && e->channels == 1 && !e->inverse_depth; }
 int sample_waves_for_radius(int) { return kSampleWaves; }
 
 template <int NF>

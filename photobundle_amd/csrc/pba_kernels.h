@@ -600,6 +600,8 @@ void k_sample(SampleParams p_in) {
   static_assert(!FAST || UNITW, "the reduced-precision walk assumes unit patch weights");
   SampleParams p = p_in;
   if (!PBA_PHASE_TIMING) p.dbg = nullptr;
+  // the inverse-depth variant runs on the unfused kernels only (the fused ones keep their register budget)
+  const double* rays = FUSED ? nullptr : p.rays;
   if (FUSED && p.lm) {
     if (p.lm->done) return;
     if (p.lm->cur != p.enq_cur) {     // the host's parity guess was off by an odd number of accepted steps
@@ -680,10 +682,10 @@ void k_sample(SampleParams p_in) {
       const CamGeom& g = s_geom_prev[slot];
       if (!p.skip_backsub && g.free_index >= 0) {
         double xw[3], Ac[2][6], Ap[2][3], Xw[3], qd[3];
-        point_world(p.rays, pt, X, Xw, qd);
+        point_world(rays, pt, X, Xw, qd);
         transform_point(g, Xw, xw);
         projection_jacobians(g, Xw, xw, p.fx, p.fy, Ac, Ap);
-        point_jacobian(p.rays, qd, Ap);
+        point_jacobian(rays, qd, Ap);
         const double* dc = p.delta_c + 6 * slot;
         double t0 = 0.0, t1 = 0.0;
 #pragma unroll
@@ -723,9 +725,9 @@ void k_sample(SampleParams p_in) {
     X[0] = p.xyz[3 * (size_t)pt]; X[1] = p.xyz[3 * (size_t)pt + 1]; X[2] = p.xyz[3 * (size_t)pt + 2];
   }
 
-  if (p.rays && active) {        // inverse-depth variant: parameters -> world point
+  if (rays && active) {          // inverse-depth variant: parameters -> world point
     double Xw[3], qd[3];
-    point_world(p.rays, pt, X, Xw, qd);
+    point_world(rays, pt, X, Xw, qd);
     X[0] = Xw[0]; X[1] = Xw[1]; X[2] = Xw[2];
   }
   PBA_STK(1);
@@ -2045,21 +2047,26 @@ __global__ __launch_bounds__(256) void k_solve_wave(SolveParams p_in) {
     }
     double pre0 = S[r * LD + 0], pre1 = 0.0;
     double lr_prev = 0.0;            // this lane's entry of the previous column
+    // lane - j, carried through the (fully unrolled) loop behind an optimisation barrier: written as `lane > j` the 2 N
+    // comparisons are loop invariant, get hoisted, and their 2 N mask pairs spill from the scalar registers
+    int rem = lane;
 #pragma unroll
     for (int j = 0; j < N; ++j) {
+      asm volatile("" : "+v"(rem));
+      const bool below = rem > 0, here = rem == 0;       // row r is below / on the diagonal of column j
       // finish column j: only the term with L_j,j-1 (lane j's entry of the previous column) was still missing
       double v = pre0 + pre1;
       if (j > 0) v = fma(-lr_prev, readlane_f64(lr_prev, j), v);
-      // rows <= j are complete: what they compute from here on is never read (their L entries are not published, their
-      // y is frozen by the select below), so the value is not masked to zero
+      // rows <= j are complete: what they compute from here on is never read (their y is frozen by the select below and
+      // the LT entries they write lie on or above the diagonal, which nobody reads), so nothing is masked to zero
       const double lrj = v * inv;
       L[j] = lrj;
       lr_prev = lrj;
       // right-hand side, column-oriented forward substitution: z_j = y_j / L_jj, then y_r -= L_rj z_j below
       const double zj = readlane_f64(y, j) * inv;
-      if (lane == j) d_own = inv;
-      y = (lane > j) ? fma(-lrj, zj, y) : ((lane == j) ? zj : y);
-      if (live && lane > j) LT[r * LE + j] = lrj;
+      d_own = here ? inv : d_own;
+      y = below ? fma(-lrj, zj, y) : (here ? zj : y);
+      LT[r * LE + j] = lrj;
       diag = fma(-lrj, lrj, diag);
       if (j + 1 < N) {
         // next pivot: every lane takes row j + 1's running diagonal and inverts it itself
@@ -2084,20 +2091,23 @@ __global__ __launch_bounds__(256) void k_solve_wave(SolveParams p_in) {
         pre0 += pre2; pre1 += pre3;
       }
       wave_lds_sync();
+      rem -= 1;
     }
     t2 = (PBA_PHASE_TIMING ? __builtin_amdgcn_s_memtime() : 0ull);
     // backward substitution L^T x = z: lane r needs column r of L = L[j][r] for j > r; fetched up front (independent
-    // LDS reads, contiguous across lanes) so that the sweep itself is mul -> readlane -> fma per row
+    // LDS reads, contiguous across lanes) so that the sweep itself is mul -> readlane -> fma per row.  Entries on or
+    // above the diagonal (j <= r) hold leftovers of the factorisation: the select in the sweep never lets them in.
     double lc[N];
 #pragma unroll
-    for (int j = 0; j < N; ++j) lc[j] = (lane < j) ? LT[j * LE + r] : 0.0;
+    for (int j = 0; j < N; ++j) lc[j] = LT[j * LE + r];
+    rem = lane - (N - 1);
 #pragma unroll
     for (int j = N - 1; j >= 0; --j) {
-      // x_j = y_j / L_jj on every lane (inv_j is not kept: d_own of lane j crosses with the value), lc[j] is zero for
-      // lanes >= j
+      asm volatile("" : "+v"(rem));
+      // x_j = y_j / L_jj on every lane (inv_j is not kept: d_own of lane j crosses with the value)
       const double xj = readlane_f64(y * d_own, j);
-      if (lane == j) y = xj;
-      y = fma(-lc[j], xj, y);
+      y = (rem < 0) ? fma(-lc[j], xj, y) : ((rem == 0) ? xj : y);      // rem = lane - j
+      rem += 1;
     }
     if (lane < N) y_s[lane] = y;
     if (lane == 0) s_ok = ok ? 1 : 0;
