@@ -19,9 +19,9 @@
 #endif
 
 // Resident waves per SIMD the Jacobian-pass sampling kernel is compiled for at patch radius <= 2 (register budget
-// 512 / N VGPRs; 38.6 KB of LDS per 256-thread workgroup allows 4).
+// 512 / N VGPRs; 38.6 KB of LDS per 256-thread workgroup allows 4).  Measured at configs[1]: 4 -> 49.3 us, 3 -> 52.1 us.
 #ifndef PBA_SAMPLE_WAVES_PER_SIMD
-#define PBA_SAMPLE_WAVES_PER_SIMD 3
+#define PBA_SAMPLE_WAVES_PER_SIMD 4
 #endif
 // Order of the exact patch walk inside one footprint row (see k_sample): experiment switch
 #ifndef PBA_WALK_ROWWISE
