@@ -2054,6 +2054,16 @@ __global__ __launch_bounds__(256) void k_solve_wave(SolveParams p_in) {
     for (int j = 0; j < N; ++j) {
       asm volatile("" : "+v"(rem));
       const bool below = rem > 0, here = rem == 0;       // row r is below / on the diagonal of column j
+      // operands of the NEXT column's prefix (row j + 1 of L, entries k < j: all in LDS since the end of the previous
+      // step) are requested first, so that their LDS latency runs under the dependent chain of this column
+      double2 rw[(N + 1) / 2];
+      const double a_next = (j + 1 < N) ? S[r * LD + j + 1] : 0.0;
+      if (j + 1 < N) {
+#pragma unroll
+        for (int k = 0; k + 1 < j; k += 2) rw[k / 2] = *reinterpret_cast<const double2*>(&LT[(j + 1) * LE + k]);
+        if (j & 1) rw[j / 2].x = LT[(j + 1) * LE + j - 1];
+      }
+      asm volatile("" ::: "memory");     // the requests stay here, ahead of the chain (the compiler would sink them next to their uses)
       // finish column j: only the term with L_j,j-1 (lane j's entry of the previous column) was still missing
       double v = pre0 + pre1;
       if (j > 0) v = fma(-lr_prev, readlane_f64(lr_prev, j), v);
@@ -2074,20 +2084,22 @@ __global__ __launch_bounds__(256) void k_solve_wave(SolveParams p_in) {
         const bool pd = (dn > 0.0) && isfinite(dn);
         ok = ok && pd;
         inv = fast_rsqrt(pd ? dn : 1.0);
-        // prefix of column j + 1 from row j + 1 of L, entries k < j (in LDS since the previous column at the latest)
-        pre0 = S[r * LD + j + 1]; pre1 = 0.0;
+        // prefix of column j + 1: four independent partial sums over k < j (same association as before); ONE wait for all
+        // of the row instead of one per operand pair
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < (j + 1) / 2; ++k) asm volatile("" : "+v"(rw[k].x), "+v"(rw[k].y));   // the sums start here, not earlier
+        pre0 = a_next; pre1 = 0.0;
         double pre2 = 0.0, pre3 = 0.0;
 #pragma unroll
         for (int k = 0; k + 3 < j; k += 4) {
-          const double2 la = *reinterpret_cast<const double2*>(&LT[(j + 1) * LE + k]);
-          const double2 lb = *reinterpret_cast<const double2*>(&LT[(j + 1) * LE + k + 2]);
-          pre0 = fma(-L[k], la.x, pre0);
-          pre1 = fma(-L[k + 1], la.y, pre1);
-          pre2 = fma(-L[k + 2], lb.x, pre2);
-          pre3 = fma(-L[k + 3], lb.y, pre3);
+          pre0 = fma(-L[k], rw[k / 2].x, pre0);
+          pre1 = fma(-L[k + 1], rw[k / 2].y, pre1);
+          pre2 = fma(-L[k + 2], rw[k / 2 + 1].x, pre2);
+          pre3 = fma(-L[k + 3], rw[k / 2 + 1].y, pre3);
         }
 #pragma unroll
-        for (int k = j & ~3; k < j; ++k) pre0 = fma(-L[k], LT[(j + 1) * LE + k], pre0);
+        for (int k = j & ~3; k < j; ++k) pre0 = fma(-L[k], (k & 1) ? rw[k / 2].y : rw[k / 2].x, pre0);
         pre0 += pre2; pre1 += pre3;
       }
       wave_lds_sync();
