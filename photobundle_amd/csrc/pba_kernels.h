@@ -638,13 +638,32 @@ void k_sample(SampleParams p_in) {
 
   // camera geometry tables -> LDS (the texel region is free until the staging phase)
   CamGeom* s_geom = reinterpret_cast<CamGeom*>(s_raw + sizeof(double) * 3 * WAVES * 64);
-  CamGeom* s_geom_prev = s_geom + kMaxFrames;
+  // compact table of the PREVIOUS cameras for the back-substitution, per slot: R (9) | t (3) | Omega (9) | dt (3) |
+  // free index (1): with Omega_a = sum_k dw_k dR_k (the step's rotation part applied to the stored derivative matrices)
+  // the camera step enters every observation as  Ac dc = dpi (Omega_a X + dt_a)  and the point side as
+  // Ap^T u = R^T (dpi^T u): ~60 fp64 operations per observation instead of the full 2x6 / 2x3 Jacobians
+  constexpr int kBk = 26;
+  static_assert(kBk * sizeof(double) <= sizeof(CamGeom), "the compact table fits the second camera-table slot");
+  double* s_bk = reinterpret_cast<double*>(s_geom + kMaxFrames);
   unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tl = p.dbg ? __builtin_amdgcn_s_memtime() : 0;
   const unsigned long long t_begin = p.dbg ? __builtin_amdgcn_s_memrealtime() : 0;   // 100 MHz, device-wide
 #define PBA_STK(k) do { if (p.dbg) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); tk[k] += tn - tl; tl = tn; } } while (0)
   stage_geom<WAVES * 64>(p.geom, s_geom, p.n_frames, threadIdx.x);
-  if (FUSED && !p.skip_backsub) stage_geom<WAVES * 64>(p.geom_prev, s_geom_prev, p.n_frames, threadIdx.x);
+  if (FUSED && !p.skip_backsub) {
+    for (int e = threadIdx.x; e < kBk * p.n_frames; e += WAVES * 64) {
+      const int a = e / kBk, k = e - a * kBk;
+      const CamGeom& gp = p.geom_prev[a];
+      const double* dc = p.delta_c + 6 * a;
+      double val;
+      if (k < 9) val = gp.R[k];
+      else if (k < 12) val = gp.t[k - 9];
+      else if (k < 21) val = dc[0] * gp.dR[k - 12] + dc[1] * gp.dR[9 + k - 12] + dc[2] * gp.dR[18 + k - 12];
+      else if (k < 24) val = dc[3 + k - 21];
+      else val = (double)gp.free_index;
+      s_bk[e] = val;
+    }
+  }
   lds_barrier();
   PBA_STK(0);
 
@@ -679,21 +698,26 @@ void k_sample(SampleParams p_in) {
 #pragma unroll
       for (int k = 0; k < 3; ++k) spk[k] = p.sp[3 * (size_t)pt + k];
       }
-      const CamGeom& g = s_geom_prev[slot];
-      if (!p.skip_backsub && g.free_index >= 0) {
-        double xw[3], Ac[2][6], Ap[2][3], Xw[3], qd[3];
-        point_world(rays, pt, X, Xw, qd);
-        transform_point(g, Xw, xw);
-        projection_jacobians(g, Xw, xw, p.fx, p.fy, Ac, Ap);
-        point_jacobian(rays, qd, Ap);
-        const double* dc = p.delta_c + 6 * slot;
-        double t0 = 0.0, t1 = 0.0;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) { t0 += Ac[0][k] * dc[k]; t1 += Ac[1][k] * dc[k]; }
+      const double* bk = s_bk + kBk * slot;
+      if (!p.skip_backsub && bk[24] >= 0.0) {
+        // xw = R X + t (plain order: this point only feeds the derivative of the projection, not a sampled position)
+        const double xw0 = bk[0] * X[0] + bk[1] * X[1] + bk[2] * X[2] + bk[9];
+        const double xw1 = bk[3] * X[0] + bk[4] * X[1] + bk[5] * X[2] + bk[10];
+        const double xw2 = bk[6] * X[0] + bk[7] * X[1] + bk[8] * X[2] + bk[11];
+        const double iz = fast_rcp(xw2);
+        const double ju0 = p.fx * iz, ju2 = -p.fx * xw0 * iz * iz;
+        const double jv1 = p.fy * iz, jv2 = -p.fy * xw1 * iz * iz;
+        // Ac dc = dpi (Omega X + dt)
+        const double s0 = bk[12] * X[0] + bk[13] * X[1] + bk[14] * X[2] + bk[21];
+        const double s1 = bk[15] * X[0] + bk[16] * X[1] + bk[17] * X[2] + bk[22];
+        const double s2 = bk[18] * X[0] + bk[19] * X[1] + bk[20] * X[2] + bk[23];
+        const double t0 = ju0 * s0 + ju2 * s2, t1 = jv1 * s1 + jv2 * s2;
         const double m0 = p.rec_prev[0 * p.rec_stride + obs], m1 = p.rec_prev[1 * p.rec_stride + obs], m2 = p.rec_prev[2 * p.rec_stride + obs];
         const double u0 = m0 * t0 + m1 * t1, u1 = m1 * t0 + m2 * t1;
+        // W_l^T dc = Ap^T u = R^T (dpi^T u)
+        const double w0 = ju0 * u0, w1 = jv1 * u1, w2 = ju2 * u0 + jv2 * u1;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) c3[k] = Ap[0][k] * u0 + Ap[1][k] * u1;
+        for (int k = 0; k < 3; ++k) c3[k] = bk[k] * w0 + bk[3 + k] * w1 + bk[6 + k] * w2;
       }
     }
     s_bs[threadIdx.x * 3 + 0] = c3[0]; s_bs[threadIdx.x * 3 + 1] = c3[1]; s_bs[threadIdx.x * 3 + 2] = c3[2];
