@@ -23,6 +23,10 @@
 #ifndef PBA_SAMPLE_WAVES_PER_SIMD
 #define PBA_SAMPLE_WAVES_PER_SIMD 4
 #endif
+// Timing experiment only (results are WRONG): irregular observations contribute nothing
+#ifndef PBA_EXPERIMENT_SKIP_IRREGULAR
+#define PBA_EXPERIMENT_SKIP_IRREGULAR 0
+#endif
 // Order of the exact patch walk inside one footprint row (see k_sample): experiment switch
 #ifndef PBA_WALK_ROWWISE
 #define PBA_WALK_ROWWISE 0
@@ -626,6 +630,7 @@ void k_sample(SampleParams p_in) {
   __shared__ __attribute__((aligned(16))) char s_raw[kTexBytes > kPreBytes ? kTexBytes : kPreBytes];
   uint32_t (*s_tex)[FF * LSTRIDE] = reinterpret_cast<uint32_t (*)[FF * LSTRIDE]>(s_raw);
   __shared__ int32_t s_base[WAVES][64];
+  __shared__ int32_t s_irr[(sample_rows_per_batch(R) == 2 * R + 2) ? WAVES : 1][64];   // (by0 << 16) | bx0 of windowed irregular observations
   __shared__ double s_red[4 * WAVES];
   __shared__ int32_t s_fail;
 
@@ -780,7 +785,39 @@ void k_sample(SampleParams p_in) {
     for (int j = 1; j < W; ++j) reg = reg && (trunc_x86(xf[j]) == bx + j) && (trunc_x86(yf[j]) == by + j);
     regular = reg;
   }
-  s_base[wave][lane] = (active && regular) ? (int32_t)(slot * (p.rows * p.cols) + by * p.cols + bx) : -1;
+  // Irregular observations (patch over the image border, clamped taps: sample_eigen.h:38-51) whose taps all fall into
+  // one F x F window of CLAMPED pixel coordinates anchored at the first tap (by0, bx0) are staged like the regular ones,
+  // texel by texel with clamped addresses, and walked with per-tap indices out of LDS (kWindow: whole footprint resident,
+  // i.e. patch radius <= 2).  Anything else -- float-rounding anomalies that stretch the window, images of 32k+ rows --
+  // keeps the per-pixel path from global memory.  A wave runs the irregular code if ANY of its lanes needs it, so its
+  // latency matters: ~240 of 6250 waves at BASELINE configs[1].
+  constexpr bool kWindow = (RB == F);
+  bool win_irr = false;
+  int by0 = 0, bx0 = 0;
+  if (kWindow && active && !regular && p.rows < 32768 && p.cols < 65536) {
+    int a1, a2, l1, l2; float dd;
+    linear_init_axis(yf[0], p.rows, a1, a2, dd);
+    linear_init_axis(yf[W - 1], p.rows, l1, l2, dd);
+    by0 = a1;
+    bool fits = (l2 - a1) <= W && l2 >= a1;
+    linear_init_axis(xf[0], p.cols, a1, a2, dd);
+    linear_init_axis(xf[W - 1], p.cols, l1, l2, dd);
+    bx0 = a1;
+    fits = fits && (l2 - a1) <= W && l2 >= a1;
+    // monotone taps in between (NaN / wild coordinates fail here)
+#pragma unroll
+    for (int j = 1; j < W - 1; ++j) {
+      int m1, m2;
+      linear_init_axis(yf[j], p.rows, m1, m2, dd);
+      fits = fits && m1 >= by0 && m2 <= by0 + W;
+      linear_init_axis(xf[j], p.cols, m1, m2, dd);
+      fits = fits && m1 >= bx0 && m2 <= bx0 + W;
+    }
+    win_irr = fits;
+  }
+  // >= 0: regular, linear texel index of the footprint origin;  -1: nothing to stage;  <= -2: windowed irregular, slot
+  s_base[wave][lane] = (active && regular) ? (int32_t)(slot * (p.rows * p.cols) + by * p.cols + bx) : (win_irr ? -2 - slot : -1);
+  if (kWindow) s_irr[wave][lane] = (by0 << 16) | bx0;
   lds_barrier();
   PBA_STK(2);
 
@@ -841,11 +878,23 @@ void k_sample(SampleParams p_in) {
             for (int j = 0; j < CW; ++j) tx[gg][rr][j] = 0;
             if (bs[gg] >= 0) __builtin_memcpy(tx[gg][rr], fbytes + (boff + (uint32_t)((r0 + rr) * p.cols) * 4u), sizeof(uint32_t) * CW);
           }
+          if (kWindow && bs[gg] <= -2) {
+            // windowed irregular observation: the same F x F window, every texel at its clamped coordinates
+            const int ir = s_irr[wave][o & 63];
+            const int wy = ir >> 16, wx = ir & 0xffff;
+            const uint32_t* fr = p.frames + (size_t)(-2 - bs[gg]) * p.rows * p.cols;
+#pragma unroll
+            for (int rr = 0; rr < RB; ++rr) {
+              const int row = min(wy + rr, p.rows - 1);
+#pragma unroll
+              for (int j = 0; j < CW; ++j) tx[gg][rr][j] = fr[(size_t)row * p.cols + min(wx + ch * CW + j, p.cols - 1)];
+            }
+          }
         }
 #pragma unroll
         for (int gg = 0; gg < GB; ++gg) {
           const int o = (g0 + gg) * OPI + oi;
-          if (bs[gg] >= 0) {
+          if (bs[gg] != -1) {
             uint32_t* dst = &s_tex[wave][(ch * CW) * LSTRIDE + o];
 #pragma unroll
             for (int rr = 0; rr < RB; ++rr) {
@@ -975,8 +1024,40 @@ void k_sample(SampleParams p_in) {
     } else if (JAC) {
       m11 *= 0.25; m12 *= 0.25; m22 *= 0.25; b1 *= 0.5; b2 *= 0.5;   // (2G)^2 / 4, (2G) e / 2: exact
     }
-  } else if (active) {
-    // border / clamped / rounding-irregular observation: per-pixel generic rule from global memory
+  } else if (kWindow && win_irr) {
+    // windowed irregular observation: the reference's per-tap rule (sample_eigen.h:38-51, :82-101) with the four texels
+    // of every pixel taken from the staged window at their clamped coordinates
+    const uint32_t* tw = &s_tex[wave][lane];
+#pragma unroll 1
+    for (int i = 0; i < W; ++i) {
+      const float yfi = (float)(v + (double)(i - R));
+      int y1, y2; float dy;
+      linear_init_axis(yfi, p.rows, y1, y2, dy);
+      const float omdy = __fsub_rn(1.0f, dy);
+      const int o1 = (y1 - by0) * F - bx0, o2 = (y2 - by0) * F - bx0;
+#pragma unroll
+      for (int j = 0; j < W; ++j) {
+        const float xfj = (float)(u + (double)(j - R));
+        int x1, x2; float dx;
+        linear_init_axis(xfj, p.cols, x1, x2, dx);
+        const uint32_t t11 = tw[(o1 + x1) * LSTRIDE], t12 = tw[(o1 + x2) * LSTRIDE];
+        const uint32_t t21 = tw[(o2 + x1) * LSTRIDE], t22 = tw[(o2 + x2) * LSTRIDE];
+        const double omdxj = __dsub_rn(1.0, (double)dx);
+        const float sI = vlerp_exact(dy, omdy, hlerp_exact(dx, omdxj, tex_I(t11), tex_I(t12)), hlerp_exact(dx, omdxj, tex_I(t21), tex_I(t22)));
+        const double e = (double)p0[i * W + j] - (double)sI;
+        const double w2 = p.w2[i * W + j];
+        cc += w2 * e * e;
+        if (JAC) {
+          const double gx = (double)(0.5f * vlerp_exact(dy, omdy, hlerp_exact(dx, omdxj, tex_gx2(t11), tex_gx2(t12)), hlerp_exact(dx, omdxj, tex_gx2(t21), tex_gx2(t22))));
+          const double gy = (double)(0.5f * vlerp_exact(dy, omdy, hlerp_exact(dx, omdxj, tex_gy2(t11), tex_gy2(t12)), hlerp_exact(dx, omdxj, tex_gy2(t21), tex_gy2(t22))));
+          const double wgx = w2 * gx, wgy = w2 * gy;
+          m11 += wgx * gx; m12 += wgx * gy; m22 += wgy * gy;
+          b1 += wgx * e; b2 += wgy * e;
+        }
+      }
+    }
+  } else if (active && !PBA_EXPERIMENT_SKIP_IRREGULAR) {
+    // rounding-irregular / wild observation (and every irregular one at patch radius > 2): per-pixel generic rule from global memory
     const uint32_t* frame = p.frames + (size_t)slot * p.rows * p.cols;
     // (pixel coordinates re-derived from (u, v) here, so that the xf / yf arrays are dead during the regular walk).
     // One patch row at a time with all of the row's 4 W texel loads in flight together: a wave that holds a single
