@@ -58,6 +58,13 @@ __device__ __forceinline__ double wave_max(double v) {
   return v;
 }
 
+// One lane's double for the whole wave (the lane index must be wave-uniform): lands in scalar registers.
+__device__ __forceinline__ double readlane_f64(double v, int src_lane) {
+  const unsigned lo = __builtin_amdgcn_readlane((unsigned)__double2loint(v), src_lane);
+  const unsigned hi = __builtin_amdgcn_readlane((unsigned)__double2hiint(v), src_lane);
+  return __hiloint2double((int)hi, (int)lo);
+}
+
 // Cooperative copy of the per-camera geometry table into LDS (8-byte words, coalesced): the per-lane gathers of
 // ~50 doubles per observation then hit LDS instead of going through the vector memory path.
 template <int NT>
@@ -1024,39 +1031,7 @@ void k_sample(SampleParams p_in) {
     } else if (JAC) {
       m11 *= 0.25; m12 *= 0.25; m22 *= 0.25; b1 *= 0.5; b2 *= 0.5;   // (2G)^2 / 4, (2G) e / 2: exact
     }
-  } else if (kWindow && win_irr) {
-    // windowed irregular observation: the reference's per-tap rule (sample_eigen.h:38-51, :82-101) with the four texels
-    // of every pixel taken from the staged window at their clamped coordinates
-    const uint32_t* tw = &s_tex[wave][lane];
-#pragma unroll 1
-    for (int i = 0; i < W; ++i) {
-      const float yfi = (float)(v + (double)(i - R));
-      int y1, y2; float dy;
-      linear_init_axis(yfi, p.rows, y1, y2, dy);
-      const float omdy = __fsub_rn(1.0f, dy);
-      const int o1 = (y1 - by0) * F - bx0, o2 = (y2 - by0) * F - bx0;
-#pragma unroll
-      for (int j = 0; j < W; ++j) {
-        const float xfj = (float)(u + (double)(j - R));
-        int x1, x2; float dx;
-        linear_init_axis(xfj, p.cols, x1, x2, dx);
-        const uint32_t t11 = tw[(o1 + x1) * LSTRIDE], t12 = tw[(o1 + x2) * LSTRIDE];
-        const uint32_t t21 = tw[(o2 + x1) * LSTRIDE], t22 = tw[(o2 + x2) * LSTRIDE];
-        const double omdxj = __dsub_rn(1.0, (double)dx);
-        const float sI = vlerp_exact(dy, omdy, hlerp_exact(dx, omdxj, tex_I(t11), tex_I(t12)), hlerp_exact(dx, omdxj, tex_I(t21), tex_I(t22)));
-        const double e = (double)p0[i * W + j] - (double)sI;
-        const double w2 = p.w2[i * W + j];
-        cc += w2 * e * e;
-        if (JAC) {
-          const double gx = (double)(0.5f * vlerp_exact(dy, omdy, hlerp_exact(dx, omdxj, tex_gx2(t11), tex_gx2(t12)), hlerp_exact(dx, omdxj, tex_gx2(t21), tex_gx2(t22))));
-          const double gy = (double)(0.5f * vlerp_exact(dy, omdy, hlerp_exact(dx, omdxj, tex_gy2(t11), tex_gy2(t12)), hlerp_exact(dx, omdxj, tex_gy2(t21), tex_gy2(t22))));
-          const double wgx = w2 * gx, wgy = w2 * gy;
-          m11 += wgx * gx; m12 += wgx * gy; m22 += wgy * gy;
-          b1 += wgx * e; b2 += wgy * e;
-        }
-      }
-    }
-  } else if (active && !PBA_EXPERIMENT_SKIP_IRREGULAR) {
+  } else if (active && !win_irr && !PBA_EXPERIMENT_SKIP_IRREGULAR) {
     // rounding-irregular / wild observation (and every irregular one at patch radius > 2): per-pixel generic rule from global memory
     const uint32_t* frame = p.frames + (size_t)slot * p.rows * p.cols;
     // (pixel coordinates re-derived from (u, v) here, so that the xf / yf arrays are dead during the regular walk).
@@ -1098,6 +1073,48 @@ void k_sample(SampleParams p_in) {
     }
   }
 
+  if constexpr (kWindow) {
+    // Windowed irregular observations, one at a time with the WAVE on one patch: lane = pixel (W^2 <= 25 lanes busy), the
+    // reference's per-tap rule (sample_eigen.h:38-51, :82-101) with the four texels of the pixel taken from the staged
+    // window of lane `src`, then six fixed-order wave reductions.  A lane-serial walk of the per-tap rule costs ~3x the
+    // regular walk and every lane of the wave waits for it; this costs ~200 instructions per irregular observation.
+    static_assert(W * W <= 64, "one lane per pixel");
+    unsigned long long im = __ballot(win_irr);
+    while (im) {
+      const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)im) - 1);
+      im &= im - 1;
+      const double us = readlane_f64(u, src), vs = readlane_f64(v, src);
+      const int wy = __builtin_amdgcn_readlane(by0, src), wx = __builtin_amdgcn_readlane(bx0, src);
+      const int pts = __builtin_amdgcn_readlane(pt, src);
+      double q_cc = 0.0, q11 = 0.0, q12 = 0.0, q22 = 0.0, q1 = 0.0, q2 = 0.0;
+      if (lane < W * W) {
+        const int i = lane / W, j = lane - i * W;
+        const float yfi = (float)(vs + (double)(i - R)), xfj = (float)(us + (double)(j - R));
+        int y1, y2, x1, x2; float dy, dx;
+        linear_init_axis(yfi, p.rows, y1, y2, dy);
+        linear_init_axis(xfj, p.cols, x1, x2, dx);
+        const float omdy = __fsub_rn(1.0f, dy);
+        const double omdxj = __dsub_rn(1.0, (double)dx);
+        const uint32_t* tw = &s_tex[wave][src];
+        const int o1 = (y1 - wy) * F - wx, o2 = (y2 - wy) * F - wx;
+        const uint32_t t11 = tw[(o1 + x1) * LSTRIDE], t12 = tw[(o1 + x2) * LSTRIDE];
+        const uint32_t t21 = tw[(o2 + x1) * LSTRIDE], t22 = tw[(o2 + x2) * LSTRIDE];
+        const float sI = vlerp_exact(dy, omdy, hlerp_exact(dx, omdxj, tex_I(t11), tex_I(t12)), hlerp_exact(dx, omdxj, tex_I(t21), tex_I(t22)));
+        const double e = (double)p.desc[(size_t)pts * (W * W) + lane] - (double)sI;
+        const double w2 = p.w2[lane];
+        q_cc = w2 * e * e;
+        if (JAC) {
+          const double gx = (double)(0.5f * vlerp_exact(dy, omdy, hlerp_exact(dx, omdxj, tex_gx2(t11), tex_gx2(t12)), hlerp_exact(dx, omdxj, tex_gx2(t21), tex_gx2(t22))));
+          const double gy = (double)(0.5f * vlerp_exact(dy, omdy, hlerp_exact(dx, omdxj, tex_gy2(t11), tex_gy2(t12)), hlerp_exact(dx, omdxj, tex_gy2(t21), tex_gy2(t22))));
+          const double wgx = w2 * gx, wgy = w2 * gy;
+          q11 = wgx * gx; q12 = wgx * gy; q22 = wgy * gy; q1 = wgx * e; q2 = wgy * e;
+        }
+      }
+      q_cc = wave_sum(q_cc);
+      if (JAC) { q11 = wave_sum(q11); q12 = wave_sum(q12); q22 = wave_sum(q22); q1 = wave_sum(q1); q2 = wave_sum(q2); }
+      if (lane == src) { cc = q_cc; m11 = q11; m12 = q12; m22 = q22; b1 = q1; b2 = q2; }
+    }
+  }
   PBA_STK(4);
   // ---- phase 4: loss (HuberLoss::Evaluate + Corrector with rho'' <= 0), record, block cost ---------------
   double cost_obs = 0.0;
@@ -1994,11 +2011,6 @@ __device__ __forceinline__ bool solve_resolve(SolveParams& p) {
   return true;
 }
 
-__device__ __forceinline__ double readlane_f64(double v, int src_lane) {
-  const unsigned lo = __builtin_amdgcn_readlane((unsigned)__double2loint(v), src_lane);
-  const unsigned hi = __builtin_amdgcn_readlane((unsigned)__double2hiint(v), src_lane);
-  return __hiloint2double((int)hi, (int)lo);
-}
 
 // Shared prologue: scale / damp / scatter the packed pair blocks into the dense symmetric matrix S (LDS, leading
 // dimension ld), right-hand side into y.  T threads.
