@@ -1081,11 +1081,22 @@ void k_sample(SampleParams p_in) {
     static_assert(W * W <= 64, "one lane per pixel");
     unsigned long long im = __ballot(win_irr);
     while (im) {
-      const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)im) - 1);
-      im &= im - 1;
+      // up to four irregular observations per trip: their descriptor values (lane = pixel) are requested together, so
+      // that one global round trip serves four patches
+      int srcs[4]; float dsc[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        srcs[k] = im ? __builtin_amdgcn_readfirstlane(__ffsll((long long)im) - 1) : -1;
+        if (im) im &= im - 1;
+        dsc[k] = 0.f;
+        if (srcs[k] >= 0 && lane < W * W) dsc[k] = p.desc[(size_t)__builtin_amdgcn_readlane(pt, srcs[k] < 0 ? 0 : srcs[k]) * (W * W) + lane];
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+      const int src = srcs[k];
+      if (src < 0) break;
       const double us = readlane_f64(u, src), vs = readlane_f64(v, src);
       const int wy = __builtin_amdgcn_readlane(by0, src), wx = __builtin_amdgcn_readlane(bx0, src);
-      const int pts = __builtin_amdgcn_readlane(pt, src);
       double q_cc = 0.0, q11 = 0.0, q12 = 0.0, q22 = 0.0, q1 = 0.0, q2 = 0.0;
       if (lane < W * W) {
         const int i = lane / W, j = lane - i * W;
@@ -1100,8 +1111,8 @@ void k_sample(SampleParams p_in) {
         const uint32_t t11 = tw[(o1 + x1) * LSTRIDE], t12 = tw[(o1 + x2) * LSTRIDE];
         const uint32_t t21 = tw[(o2 + x1) * LSTRIDE], t22 = tw[(o2 + x2) * LSTRIDE];
         const float sI = vlerp_exact(dy, omdy, hlerp_exact(dx, omdxj, tex_I(t11), tex_I(t12)), hlerp_exact(dx, omdxj, tex_I(t21), tex_I(t22)));
-        const double e = (double)p.desc[(size_t)pts * (W * W) + lane] - (double)sI;
-        const double w2 = p.w2[lane];
+        const double e = (double)dsc[k] - (double)sI;
+        const double w2 = UNITW ? 1.0 : p.w2[lane];
         q_cc = w2 * e * e;
         if (JAC) {
           const double gx = (double)(0.5f * vlerp_exact(dy, omdy, hlerp_exact(dx, omdxj, tex_gx2(t11), tex_gx2(t12)), hlerp_exact(dx, omdxj, tex_gx2(t21), tex_gx2(t22))));
@@ -1113,6 +1124,7 @@ void k_sample(SampleParams p_in) {
       q_cc = wave_sum(q_cc);
       if (JAC) { q11 = wave_sum(q11); q12 = wave_sum(q12); q22 = wave_sum(q22); q1 = wave_sum(q1); q2 = wave_sum(q2); }
       if (lane == src) { cc = q_cc; m11 = q11; m12 = q12; m22 = q22; b1 = q1; b2 = q2; }
+      }
     }
   }
   PBA_STK(4);
