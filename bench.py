@@ -8,9 +8,13 @@ One "step" = one trust-region LM iteration of the reference's solve (reference s
 solve of the stored linearisation + candidate cost pass, and -- when the step is accepted -- the Jacobian pass at the
 new point.  Workload at N = 1: BASELINE.json configs[1] (8-frame window, 50k points, 5x5 patch, single level, synthetic
 KITTI-shaped frames).  N > 1 is WEAK scaling: every rank owns 50k points of one N*50k-point window, all
-cameras/frames replicated, one RCCL all-reduce of the reduced camera system per solve; `value` is the whole-job rate
+cameras/frames replicated, one RCCL all-reduce of the reduced camera system per step; `value` is the whole-job rate
 in 50k-point-window LM iterations per second (= N * iterations/sec), `residuals_per_sec` is the same thing in scalar
 residual evaluations.  Inputs are resident in HBM before the timed region.
+
+--config 3 is BASELINE.json configs[3] as a STRONG-scaling workload: ONE 16-frame x 200k-point window whose points are
+sharded over the N ranks (`value` = LM iterations per second of that one window, not multiplied by N); --config 4 is
+configs[4] (11x11 patches + Huber 0.05, weak scaling like configs[1]).
 """
 import argparse
 import json
