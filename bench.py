@@ -276,6 +276,10 @@ def main():
         "avg_launch_us": avg_s * 1e6, "algorithmic_bytes_per_obs": bytes_per_obs,
         "whole_iteration_frac": (run_bytes / elapsed) / (HBM_PEAK * world),
         "kernels_ms_per_launch": {k: (v[0] / max(1, v[1])) for k, v in kern.items()},
+        # the same figures for every timed kernel (the two big ones are within a few microseconds of each other)
+        "per_kernel": {k: {"avg_launch_us": 1e3 * v[0] / v[1], "algorithmic_bytes_per_obs": v[2],
+                           "frac": n_obs_local * v[2] / (1e-3 * v[0] / v[1]) / HBM_PEAK}
+                       for k, v in kern.items() if v[1] > 0 and v[0] > 0},
     }
 
     out = {
