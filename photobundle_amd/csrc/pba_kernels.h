@@ -23,6 +23,10 @@
 #ifndef PBA_SAMPLE_WAVES_PER_SIMD
 #define PBA_SAMPLE_WAVES_PER_SIMD 4
 #endif
+// ... and at patch radius >= 4 (register budget 512 / N)
+#ifndef PBA_SAMPLE_WAVES_LARGE
+#define PBA_SAMPLE_WAVES_LARGE 2
+#endif
 // Timing experiment only (results are WRONG): irregular observations contribute nothing
 #ifndef PBA_EXPERIMENT_SKIP_IRREGULAR
 #define PBA_EXPERIMENT_SKIP_IRREGULAR 0
@@ -605,7 +609,7 @@ constexpr int sample_stage_groups(int ng, int per_group) {
 // amdgpu_waves_per_eu(N, N): the register allocator / scheduler works for exactly N resident waves per SIMD (with only a
 // lower bound it trades instruction-level parallelism for an occupancy the kernel does not profit from: measured).
 template <int R, bool JAC, int WAVES, bool FUSED, bool UNITW, bool FAST>
-__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu((R <= 2 ? (JAC ? PBA_SAMPLE_WAVES_PER_SIMD : 2) : 2), (R <= 2 ? (JAC ? PBA_SAMPLE_WAVES_PER_SIMD : 2) : 2))))
+__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu((R <= 2 ? (JAC ? PBA_SAMPLE_WAVES_PER_SIMD : 2) : (R >= 4 ? PBA_SAMPLE_WAVES_LARGE : 2)), (R <= 2 ? (JAC ? PBA_SAMPLE_WAVES_PER_SIMD : 2) : (R >= 4 ? PBA_SAMPLE_WAVES_LARGE : 2)))))
 void k_sample(SampleParams p_in) {
   static_assert(!FUSED || (WAVES * 64) % 128 == 0, "fused tiles are 128 observations");
   static_assert(!FAST || UNITW, "the reduced-precision walk assumes unit patch weights");
@@ -844,8 +848,10 @@ void k_sample(SampleParams p_in) {
   double m11 = 0, m12 = 0, m22 = 0, b1 = 0, b2 = 0, cc = 0;
   const bool walk = active && regular;
   const float* p0 = p.desc + (size_t)pt * (W * W);
-  float dxs[W], dys[W];
-  double omdx[W];
+  // kLean (large patches): 1 - dx and dy are formed again where they are used instead of living in 33 registers
+  constexpr bool kLean = (R >= 4);
+  float dxs[W], dys[kLean ? 1 : W];
+  double omdx[kLean ? 1 : W];
   double Hp[FAST ? 1 : NPL][W];
   float fHp[FAST ? NPL : 1][W];
   float fa11 = 0.f, fa12 = 0.f, fa22 = 0.f, fc1 = 0.f, fc2 = 0.f, fc0 = 0.f;
@@ -859,8 +865,10 @@ void k_sample(SampleParams p_in) {
 #pragma unroll
   for (int j = 0; j < W; ++j) {
     dxs[j] = __fsub_rn((float)(bx + j + 1), xf[j]);
-    dys[j] = __fsub_rn((float)(by + j + 1), yf[j]);
-    omdx[j] = __dsub_rn(1.0, (double)dxs[j]);
+    if (!kLean) {
+      dys[j] = __fsub_rn((float)(by + j + 1), yf[j]);
+      omdx[j] = __dsub_rn(1.0, (double)dxs[j]);
+    }
   }
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
@@ -930,7 +938,7 @@ void k_sample(SampleParams p_in) {
           // ---- reduced-precision walk (opt-in, BASELINE configs[4] tolerance sweep; NOT bit-compatible with the
           //   reference): prec 1: fp32 interpolation and fp32 accumulation of M, b, c;  prec 2: additionally the
           //   residual and the gradients are rounded to bf16 before they enter the (fp32) accumulation.
-          const float dy = dys[r >= 1 ? i : 0], omdy = 1.0f - dy;
+          const float dy = kLean ? __fsub_rn((float)(by + (r >= 1 ? i : 0) + 1), (float)(v + (double)((r >= 1 ? i : 0) - R))) : dys[kLean ? 0 : (r >= 1 ? i : 0)], omdy = 1.0f - dy;
 #pragma unroll
           for (int j = 0; j < W; ++j) {
             const float om = 1.0f - dxs[j];
@@ -955,7 +963,7 @@ void k_sample(SampleParams p_in) {
             if (JAC) { fHp[NPL > 1 ? 1 : 0][j] = h1; fHp[NPL > 2 ? 2 : 0][j] = h2; }
           }
         } else {
-          const float dy = dys[r >= 1 ? i : 0];
+          const float dy = kLean ? __fsub_rn((float)(by + (r >= 1 ? i : 0) + 1), (float)(v + (double)((r >= 1 ? i : 0) - R))) : dys[kLean ? 0 : (r >= 1 ? i : 0)];
           const float omdy = __fsub_rn(1.0f, dy);
           // PBA_WALK_ROWWISE: all horizontal lerps of the row first (independent work for the scheduler), then the
           // pixels; otherwise column by column (a third fewer live registers).  Same sums in the same order.
@@ -963,10 +971,11 @@ void k_sample(SampleParams p_in) {
           if (PBA_WALK_ROWWISE) {
 #pragma unroll
             for (int j = 0; j < W; ++j) {
-              Hc[0][j] = hlerp_exact(dxs[j], omdx[j], tex_I(t[j]), tex_I(t[j + 1]));
+              const double om_j = kLean ? __dsub_rn(1.0, (double)dxs[j]) : omdx[kLean ? 0 : j];
+              Hc[0][j] = hlerp_exact(dxs[j], om_j, tex_I(t[j]), tex_I(t[j + 1]));
               if (JAC) {
-                Hc[PBA_WALK_ROWWISE && NPL > 1 ? 1 : 0][j] = hlerp_exact(dxs[j], omdx[j], tex_gx2(t[j]), tex_gx2(t[j + 1]));
-                Hc[PBA_WALK_ROWWISE && NPL > 2 ? 2 : 0][j] = hlerp_exact(dxs[j], omdx[j], tex_gy2(t[j]), tex_gy2(t[j + 1]));
+                Hc[PBA_WALK_ROWWISE && NPL > 1 ? 1 : 0][j] = hlerp_exact(dxs[j], om_j, tex_gx2(t[j]), tex_gx2(t[j + 1]));
+                Hc[PBA_WALK_ROWWISE && NPL > 2 ? 2 : 0][j] = hlerp_exact(dxs[j], om_j, tex_gy2(t[j]), tex_gy2(t[j + 1]));
               }
             }
           }
@@ -977,10 +986,11 @@ void k_sample(SampleParams p_in) {
               h0 = Hc[0][j];
               if (JAC) { h1 = Hc[PBA_WALK_ROWWISE && NPL > 1 ? 1 : 0][j]; h2 = Hc[PBA_WALK_ROWWISE && NPL > 2 ? 2 : 0][j]; }
             } else {
-              h0 = hlerp_exact(dxs[j], omdx[j], tex_I(t[j]), tex_I(t[j + 1]));
+              const double om_j = kLean ? __dsub_rn(1.0, (double)dxs[j]) : omdx[kLean ? 0 : j];
+              h0 = hlerp_exact(dxs[j], om_j, tex_I(t[j]), tex_I(t[j + 1]));
               if (JAC) {
-                h1 = hlerp_exact(dxs[j], omdx[j], tex_gx2(t[j]), tex_gx2(t[j + 1]));
-                h2 = hlerp_exact(dxs[j], omdx[j], tex_gy2(t[j]), tex_gy2(t[j + 1]));
+                h1 = hlerp_exact(dxs[j], om_j, tex_gx2(t[j]), tex_gx2(t[j + 1]));
+                h2 = hlerp_exact(dxs[j], om_j, tex_gy2(t[j]), tex_gy2(t[j + 1]));
               }
             }
             if (r >= 1) {
