@@ -136,7 +136,7 @@ typedef struct pba_step_info {
   double gradient_norm;
   double model_cost_change;
   double step_norm;          /* |delta| unscaled */
-  double x_norm;             /* |x| over free parameters at the current point */
+  double x_norm;             /* |x| over the free cameras that have residual blocks and all points, at the current point */
   double candidate_cost;
   int32_t linear_solver_ok;  /* 0: LINEAR_SOLVER_FAILURE (non-PD block / non-finite step) */
   int32_t eval_ok;           /* 0: candidate evaluation non-finite */

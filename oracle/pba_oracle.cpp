@@ -387,6 +387,8 @@ struct Program {
   int n_cam_params;              // 6 * free cameras
   int n_params;                  // n_cam_params + 3 n_p
   std::vector<int> pt_begin;     // CSR over obs (grouped by point)
+  std::vector<char> cam_in_program;   // slot has at least one residual block (a camera nobody observes is never handed
+                                      // to AddResidualBlock, photobundle.cc:791-804: Ceres does not know it exists)
   bool autodiff;
   int threads;
   // materialised (corrected, and after ScaleColumns: scaled) residuals + Jacobian
@@ -405,6 +407,17 @@ struct Program {
     pt_begin.assign(n_p + 1, 0);
     for (int o = 0; o < n_obs; ++o) pt_begin[p->obs_point[o] + 1]++;
     for (int i = 0; i < n_p; ++i) pt_begin[i + 1] += pt_begin[i];
+    cam_in_program.assign(n_c, 0);
+    for (int o = 0; o < n_obs; ++o) cam_in_program[p->obs_slot[o]] = 1;
+  }
+  // |x| over the parameter blocks of the Ceres program: the free cameras WITH residual blocks and every point.  (The
+  // columns of an unobserved free camera stay in this restatement's x -- zero Jacobian, zero step -- but not in |x|.)
+  double programNorm(const std::vector<double>& x) const {
+    double s = 0.0;
+    for (int c = 0; c < n_c; ++c)
+      if (cam_col[c] >= 0 && cam_in_program[c]) for (int k = 0; k < 6; ++k) s += x[cam_col[c] + k] * x[cam_col[c] + k];
+    for (int i = n_cam_params; i < n_params; ++i) s += x[i] * x[i];
+    return std::sqrt(s);
   }
 
   // x layout: [free cameras in slot order | points]
@@ -996,7 +1009,7 @@ int oracle_solve(oracle_problem* p, const oracle_options* opt, oracle_summary* s
 
   std::vector<double> x, candidate_x, gradient, scale, diagonal, D, step, delta, model_residuals;
   g.pack(p->cams, p->xyz, x);
-  double x_cost = 0.0, candidate_cost = 0.0, x_norm = Norm(x);
+  double x_cost = 0.0, candidate_cost = 0.0, x_norm = g.programNorm(x);
   double radius = opt->initial_trust_region_radius, decrease_factor = 2.0;
   bool reuse_diagonal = false;
   int num_consecutive_invalid_steps = 0;
@@ -1143,7 +1156,7 @@ int oracle_solve(oracle_problem* p, const oracle_options* opt, oracle_summary* s
     it.relative_decrease = (x_cost - candidate_cost) / model_cost_change;
     if (it.relative_decrease > opt->min_relative_decrease) {
       // HandleSuccessfulStep
-      x = candidate_x; x_norm = Norm(x);
+      x = candidate_x; x_norm = g.programNorm(x);
       if (!eval_grad_jac()) {
         sum->termination_type = 2; std::snprintf(sum->message, sizeof(sum->message), "Residual and Jacobian evaluation failed.");
         done = true; break;

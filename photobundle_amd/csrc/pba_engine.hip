@@ -64,7 +64,7 @@ struct pba_engine {
   double* d_rec[2] = {nullptr, nullptr};   // [6][rec_stride] per point parity
   double* d_sp = nullptr;           // [n_points][3]
   double* d_ptrec = nullptr;        // [n_points][12]
-  double* d_sc = nullptr;           // [6 * kMaxFrames]
+  double* d_sc = nullptr;           // [2][6 * kMaxFrames]: Jacobi scales | live flags (the [1] part starts at 6 n_free)
   double* d_delta_c = nullptr;      // [kMaxFrames][6]
   double* d_partial = nullptr;      // [schur_grid][part_stride]
   double* d_red = nullptr;          // [kChunks][part_stride]
@@ -382,7 +382,7 @@ int pba_create(const pba_config* cfg, pba_engine** out) {
     if ((rc = dev_alloc(e, &e->d_cams[k], 6 * kMaxFrames))) return bail(rc);
     if ((rc = dev_alloc(e, &e->d_geom[k], kMaxFrames))) return bail(rc);
   }
-  if ((rc = dev_alloc(e, &e->d_sc, 6 * kMaxFrames))) return bail(rc);
+  if ((rc = dev_alloc(e, &e->d_sc, 2 * 6 * kMaxFrames))) return bail(rc);
   if ((rc = dev_alloc(e, &e->d_delta_c, 6 * kMaxFrames))) return bail(rc);
   if ((rc = dev_alloc(e, &e->d_scal, (size_t)kNumScal))) return bail(rc);
   if ((rc = dev_alloc(e, &e->d_S, (size_t)36 * kMaxFrames * kMaxFrames))) return bail(rc);

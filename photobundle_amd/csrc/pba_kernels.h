@@ -2005,7 +2005,7 @@ struct SolveParams {
   const double* cams;       // current cameras [n_frames][6]
   double* cams_cand;        // candidate cameras
   double* delta_c;          // [n_frames][6] unscaled camera step (0 for the constant camera)
-  double* sc;               // [6 n_free] Jacobi scale of the camera columns (written when init_scale)
+  double* sc;               // [2][6 n_free] Jacobi scale of the camera columns | column-is-live flags (written when init_scale)
   double* S_dbg;            // [n*n] scaled + damped reduced matrix (test hook), may be null
   double* rhs_dbg;          // [n]
   double* scal;
@@ -2050,7 +2050,9 @@ __device__ __forceinline__ void solve_prologue(const SolveParams& p, int n, int 
     const double du = src[nT + 2 * n + i];
     const double g = src[nT + n + i];
     double s;
-    if (p.init_scale) { s = p.jacobi ? 1.0 / (1.0 + sqrt(du)) : 1.0; p.sc[i] = s; }
+    // sc[n + i]: the column has a nonzero norm at the initial point.  A free camera whose six flags are all zero has no
+    // residual block anywhere (the sums are global at world > 1): not a parameter block of the Ceres program
+    if (p.init_scale) { s = p.jacobi ? 1.0 / (1.0 + sqrt(du)) : 1.0; p.sc[i] = s; p.sc[n + i] = du > 0.0 ? 1.0 : 0.0; }
     else s = p.sc[i];
     sc[i] = s;
     D2[i] = fmin(fmax(s * s * du, p.min_diag), p.max_diag) / p.radius;
@@ -2127,8 +2129,12 @@ __device__ __forceinline__ void solve_epilogue(const SolveParams& p, int n, cons
       gn2 += gc[i] * gc[i];
       if (!isfinite(y[i])) bad = 1.0;
     }
-    for (int i = tid; i < 6 * p.n_frames; i += 64)
-      if (p.geom[i / 6].free_index >= 0) x2 += p.cams[i] * p.cams[i];
+    for (int i = tid; i < 6 * p.n_frames; i += 64) {
+      const int fa = p.geom[i / 6].free_index;
+      if (fa < 0) continue;
+      const double* live = p.sc + n + 6 * fa;     // written by this kernel at the first linearisation (or just above)
+      if (live[0] + live[1] + live[2] + live[3] + live[4] + live[5] > 0.0) x2 += p.cams[i] * p.cams[i];
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
       mcc += __shfl_xor(mcc, off); st2 += __shfl_xor(st2, off); x2 += __shfl_xor(x2, off);

@@ -98,6 +98,20 @@ def test_unobserved_free_camera():
     q = _subsample(p, p.obs_slot != 3)
     ref, res = _check_against_oracle(q, iterations=6)
     assert np.array_equal(res["cams"][3], q.cams[3])
+    # ... and is not a parameter block of the Ceres program (it never reaches AddResidualBlock, photobundle.cc:791-804):
+    # |x| of the parameter-tolerance test runs over the observed free cameras and the points only
+    with make_engine(q) as e:
+        e.linearize()
+        info = e.step(1e4, init_scale=True)
+    big = copy.copy(q)
+    big.cams = q.cams.copy()
+    big.cams[3, 3:] = 1e9          # counted in |x| it would end the solve at the first parameter-tolerance test
+    with make_engine(big) as e:
+        res_big = e.solve(default_solver_options(max_num_iterations=6))
+    assert [i["cost"] for i in res_big["iterations"]] == [i["cost"] for i in res["iterations"]]
+    live = [c for c in range(q.n_frames) if c != q.fixed_slot and c != 3]
+    expect = np.sqrt((q.cams[live] ** 2).sum() + (q.xyz ** 2).sum())
+    assert np.isclose(info["x_norm"], expect, rtol=1e-13), (info["x_norm"], expect)
 
 
 def test_rejected_inputs(small_window_edge=None):

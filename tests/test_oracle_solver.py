@@ -167,6 +167,25 @@ def test_fixed_camera_is_constant_and_thread_invariance(small_window):
     assert np.array_equal(a["cams"], b["cams"]) and np.array_equal(a["xyz"], b["xyz"])
 
 
+def test_camera_without_residual_blocks_is_not_in_the_program():
+    """A window slot nobody observes never reaches AddResidualBlock (photobundle.cc:791-804), so Ceres neither moves it
+    nor counts it in |x| of the parameter-tolerance test: blowing its (unused) pose up must not change the solve."""
+    import copy
+    from photobundle_amd import synthetic
+    p = synthetic.make_window(n_frames=5, n_points=150, radius=2, size=(120, 200), K=(250.0, 250.0, 100.0, 60.0), seed_offset=8)
+    keep = p.obs_slot != 3
+    q = copy.copy(p)
+    q.obs_point, q.obs_slot = p.obs_point[keep].copy(), p.obs_slot[keep].copy()
+    a = oracle.solve(q, oracle.default_options(max_num_iterations=12))
+    big = copy.copy(q)
+    big.cams = q.cams.copy()
+    big.cams[3, 3:] = 1e9          # |x| would be ~1.7e9: any step would pass "step_norm <= 1e-6 |x|" at once
+    b = oracle.solve(big, oracle.default_options(max_num_iterations=12))
+    assert len(a["iterations"]) == len(b["iterations"]) >= 5 and a["message"] == b["message"]
+    assert [i["cost"] for i in a["iterations"]] == [i["cost"] for i in b["iterations"]]
+    assert np.array_equal(b["cams"][3], big.cams[3])
+
+
 def test_converges_towards_ground_truth():
     """Smooth texture + mild perturbation: LM must pull the free cameras back towards ground truth."""
     from photobundle_amd import synthetic
