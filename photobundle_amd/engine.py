@@ -167,16 +167,29 @@ class Engine:
 
     # ---- the LM loop ---------------------------------------------------------------------------------------
     def solve(self, options=None, max_iterations_out=512, fetch_state=True):
+        res = self.unpack_solve(*self.solve_raw(options, max_iterations_out))
+        if fetch_state:
+            res["cams"], res["xyz"] = self.get_state()
+        return res
+
+    def solve_raw(self, options=None, max_iterations_out=512, buffers=None):
+        """pba_solve and nothing else: returns the C structs (summary, iteration array) as filled by the library.
+        `buffers` = a (summary, iteration array) pair from an earlier call to reuse (timing loops)."""
         o = options or default_solver_options()
-        s = _lib.SolverSummary()
-        its = (_lib.IterationSummary * max_iterations_out)()
-        self._check(self._L.pba_solve(self._h, C.byref(o), C.byref(s), its, max_iterations_out), "pba_solve")
+        s, its = buffers if buffers is not None else self.solve_buffers(max_iterations_out)
+        self._check(self._L.pba_solve(self._h, C.byref(o), C.byref(s), its, len(its)), "pba_solve")
+        return s, its
+
+    @staticmethod
+    def solve_buffers(max_iterations_out=512):
+        return _lib.SolverSummary(), (_lib.IterationSummary * max_iterations_out)()
+
+    @staticmethod
+    def unpack_solve(s, its):
         res = {f: getattr(s, f) for f, _ in _lib.SolverSummary._fields_}
         res["message"] = s.message.decode()
         res["iterations"] = [{f: getattr(its[i], f) for f, _ in _lib.IterationSummary._fields_}
                              for i in range(s.num_iterations)]
-        if fetch_state:
-            res["cams"], res["xyz"] = self.get_state()
         return res
 
     # ---- multi-GPU -------------------------------------------------------------------------------------------
