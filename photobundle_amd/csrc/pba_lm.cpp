@@ -11,6 +11,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 
@@ -30,11 +31,16 @@ static int solve_async(pba_engine* e, const pba_solver_options* o, pba_solver_su
                        int32_t max_out, double t_start, bool verbose) {
   using pba::LmState;
   constexpr int kAhead = 3;
+  static const bool tr = getenv("PBA_TRACE_SOLVE") != nullptr;
+  double tt[8] = {0};
+  tt[0] = now();
   int rc = pba_internal_async_begin(e, o);
   if (rc) return rc;
+  tt[1] = now();
   const volatile LmState* st = static_cast<const volatile LmState*>(pba_internal_async_state(e));
   unsigned long long seq = 0, seqs[kAhead + 1] = {0};
   if ((rc = pba_internal_async_enqueue(e, 0, 0, o, &seq))) return rc;
+  tt[2] = now();
   int enq = 0;
   unsigned long long last_seq = 0;
   // Multi-rank: every enqueued step carries collectives, so all ranks must enqueue the SAME number of steps although
@@ -56,13 +62,19 @@ static int solve_async(pba_engine* e, const pba_solver_options* o, pba_solver_su
   // Iteration limit (or max_num_iterations <= 0): the gradient norms of the final point may still be missing.  The pass
   // that computes them is enqueued unconditionally and gates itself on the device state (lm_final_pass_needed), which
   // saves a host round trip; then ONE flush brings the last outcome and the iteration log to the host mirror.
+  tt[3] = now();
   if (enq >= o->max_num_iterations) {
     if ((rc = pba_internal_async_enqueue(e, 2, o->max_num_iterations <= 0 ? 1 : 0, o, &seq))) return rc;
   }
   if ((rc = pba_internal_async_enqueue(e, 3, 0, o, &seq))) return rc;
+  tt[4] = now();
   if ((rc = pba_internal_async_wait(e, seq))) return rc;
+  tt[5] = now();
   (void)last_seq;
   if ((rc = pba_internal_async_end(e))) return rc;
+  tt[6] = now();
+  if (tr) std::fprintf(stderr, "solve_async us: entry->begin %.1f, begin %.1f, enqueue0 %.1f, loop %.1f, final enqueues %.1f, final wait %.1f, end %.1f\n",
+                       1e6 * (tt[0] - t_start), 1e6 * (tt[1] - tt[0]), 1e6 * (tt[2] - tt[1]), 1e6 * (tt[3] - tt[2]), 1e6 * (tt[4] - tt[3]), 1e6 * (tt[5] - tt[4]), 1e6 * (tt[6] - tt[5]));
   LmState fin;
   std::memcpy(&fin, const_cast<const LmState*>(static_cast<const LmState*>(pba_internal_async_state(e))), sizeof(fin));
   const pba_iteration_summary* log = pba_internal_async_log(e);
