@@ -1617,6 +1617,7 @@ __global__ __launch_bounds__(kTile, 2) void k_schur(SchurParams p_in) {
     greg[u] = (k < n_geom_words) ? reinterpret_cast<const unsigned long long*>(p.geom)[k] : 0ull;
   }
 
+  if (tid == 0) s_red[0] = 0.0;      // the zero cell of the camera-side sums (s_red is otherwise unused until the epilogue)
   unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tlast = p.dbg ? __builtin_amdgcn_s_memtime() : 0;
   const unsigned long long t_rt0 = p.dbg ? __builtin_amdgcn_s_memrealtime() : 0;
@@ -1809,14 +1810,18 @@ __global__ __launch_bounds__(kTile, 2) void k_schur(SchurParams p_in) {
           const int lw[4] = {l4.x, l4.y, l4.z, l4.w};
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
-            double x[8];
+            // a camera without an observation of the point reads the zero cell: no select on the loaded VALUE, so the
+            // eight reads stay in flight together (with the select the compiler waited for each one in turn).  Entries
+            // beyond n_pts are -1 from the per-tile reset.
+            int off[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
               const int la = (int)(int8_t)((lw[2 * h + (k >> 2)] >> (8 * (k & 3))) & 0xff);
-              const bool ok = (q0 + 8 * h + k < n_pts) && la >= 0;
-              const double val = s_obs[(ok ? la : 0) * kObsStride + v];
-              x[k] = ok ? val : 0.0;
+              off[k] = la >= 0 ? la * kObsStride + v : kTile * kObsStride;
             }
+            double x[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) x[k] = s_obs[off[k]];
 #pragma unroll
             for (int k = 0; k < 8; ++k) acc_cam[u] += x[k];
           }
@@ -1856,8 +1861,8 @@ __global__ __launch_bounds__(kTile, 2) void k_schur(SchurParams p_in) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
 #pragma unroll
-          for (int j = 0; j < 6; ++j)
-            acc[6 * i + j] -= yy[3 * i] * wb[3 * j] + yy[3 * i + 1] * wb[3 * j + 1] + yy[3 * i + 2] * wb[3 * j + 2];
+          for (int j = 0; j < 6; ++j)     // three chained FMAs per entry (the sum-then-subtract form costs a fourth operation)
+            acc[6 * i + j] = fma(-yy[3 * i + 2], wb[3 * j + 2], fma(-yy[3 * i + 1], wb[3 * j + 1], fma(-yy[3 * i], wb[3 * j], acc[6 * i + j])));
         }
       }
     }
