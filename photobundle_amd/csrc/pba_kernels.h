@@ -741,7 +741,23 @@ void k_sample(SampleParams p_in) {
     if (active && !p.skip_backsub) {
       double acc[3] = {0.0, 0.0, 0.0};
       const double* src = s_bs + (half * 128 + l0) * 3;
-      for (int l = 0; l < cnt; ++l) { acc[0] += src[3 * l]; acc[1] += src[3 * l + 1]; acc[2] += src[3 * l + 2]; }
+      // four observations per trip, their twelve LDS reads in flight together (one dependent read per trip otherwise);
+      // the adds keep the lane order
+      for (int lb = 0; lb < cnt; lb += 4) {
+        double x[4][3];
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+          const int li = (lb + l < cnt) ? lb + l : cnt - 1;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) x[l][k] = src[3 * li + k];
+        }
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+          const bool in = lb + l < cnt;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) acc[k] += in ? x[l][k] : 0.0;
+        }
+      }
       const double q0 = pr[6] + acc[0], q1 = pr[7] + acc[1], q2 = pr[8] + acc[2];
       const double d[3] = {-(pr[0] * q0 + pr[1] * q1 + pr[2] * q2), -(pr[1] * q0 + pr[3] * q1 + pr[4] * q2),
                            -(pr[2] * q0 + pr[4] * q1 + pr[5] * q2)};
@@ -1617,7 +1633,8 @@ __global__ __launch_bounds__(kTile, 2) void k_schur(SchurParams p_in) {
     greg[u] = (k < n_geom_words) ? reinterpret_cast<const unsigned long long*>(p.geom)[k] : 0ull;
   }
 
-  if (tid == 0) s_red[0] = 0.0;      // the zero cell of the camera-side sums (s_red is otherwise unused until the epilogue)
+  if (tid < kCamVals) s_red[tid] = 0.0;   // "row 128" of the camera-side sums: zeros (s_red is otherwise unused until the epilogue)
+  static_assert(kCamVals <= kTile, "zero row fits s_red");
   unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tlast = p.dbg ? __builtin_amdgcn_s_memtime() : 0;
   const unsigned long long t_rt0 = p.dbg ? __builtin_amdgcn_s_memrealtime() : 0;
@@ -1630,7 +1647,7 @@ __global__ __launch_bounds__(kTile, 2) void k_schur(SchurParams p_in) {
     const bool active = tid < n_here;
     const int obs = o0 + tid;
 
-    for (int k = tid; k < kMaxFrames * kTile / 4; k += kTile) reinterpret_cast<int32_t*>(s_lane_of)[k] = -1;
+    for (int k = tid; k < kMaxFrames * kTile / 4; k += kTile) reinterpret_cast<uint32_t*>(s_lane_of)[k] = 0x80808080u;   // -128: no observation
     CamGeom* s_geom = reinterpret_cast<CamGeom*>(s_obs);   // P1 only; P2 overwrites the region with W | Y
 #pragma unroll
     for (int u = 0; u < kGeomRegs; ++u) {
@@ -1810,15 +1827,13 @@ __global__ __launch_bounds__(kTile, 2) void k_schur(SchurParams p_in) {
           const int lw[4] = {l4.x, l4.y, l4.z, l4.w};
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
-            // a camera without an observation of the point reads the zero cell: no select on the loaded VALUE, so the
-            // eight reads stay in flight together (with the select the compiler waited for each one in turn).  Entries
-            // beyond n_pts are -1 from the per-tile reset.
+            // a camera without an observation of the point (byte 0x80 = lane 128, also every entry beyond n_pts after
+            // the per-tile reset) reads row 128 = the zeroed head of s_red: no select on the address or on the loaded
+            // value, and the eight reads stay in flight together (with a select on the value the compiler waited for
+            // each read in turn)
             int off[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-              const int la = (int)(int8_t)((lw[2 * h + (k >> 2)] >> (8 * (k & 3))) & 0xff);
-              off[k] = la >= 0 ? la * kObsStride + v : kTile * kObsStride;
-            }
+            for (int k = 0; k < 8; ++k) off[k] = (int)((lw[2 * h + (k >> 2)] >> (8 * (k & 3))) & 0xff) * kObsStride + v;
             double x[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) x[k] = s_obs[off[k]];
