@@ -1827,6 +1827,7 @@ __global__ __launch_bounds__(kTile, 2) void k_schur(SchurParams p_in) {
           const int lw[4] = {l4.x, l4.y, l4.z, l4.w};
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
+            if (q0 + 8 * h >= n_pts) continue;      // (uniform) nothing but sentinels in this half: 16-frame tiles hold 8 points
             // a camera without an observation of the point (byte 0x80 = lane 128, also every entry beyond n_pts after
             // the per-tile reset) reads row 128 = the zeroed head of s_red: no select on the address or on the loaded
             // value, and the eight reads stay in flight together (with a select on the value the compiler waited for
