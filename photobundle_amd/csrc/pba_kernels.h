@@ -1794,14 +1794,14 @@ __global__ __launch_bounds__(kTile, 2) void k_schur(SchurParams p_in) {
       double* so = s_obs + tid * kObsStride;
       const double Pg[3] = {Pm[0] * gp[0] + Pm[1] * gp[1] + Pm[2] * gp[2], Pm[1] * gp[0] + Pm[3] * gp[1] + Pm[4] * gp[2],
                             Pm[2] * gp[0] + Pm[4] * gp[1] + Pm[5] * gp[2]};
+      // r_l = g_c,l - W_l (P g_p) = -Ac^T (b + (M Ap)(P g_p)): the 2-vector first, then one 2-term product per row
+      // (forming the rows of W_l for it cost 36 more operations per observation)
+      const double bq0 = b[0] + (MAp[0][0] * Pg[0] + MAp[0][1] * Pg[1] + MAp[0][2] * Pg[2]);
+      const double bq1 = b[1] + (MAp[1][0] * Pg[0] + MAp[1][1] * Pg[1] + MAp[1][2] * Pg[2]);
 #pragma unroll
       for (int j = 0; j < 6; ++j) {
-        const double w0 = Ac[0][j] * MAp[0][0] + Ac[1][j] * MAp[1][0];
-        const double w1 = Ac[0][j] * MAp[0][1] + Ac[1][j] * MAp[1][1];
-        const double w2 = Ac[0][j] * MAp[0][2] + Ac[1][j] * MAp[1][2];
-        const double gcl = -(Ac[0][j] * b[0] + Ac[1][j] * b[1]);     // g_c,l = -Ac^T b
-        so[27 + j] = gcl;
-        so[21 + j] = gcl - (w0 * Pg[0] + w1 * Pg[1] + w2 * Pg[2]);
+        so[27 + j] = -(Ac[0][j] * b[0] + Ac[1][j] * b[1]);           // g_c,l = -Ac^T b
+        so[21 + j] = -(Ac[0][j] * bq0 + Ac[1][j] * bq1);
       }
       // U_l = Ac^T M Ac (packed upper triangle)
       double MAc[2][6];
