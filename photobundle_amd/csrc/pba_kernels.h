@@ -1640,9 +1640,17 @@ __global__ __launch_bounds__(kTile, 2) void k_schur(SchurParams p_in) {
   const unsigned long long t_rt0 = p.dbg ? __builtin_amdgcn_s_memrealtime() : 0;
 #define PBA_TICK(k) do { if (p.dbg) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); tph[k] += tn - tlast; tlast = tn; } } while (0)
   int4 ti_next = p.tile_info[min((int)blockIdx.x, p.n_tiles - 1)];
+  // the observation's indices are requested one tile ahead (at the start of the pair-block phase) so that the
+  // per-observation phase starts with its second round trip (point, Jacobi scale, record) instead of its first
+  int nx_pt = 0, nx_slot = 0, nx_l0 = 0, nx_cnt = 0;
+  if (tid < ti_next.y) {
+    const int o = ti_next.x + tid;
+    nx_pt = p.obs_point[o]; nx_slot = p.obs_slot[o]; nx_l0 = p.obs_l0[o]; nx_cnt = p.obs_cnt[o];
+  }
   for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
     const int4 ti = ti_next;
     ti_next = p.tile_info[min(tile + (int)gridDim.x, p.n_tiles - 1)];   // prefetch the next tile's descriptor
+    const int cur_pt = nx_pt, cur_slot = nx_slot, cur_l0 = nx_l0, cur_cnt = nx_cnt;
     const int o0 = ti.x, n_here = ti.y, pt0 = ti.z, n_pts = ti.w;
     const bool active = tid < n_here;
     const int obs = o0 + tid;
@@ -1665,9 +1673,9 @@ __global__ __launch_bounds__(kTile, 2) void k_schur(SchurParams p_in) {
     double MAp[2][3];
     double s_pt[3] = {1.0, 1.0, 1.0};
     if (active) {
-      pt = p.obs_point[obs];
-      const int slot = p.obs_slot[obs];
-      l0 = p.obs_l0[obs]; l1 = l0 + p.obs_cnt[obs];
+      pt = cur_pt;
+      const int slot = cur_slot;
+      l0 = cur_l0; l1 = l0 + cur_cnt;
       if (!p.init_scale) { s_pt[0] = p.sp[3 * (size_t)pt]; s_pt[1] = p.sp[3 * (size_t)pt + 1]; s_pt[2] = p.sp[3 * (size_t)pt + 2]; }
       const CamGeom& g = s_geom[slot];
       fa = g.free_index;
@@ -1863,6 +1871,10 @@ __global__ __launch_bounds__(kTile, 2) void k_schur(SchurParams p_in) {
     PBA_TICK(5);
 
     // ---- P3a: block owners: T(a, b) -= Y_la W_lb^T over this group's points ----------------------------------
+    if (tile + (int)gridDim.x < p.n_tiles && tid < ti_next.y) {
+      const int o = ti_next.x + tid;
+      nx_pt = p.obs_point[o]; nx_slot = p.obs_slot[o]; nx_l0 = p.obs_l0[o]; nx_cnt = p.obs_cnt[o];
+    }
     if (owner) {
       const int8_t* la_row = s_lane_of + pa * kTile;
       const int8_t* lb_row = s_lane_of + pb * kTile;
