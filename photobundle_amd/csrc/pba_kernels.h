@@ -1643,14 +1643,17 @@ __global__ __launch_bounds__(kTile, 2) void k_schur(SchurParams p_in) {
   // the observation's indices are requested one tile ahead (at the start of the pair-block phase) so that the
   // per-observation phase starts with its second round trip (point, Jacobi scale, record) instead of its first
   int nx_pt = 0, nx_slot = 0, nx_l0 = 0, nx_cnt = 0;
+  double nx_x[3] = {0.0, 0.0, 0.0};
   if (tid < ti_next.y) {
     const int o = ti_next.x + tid;
     nx_pt = p.obs_point[o]; nx_slot = p.obs_slot[o]; nx_l0 = p.obs_l0[o]; nx_cnt = p.obs_cnt[o];
+    nx_x[0] = p.xyz[3 * (size_t)nx_pt]; nx_x[1] = p.xyz[3 * (size_t)nx_pt + 1]; nx_x[2] = p.xyz[3 * (size_t)nx_pt + 2];
   }
   for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
     const int4 ti = ti_next;
     ti_next = p.tile_info[min(tile + (int)gridDim.x, p.n_tiles - 1)];   // prefetch the next tile's descriptor
     const int cur_pt = nx_pt, cur_slot = nx_slot, cur_l0 = nx_l0, cur_cnt = nx_cnt;
+    const double cur_x[3] = {nx_x[0], nx_x[1], nx_x[2]};
     const int o0 = ti.x, n_here = ti.y, pt0 = ti.z, n_pts = ti.w;
     const bool active = tid < n_here;
     const int obs = o0 + tid;
@@ -1679,7 +1682,7 @@ __global__ __launch_bounds__(kTile, 2) void k_schur(SchurParams p_in) {
       if (!p.init_scale) { s_pt[0] = p.sp[3 * (size_t)pt]; s_pt[1] = p.sp[3 * (size_t)pt + 1]; s_pt[2] = p.sp[3 * (size_t)pt + 2]; }
       const CamGeom& g = s_geom[slot];
       fa = g.free_index;
-      const double prm[3] = {p.xyz[3 * (size_t)pt], p.xyz[3 * (size_t)pt + 1], p.xyz[3 * (size_t)pt + 2]};
+      const double prm[3] = {cur_x[0], cur_x[1], cur_x[2]};
       double X[3], qd[3];
       point_world(p.rays, pt, prm, X, qd);
       double xw[3];
@@ -1822,6 +1825,10 @@ __global__ __launch_bounds__(kTile, 2) void k_schur(SchurParams p_in) {
     }
     lds_barrier();
     PBA_TICK(3);
+    if (tile + (int)gridDim.x < p.n_tiles && tid < ti_next.y) {      // next tile's indices: two phases ahead of its coordinates
+      const int o = ti_next.x + tid;
+      nx_pt = p.obs_point[o]; nx_slot = p.obs_slot[o]; nx_l0 = p.obs_l0[o]; nx_cnt = p.obs_cnt[o];
+    }
 
     // ---- P3b: camera-side sums of [U_l | r_l | g_c,l] by camera -------------------------------------------------
 #pragma unroll
@@ -1872,8 +1879,7 @@ __global__ __launch_bounds__(kTile, 2) void k_schur(SchurParams p_in) {
 
     // ---- P3a: block owners: T(a, b) -= Y_la W_lb^T over this group's points ----------------------------------
     if (tile + (int)gridDim.x < p.n_tiles && tid < ti_next.y) {
-      const int o = ti_next.x + tid;
-      nx_pt = p.obs_point[o]; nx_slot = p.obs_slot[o]; nx_l0 = p.obs_l0[o]; nx_cnt = p.obs_cnt[o];
+      nx_x[0] = p.xyz[3 * (size_t)nx_pt]; nx_x[1] = p.xyz[3 * (size_t)nx_pt + 1]; nx_x[2] = p.xyz[3 * (size_t)nx_pt + 2];
     }
     if (owner) {
       const int8_t* la_row = s_lane_of + pa * kTile;
