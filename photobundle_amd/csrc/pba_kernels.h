@@ -56,6 +56,19 @@ __device__ __forceinline__ double wave_sum(double v) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
   return v;
 }
+// N wave sums at once, level by level: the 2 N cross-lane moves of a level are in flight together (N calls of wave_sum
+// leave the compiler with N dependent chains it only partly interleaves).  Same butterfly, same bits as wave_sum.
+template <int N>
+__device__ __forceinline__ void wave_sum_n(double (&v)[N]) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    double t[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) t[k] = __shfl_xor(v[k], off);
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] += t[k];
+  }
+}
 __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off));
@@ -812,6 +825,7 @@ void k_sample(SampleParams p_in) {
     for (int j = 1; j < W; ++j) reg = reg && (trunc_x86(xf[j]) == bx + j) && (trunc_x86(yf[j]) == by + j);
     regular = reg;
   }
+  if (PBA_EXPERIMENT_SKIP_IRREGULAR == 2 && p.n_obs > 0) active = active && regular;   // timing experiment (WRONG results): paths compiled in, never taken
   // Irregular observations (patch over the image border, clamped taps: sample_eigen.h:38-51) whose taps all fall into
   // one F x F window of CLAMPED pixel coordinates anchored at the first tap (by0, bx0) are staged like the regular ones,
   // texel by texel with clamped addresses, and walked with per-tap indices out of LDS (kWindow: whole footprint resident,
@@ -845,6 +859,20 @@ void k_sample(SampleParams p_in) {
   // >= 0: regular, linear texel index of the footprint origin;  -1: nothing to stage;  <= -2: windowed irregular, slot
   s_base[wave][lane] = (active && regular) ? (int32_t)(slot * (p.rows * p.cols) + by * p.cols + bx) : (win_irr ? -2 - slot : -1);
   if (kWindow) s_irr[wave][lane] = (by0 << 16) | bx0;
+  // descriptors of the first (up to) four windowed irregular observations of this wave, lane = pixel: requested here so
+  // that the cooperative pass after the walk does not start with a global round trip the whole workgroup waits for
+  int irr_src[4] = {-1, -1, -1, -1};
+  float irr_dsc[4] = {0.f, 0.f, 0.f, 0.f};
+  unsigned long long irr_rest = 0;
+  if (kWindow) {
+    irr_rest = __ballot(win_irr);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      irr_src[k] = irr_rest ? __builtin_amdgcn_readfirstlane(__ffsll((long long)irr_rest) - 1) : -1;
+      if (irr_rest) irr_rest &= irr_rest - 1;
+      if (irr_src[k] >= 0 && lane < W * W) irr_dsc[k] = p.desc[(size_t)__builtin_amdgcn_readlane(pt, irr_src[k] < 0 ? 0 : irr_src[k]) * (W * W) + lane];
+    }
+  }
   lds_barrier();
   PBA_STK(2);
 
@@ -1105,18 +1133,21 @@ void k_sample(SampleParams p_in) {
     // window of lane `src`, then six fixed-order wave reductions.  A lane-serial walk of the per-tap rule costs ~3x the
     // regular walk and every lane of the wave waits for it; this costs ~200 instructions per irregular observation.
     static_assert(W * W <= 64, "one lane per pixel");
-    unsigned long long im = __ballot(win_irr);
-    while (im) {
+    unsigned long long im = irr_rest;
+    bool first_trip = true;
+    while (first_trip ? (irr_src[0] >= 0) : (im != 0)) {
       // up to four irregular observations per trip: their descriptor values (lane = pixel) are requested together, so
-      // that one global round trip serves four patches
+      // that one global round trip serves four patches; the first trip's were requested before the walk
       int srcs[4]; float dsc[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
+        if (first_trip) { srcs[k] = irr_src[k]; dsc[k] = irr_dsc[k]; continue; }
         srcs[k] = im ? __builtin_amdgcn_readfirstlane(__ffsll((long long)im) - 1) : -1;
         if (im) im &= im - 1;
         dsc[k] = 0.f;
         if (srcs[k] >= 0 && lane < W * W) dsc[k] = p.desc[(size_t)__builtin_amdgcn_readlane(pt, srcs[k] < 0 ? 0 : srcs[k]) * (W * W) + lane];
       }
+      first_trip = false;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
       const int src = srcs[k];
@@ -1147,8 +1178,13 @@ void k_sample(SampleParams p_in) {
           q11 = wgx * gx; q12 = wgx * gy; q22 = wgy * gy; q1 = wgx * e; q2 = wgy * e;
         }
       }
-      q_cc = wave_sum(q_cc);
-      if (JAC) { q11 = wave_sum(q11); q12 = wave_sum(q12); q22 = wave_sum(q22); q1 = wave_sum(q1); q2 = wave_sum(q2); }
+      if (JAC) {
+        double q6[6] = {q_cc, q11, q12, q22, q1, q2};
+        wave_sum_n<6>(q6);
+        q_cc = q6[0]; q11 = q6[1]; q12 = q6[2]; q22 = q6[3]; q1 = q6[4]; q2 = q6[5];
+      } else {
+        q_cc = wave_sum(q_cc);
+      }
       if (lane == src) { cc = q_cc; m11 = q11; m12 = q12; m22 = q22; b1 = q1; b2 = q2; }
       }
     }
@@ -1182,8 +1218,13 @@ void k_sample(SampleParams p_in) {
   double red_out[NQ];
   {
     double v[NQ];
-    v[0] = wave_sum(cost_obs);
-    if (FUSED) { v[NQ > 1 ? 1 : 0] = wave_sum(bs_mcc); v[NQ > 2 ? 2 : 0] = wave_sum(bs_st2); v[NQ > 3 ? 3 : 0] = wave_sum(bs_x2); }
+    if (FUSED) {
+      double q4[4] = {cost_obs, bs_mcc, bs_st2, bs_x2};
+      wave_sum_n<4>(q4);
+      v[0] = q4[0]; v[NQ > 1 ? 1 : 0] = q4[1]; v[NQ > 2 ? 2 : 0] = q4[2]; v[NQ > 3 ? 3 : 0] = q4[3];
+    } else {
+      v[0] = wave_sum(cost_obs);
+    }
     if (lane == 0) {
 #pragma unroll
       for (int q = 0; q < NQ; ++q) s_red[q * WAVES + wave] = v[q];
