@@ -806,7 +806,7 @@ void k_sample(SampleParams p_in) {
 #pragma unroll
   for (int j = 0; j < W; ++j) { xf[j] = 0.f; yf[j] = 0.f; }
   int bx = 0, by = 0;
-  bool regular = false;
+  bool regular = false, reg_clamped = false;
   if (active) {
     double xw[3];
     transform_point(s_geom[slot], X, xw);
@@ -820,10 +820,17 @@ void k_sample(SampleParams p_in) {
     }
     bx = trunc_x86(xf[0]);
     by = trunc_x86(yf[0]);
-    reg = (bx >= 0) && (bx + W - 1 <= p.cols - 2) && (by >= 0) && (by + W - 1 <= p.rows - 2);
+    reg = (bx >= 0) && (by >= 0);
 #pragma unroll
     for (int j = 1; j < W; ++j) reg = reg && (trunc_x86(xf[j]) == bx + j) && (trunc_x86(yf[j]) == by + j);
-    regular = reg;
+    const bool inside = (bx + W - 1 <= p.cols - 2) && (by + W - 1 <= p.rows - 2);
+    regular = reg && inside;
+    // Consecutive taps that hang over the RIGHT / BOTTOM border only: LinearInitAxis (sample_eigen.h:38-51) turns a tap
+    // with ix > size - 2 into (size - 1, size - 1, d = 1), which is what the regular separable walk computes on a window
+    // staged with clamped coordinates once the weights of those columns / rows are forced to 1 (both texels are the same
+    // pixel, 1 a + 0 a is exact).  About half of the border observations; the rest (left / top: the truncation toward
+    // zero maps two taps to pixel 0) keeps the per-tap pass.
+    reg_clamped = (RB == F) && reg && !inside && bx < 65536 && by < 32768 && p.rows < 32768 && p.cols < 65536;
   }
   if (PBA_EXPERIMENT_SKIP_IRREGULAR == 2 && p.n_obs > 0) active = active && regular;   // timing experiment (WRONG results): paths compiled in, never taken
   // Irregular observations (patch over the image border, clamped taps: sample_eigen.h:38-51) whose taps all fall into
@@ -835,7 +842,8 @@ void k_sample(SampleParams p_in) {
   constexpr bool kWindow = (RB == F);
   bool win_irr = false;
   int by0 = 0, bx0 = 0;
-  if (kWindow && active && !regular && p.rows < 32768 && p.cols < 65536) {
+  if (kWindow && reg_clamped) { by0 = by; bx0 = bx; }
+  if (kWindow && active && !regular && !reg_clamped && p.rows < 32768 && p.cols < 65536) {
     int a1, a2, l1, l2; float dd;
     linear_init_axis(yf[0], p.rows, a1, a2, dd);
     linear_init_axis(yf[W - 1], p.rows, l1, l2, dd);
@@ -857,22 +865,8 @@ void k_sample(SampleParams p_in) {
     win_irr = fits;
   }
   // >= 0: regular, linear texel index of the footprint origin;  -1: nothing to stage;  <= -2: windowed irregular, slot
-  s_base[wave][lane] = (active && regular) ? (int32_t)(slot * (p.rows * p.cols) + by * p.cols + bx) : (win_irr ? -2 - slot : -1);
+  s_base[wave][lane] = (active && regular) ? (int32_t)(slot * (p.rows * p.cols) + by * p.cols + bx) : ((win_irr || reg_clamped) ? -2 - slot : -1);
   if (kWindow) s_irr[wave][lane] = (by0 << 16) | bx0;
-  // descriptors of the first (up to) four windowed irregular observations of this wave, lane = pixel: requested here so
-  // that the cooperative pass after the walk does not start with a global round trip the whole workgroup waits for
-  int irr_src[4] = {-1, -1, -1, -1};
-  float irr_dsc[4] = {0.f, 0.f, 0.f, 0.f};
-  unsigned long long irr_rest = 0;
-  if (kWindow) {
-    irr_rest = __ballot(win_irr);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      irr_src[k] = irr_rest ? __builtin_amdgcn_readfirstlane(__ffsll((long long)irr_rest) - 1) : -1;
-      if (irr_rest) irr_rest &= irr_rest - 1;
-      if (irr_src[k] >= 0 && lane < W * W) irr_dsc[k] = p.desc[(size_t)__builtin_amdgcn_readlane(pt, irr_src[k] < 0 ? 0 : irr_src[k]) * (W * W) + lane];
-    }
-  }
   lds_barrier();
   PBA_STK(2);
 
@@ -890,7 +884,7 @@ void k_sample(SampleParams p_in) {
   constexpr int GB = sample_stage_groups(NG, RB * CW);
   constexpr int NPL = JAC ? 3 : 1;
   double m11 = 0, m12 = 0, m22 = 0, b1 = 0, b2 = 0, cc = 0;
-  const bool walk = active && regular;
+  const bool walk = active && (regular || reg_clamped);
   const float* p0 = p.desc + (size_t)pt * (W * W);
   // kLean (large patches): 1 - dx and dy are formed again where they are used instead of living in 33 registers
   constexpr bool kLean = (R >= 4);
@@ -906,11 +900,13 @@ void k_sample(SampleParams p_in) {
     u += 0x7fffu + ((u >> 16) & 1u);
     return __uint_as_float(u & 0xffff0000u);
   };
+  // columns / rows beyond these indices sit on the clamped border pixel (reg_clamped only)
+  const int jx_clamp = reg_clamped ? p.cols - 2 - bx : W, jy_clamp = reg_clamped ? p.rows - 2 - by : W;
 #pragma unroll
   for (int j = 0; j < W; ++j) {
-    dxs[j] = __fsub_rn((float)(bx + j + 1), xf[j]);
+    dxs[j] = (j > jx_clamp) ? 1.0f : __fsub_rn((float)(bx + j + 1), xf[j]);
     if (!kLean) {
-      dys[j] = __fsub_rn((float)(by + j + 1), yf[j]);
+      dys[j] = (j > jy_clamp) ? 1.0f : __fsub_rn((float)(by + j + 1), yf[j]);
       omdx[j] = __dsub_rn(1.0, (double)dxs[j]);
     }
   }
@@ -1133,21 +1129,18 @@ void k_sample(SampleParams p_in) {
     // window of lane `src`, then six fixed-order wave reductions.  A lane-serial walk of the per-tap rule costs ~3x the
     // regular walk and every lane of the wave waits for it; this costs ~200 instructions per irregular observation.
     static_assert(W * W <= 64, "one lane per pixel");
-    unsigned long long im = irr_rest;
-    bool first_trip = true;
-    while (first_trip ? (irr_src[0] >= 0) : (im != 0)) {
+    unsigned long long im = __ballot(win_irr);
+    while (im) {
       // up to four irregular observations per trip: their descriptor values (lane = pixel) are requested together, so
-      // that one global round trip serves four patches; the first trip's were requested before the walk
+      // that one global round trip serves four patches
       int srcs[4]; float dsc[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        if (first_trip) { srcs[k] = irr_src[k]; dsc[k] = irr_dsc[k]; continue; }
         srcs[k] = im ? __builtin_amdgcn_readfirstlane(__ffsll((long long)im) - 1) : -1;
         if (im) im &= im - 1;
         dsc[k] = 0.f;
         if (srcs[k] >= 0 && lane < W * W) dsc[k] = p.desc[(size_t)__builtin_amdgcn_readlane(pt, srcs[k] < 0 ? 0 : srcs[k]) * (W * W) + lane];
       }
-      first_trip = false;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
       const int src = srcs[k];
