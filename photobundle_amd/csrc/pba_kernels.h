@@ -1776,8 +1776,16 @@ __global__ __launch_bounds__(kTile, 2) void k_schur(SchurParams p_in) {
     }
     lds_barrier();     // every lane has its point totals: the region may now be overwritten with W | Y
     PBA_TICK(2);
+    // gradient-only pass (the last accepted point of a solve that stops at the iteration limit): only g_p and the
+    // camera sums of g_c,l are consumed, so the point-block inverse, U_l, r_l, W | Y and the pair blocks are skipped
+    const bool grad_only = p.final_pass != 0 && !p.init_scale;
     double Pm[6] = {0, 0, 0, 0, 0, 0};
-    if (active) {
+    if (active && grad_only) {
+      if (tid == l0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { gmax = fmax(gmax, fabs(gp[k])); gn2 += gp[k] * gp[k]; }
+      }
+    } else if (active) {
       const bool head = (tid == l0);
       double s[3];
       const double vd[3] = {V[0], V[3], V[5]};
@@ -1835,7 +1843,11 @@ __global__ __launch_bounds__(kTile, 2) void k_schur(SchurParams p_in) {
     // W_l (P g_p)) and again, together with Y_l = W_l P, when the pair goes to LDS after the camera-side sums: Ac, M Ap
     // and P are what stays in registers in between, and nothing of it survives into the pair-block phase, where the
     // register pressure peaks
-    if (active && fa >= 0) {
+    if (active && fa >= 0 && grad_only) {
+      double* so = s_obs + tid * kObsStride;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) so[27 + j] = -(Ac[0][j] * b[0] + Ac[1][j] * b[1]);
+    } else if (active && fa >= 0) {
       double* so = s_obs + tid * kObsStride;
       const double Pg[3] = {Pm[0] * gp[0] + Pm[1] * gp[1] + Pm[2] * gp[2], Pm[1] * gp[0] + Pm[3] * gp[1] + Pm[4] * gp[2],
                             Pm[2] * gp[0] + Pm[4] * gp[1] + Pm[5] * gp[2]};
@@ -1870,6 +1882,7 @@ __global__ __launch_bounds__(kTile, 2) void k_schur(SchurParams p_in) {
       const int e = tid + u * kTile;
       if (e < kCamVals * nf) {
         const int a = e / kCamVals, v = e - a * kCamVals;
+        if (grad_only && v < 27) continue;
         for (int q0 = 0; q0 < n_pts; q0 += 16) {
           // 16 lane indices of camera a in one 128-bit read, then independent loads, then the adds in point order
           const int4 l4 = *reinterpret_cast<const int4*>(s_lane_of + a * kTile + q0);
@@ -1895,6 +1908,10 @@ __global__ __launch_bounds__(kTile, 2) void k_schur(SchurParams p_in) {
     }
     lds_barrier();
     PBA_TICK(4);
+    if (tile + (int)gridDim.x < p.n_tiles && tid < ti_next.y) {      // next tile's point coordinates: one phase ahead
+      nx_x[0] = p.xyz[3 * (size_t)nx_pt]; nx_x[1] = p.xyz[3 * (size_t)nx_pt + 1]; nx_x[2] = p.xyz[3 * (size_t)nx_pt + 2];
+    }
+    if (grad_only) continue;      // (uniform) the barrier above already separates this tile's reads from the next tile's stores
     if (active && fa >= 0) {
       double* so = s_obs + tid * kObsStride;
 #pragma unroll
@@ -1912,9 +1929,6 @@ __global__ __launch_bounds__(kTile, 2) void k_schur(SchurParams p_in) {
     PBA_TICK(5);
 
     // ---- P3a: block owners: T(a, b) -= Y_la W_lb^T over this group's points ----------------------------------
-    if (tile + (int)gridDim.x < p.n_tiles && tid < ti_next.y) {
-      nx_x[0] = p.xyz[3 * (size_t)nx_pt]; nx_x[1] = p.xyz[3 * (size_t)nx_pt + 1]; nx_x[2] = p.xyz[3 * (size_t)nx_pt + 2];
-    }
     if (owner) {
       const int8_t* la_row = s_lane_of + pa * kTile;
       const int8_t* lb_row = s_lane_of + pb * kTile;
@@ -2174,7 +2188,7 @@ template <int T>
 __device__ __forceinline__ void solve_epilogue(const SolveParams& p, int n, const double* y, const double* sc,
                                                const double* D2, const double* gcs, const double* gc, bool chol_ok,
                                                int tid) {
-  if (tid < 6 * p.n_frames) {
+  if (tid < 6 * p.n_frames && !(p.final_pass && !p.init_scale)) {
     const int slot = tid / 6, k = tid % 6;
     const int fa = p.geom[slot].free_index;
     double d = 0.0;
@@ -2246,7 +2260,9 @@ __global__ __launch_bounds__(256) void k_solve_wave(SolveParams p_in) {
   unsigned long long t0 = (PBA_PHASE_TIMING ? __builtin_amdgcn_s_memtime() : 0ull), t1 = 0, t2 = 0, t3 = 0, t4 = 0;
   solve_prologue<256>(p, N, LD, S, y_s, sc, D2, gcs, gc, tid);
   t1 = (PBA_PHASE_TIMING ? __builtin_amdgcn_s_memtime() : 0ull);
-  if (tid < 64) {
+  if (p.final_pass && !p.init_scale) {
+    if (tid == 0) s_ok = 1;      // gradient-only pass: the epilogue only reports the norms of g_c
+  } else if (tid < 64) {
     const int lane = tid;
     const int r = lane < N ? lane : N - 1;
     const bool live = lane < N;

@@ -90,6 +90,7 @@ def _compare_traces(p, max_it, pose_tol=1e-5):
         assert np.isclose(a["cost"], b["cost"], rtol=1e-9), a["iteration"]
         assert np.isclose(a["trust_region_radius"], b["trust_region_radius"], rtol=1e-6)
         assert np.isclose(a["gradient_max_norm"], b["gradient_max_norm"], rtol=1e-6)
+        assert np.isclose(a["gradient_norm"], b["gradient_norm"], rtol=1e-6), a["iteration"]   # the last one: gradient-only pass
         if a["iteration"] > 0 and a["step_is_valid"]:
             assert np.isclose(a["step_norm"], b["step_norm"], rtol=1e-5)
     assert res["termination_type"] == ref["termination_type"]
