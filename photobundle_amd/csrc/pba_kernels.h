@@ -678,6 +678,21 @@ void k_sample(SampleParams p_in) {
   unsigned long long tl = p.dbg ? __builtin_amdgcn_s_memtime() : 0;
   const unsigned long long t_begin = p.dbg ? __builtin_amdgcn_s_memrealtime() : 0;   // 100 MHz, device-wide
 #define PBA_STK(k) do { if (p.dbg) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); tk[k] += tn - tl; tl = tn; } } while (0)
+  // fused form: the tile descriptor and the observation's indices do not depend on the tables -- requested first so
+  // that their two dependent round trips overlap the table loads instead of following the barrier
+  int4 ti_f = make_int4(0, 0, 0, 0);
+  int pt_f = 0, slot_f = 0, l0_f = 0, cnt_f = 0;
+  if (FUSED) {
+    const int tile = bid * ((WAVES * 64) / 128) + (int)(threadIdx.x >> 7);
+    if (tile < p.n_tiles) ti_f = p.tile_info[tile];
+    const int lt = threadIdx.x & 127;
+    if (lt < ti_f.y) {
+      const int o = ti_f.x + lt;
+      pt_f = p.obs_point[o];
+      slot_f = p.obs_slot[o];
+      l0_f = p.obs_l0[o]; cnt_f = p.obs_cnt[o];
+    }
+  }
   stage_geom<WAVES * 64>(p.geom, s_geom, p.n_frames, threadIdx.x);
   if (FUSED && !p.skip_backsub) {
     for (int e = threadIdx.x; e < kBk * p.n_frames; e += WAVES * 64) {
@@ -704,9 +719,7 @@ void k_sample(SampleParams p_in) {
     // delta_p = -P (g_p + sum_l W_l^T delta_c[slot_l]),  W_l^T delta_c = Ap^T M' (Ac delta_c)
     double* s_bs = reinterpret_cast<double*>(&s_tex[0][0]);       // [WAVES * 64][3], reused before the staging
     const int half = threadIdx.x >> 7, lt = threadIdx.x & 127;
-    const int tile = bid * ((WAVES * 64) / 128) + half;
-    int4 ti = make_int4(0, 0, 0, 0);
-    if (tile < p.n_tiles) ti = p.tile_info[tile];
+    const int4 ti = ti_f;
     active = lt < ti.y;
     obs = ti.x + lt;
     int l0 = 0, cnt = 0;
@@ -715,9 +728,9 @@ void k_sample(SampleParams p_in) {
 #pragma unroll
     for (int k = 0; k < 12; ++k) pr[k] = 0.0;
     if (active) {
-      pt = p.obs_point[obs];
-      slot = p.obs_slot[obs];
-      l0 = p.obs_l0[obs]; cnt = p.obs_cnt[obs];
+      pt = pt_f;
+      slot = slot_f;
+      l0 = l0_f; cnt = cnt_f;
       const double* xsrc = p.skip_backsub ? p.xyz : p.xyz_prev;
       X[0] = xsrc[3 * (size_t)pt]; X[1] = xsrc[3 * (size_t)pt + 1]; X[2] = xsrc[3 * (size_t)pt + 2];
       // issued here (same dependency level as X) so that they are in flight across the barrier below
