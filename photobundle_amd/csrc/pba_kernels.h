@@ -2070,14 +2070,20 @@ __global__ __launch_bounds__(1024) void k_reduce_final(const double* __restrict_
         for (int k = 0; k < 16; ++k) acc = is_max ? fmax(acc, v[k]) : acc + v[k];
       }
     }
-    s_red[sub][ex] = acc;
-    __syncthreads();
-    for (int s = SUB / 2; s > 0; s >>= 1) {
-      if (sub < s) s_red[sub][ex] = is_max ? fmax(s_red[sub][ex], s_red[sub + s][ex]) : s_red[sub][ex] + s_red[sub + s][ex];
-      __syncthreads();
+    // the four sub-chunks of a wave (lanes ex, ex + 16, ex + 32, ex + 48) combine by two cross-lane steps, the 16 waves
+    // through LDS, one thread per entry adds them in wave order: two barriers instead of a seven-level tree
+    static_assert(EX == 16, "lane = 16 (sub % 4) + ex");
+#pragma unroll
+    for (int off = 16; off <= 32; off <<= 1) {
+      const double o = __shfl_xor(acc, off);
+      acc = is_max ? fmax(acc, o) : acc + o;
     }
+    if ((tid & 63) < EX) s_red[tid >> 6][ex] = acc;
+    __syncthreads();
     if (sub == 0 && valid) {
-      const double v = s_red[0][ex];
+      double v = s_red[0][ex];
+#pragma unroll
+      for (int w = 1; w < 1024 / 64; ++w) v = is_max ? fmax(v, s_red[w][ex]) : v + s_red[w][ex];
       if (e < stride - 3) packed[e] = v;
       else if (e == stride - 3) scal[kGmaxPts] = v;
       else if (e == stride - 2) packed[stride - 2] = v;
