@@ -646,9 +646,7 @@ int pba_set_cameras(pba_engine* e, const double* cams6, int32_t n_frames, int32_
   return PBA_OK;
 }
 
-int pba_get_state(pba_engine* e, double* cams6, double* xyz) {
-  if (!e) return PBA_ERR_INVALID;
-  if (!e->have_problem || !e->have_cams) return fail(e, PBA_ERR_STATE, "call order violated: pba_get_state before set_problem/set_cameras");
+static int fetch_state(pba_engine* e, double* cams6, double* xyz) {
   HIP_TRY(e, hipSetDevice(e->cfg.device));
   // through the engine's host-mapped pinned buffer, written by a kernel: the runtime's copy call blocks for 8 ms the
   // first time a process moves a few hundred KB device -> host (seen in the drop-in class, pinned or pageable
@@ -662,6 +660,12 @@ int pba_get_state(pba_engine* e, double* cams6, double* xyz) {
   if (cams6) std::memcpy(cams6, e->h_state_stage, sizeof(double) * nc);
   if (xyz) std::memcpy(xyz, e->h_state_stage + nc, sizeof(double) * nx);
   return PBA_OK;
+}
+
+int pba_get_state(pba_engine* e, double* cams6, double* xyz) {
+  if (!e) return PBA_ERR_INVALID;
+  if (!e->have_problem || !e->have_cams) return fail(e, PBA_ERR_STATE, "call order violated: pba_get_state before set_problem/set_cameras");
+  return fetch_state(e, cams6, xyz);
 }
 
 int pba_set_inverse_depth(pba_engine* e, const double* rays6, const double* rho) {
@@ -690,8 +694,7 @@ int pba_get_points_world(pba_engine* e, double* xyz) {
   if (!e || !xyz) return PBA_ERR_INVALID;
   if (!e->have_problem) return fail(e, PBA_ERR_STATE, "call order violated: pba_get_points_world before pba_set_problem");
   HIP_TRY(e, hipSetDevice(e->cfg.device));
-  HIP_TRY(e, hipMemcpyAsync(xyz, e->d_xyz[e->cur], sizeof(double) * 3 * e->n_points, hipMemcpyDeviceToHost, e->stream));
-  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  { const int rc = fetch_state(e, nullptr, xyz); if (rc) return rc; }
   if (e->inverse_depth) {
     for (int i = 0; i < e->n_points; ++i) {
       const double inv = 1.0 / xyz[3 * (size_t)i];
