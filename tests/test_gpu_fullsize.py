@@ -147,22 +147,28 @@ def _pose_rmse(a, b):
     return float(np.sqrt(np.mean(d[:, :3] ** 2))), float(np.sqrt(np.mean(d[:, 3:] ** 2)))
 
 
-def _noise_floor_parity(ref, alt, res, tag):
+def _noise_floor_parity(ref, alts, res, tag):
     """Long solves of this problem are CHAOTIC in the rounding: the objective is piecewise bilinear in u8 images and the
-    window has a free scale gauge (only camera 0 is constant, photobundle.cc:809-813), so two double-precision CPU
-    evaluations of the SAME algorithm that differ only in rounding (`ref` = dual-number oracle, `alt` = a second oracle
-    run: analytic Jacobian, or inputs moved by one ulp) drift apart after a handful of iterations -- by 1e-4 in cost and
-    1e-3 m in translation at convergence.  That drift is the noise floor of the reference itself; the engine is held to it:
-      * while ref and alt still agree to 1e-9 in cost (the deterministic prefix) the engine matches ref to 1e-9 with
-        identical accept / reject decisions,
-      * afterwards its distance to ref stays within 20x the ref-alt distance seen so far,
-      * at the end its final cost and refined poses are within 3x the ref-alt distance (+ the north_star 1e-5)."""
-    ri, ai, gi = ref["iterations"], alt["iterations"], res["iterations"]
+    window has a free scale gauge (only camera 0 is constant, photobundle.cc:809-813), so double-precision CPU
+    evaluations of the SAME algorithm that differ only in rounding (`ref` = dual-number oracle, `alts` = further oracle
+    runs: analytic Jacobian, inputs moved by one ulp either way) drift apart after a handful of iterations.  At
+    configs[1] five such twins stop after 63 .. 98 iterations, by function OR parameter tolerance, with final costs up to
+    2.4e-3 apart and translations up to a few mm apart.  That spread is the noise floor of the reference itself; the
+    engine (one more rounding of the same algorithm) is held to it:
+      * while all twins still agree with ref to 1e-9 in cost (the deterministic prefix) the engine matches ref to 1e-9
+        with identical accept / reject decisions and trust-region radii,
+      * afterwards its distance to ref stays within 20x the largest twin-ref distance seen so far,
+      * at the end it has converged (termination_type 0) to a cost that is within 2x the twins' spread of its nearest
+        twin -- or below every twin's --, with poses within 2x the twins' pose spread (+ the north_star 1e-5) of its
+        nearest twin."""
+    if isinstance(alts, dict):
+        alts = [alts]
+    ri, gi = ref["iterations"], res["iterations"]
     floor, prefix = 0.0, 0
     rows = []
-    for i in range(min(len(ri), len(ai), len(gi))):
-        a, b, g = ri[i], ai[i], gi[i]
-        floor = max(floor, abs(a["cost"] - b["cost"]) / a["cost"])
+    for i in range(min([len(ri), len(gi)] + [len(a["iterations"]) for a in alts])):
+        a, g = ri[i], gi[i]
+        floor = max([floor] + [abs(a["cost"] - b["iterations"][i]["cost"]) / a["cost"] for b in alts])
         dg = abs(a["cost"] - g["cost"]) / a["cost"]
         rows.append((i, floor, dg))
         if floor <= 1e-9:
@@ -173,16 +179,23 @@ def _noise_floor_parity(ref, alt, res, tag):
         else:
             assert dg <= 20.0 * floor, (tag, i, floor, dg)
     assert prefix >= 4, (tag, prefix, rows[:8])
-    fc_floor = abs(ref["final_cost"] - alt["final_cost"]) / ref["final_cost"]
-    fc = abs(ref["final_cost"] - res["final_cost"]) / ref["final_cost"]
-    pr_floor, pt_floor = _pose_rmse(ref["cams"], alt["cams"])
-    pr, pt = _pose_rmse(ref["cams"], res["cams"])
-    print("%s: iterations ref %d / alt %d / engine %d; deterministic prefix %d iterations; final cost rel diff engine-ref %.3e "
-          "(ref-alt floor %.3e); pose RMSE engine-ref rot %.3e rad trans %.3e m (ref-alt floor %.3e / %.3e)"
-          % (tag, len(ri) - 1, len(ai) - 1, len(gi) - 1, prefix, fc, fc_floor, pr, pt, pr_floor, pt_floor))
-    assert fc <= 3.0 * fc_floor + 1e-9
-    assert pr <= 3.0 * pr_floor + 1e-5 and pt <= 3.0 * pt_floor + 1e-5
-    assert res["termination_type"] == ref["termination_type"]
+    twins = [ref] + list(alts)
+    fcs = np.array([t["final_cost"] for t in twins])
+    fc_spread = float((fcs.max() - fcs.min()) / fcs.min())
+    fc_near = float(np.min(np.abs(fcs - res["final_cost"]) / fcs))
+    pose_spread = [0.0, 0.0]
+    for i in range(len(twins)):
+        for j in range(i + 1, len(twins)):
+            r, t = _pose_rmse(twins[i]["cams"], twins[j]["cams"])
+            pose_spread = [max(pose_spread[0], r), max(pose_spread[1], t)]
+    pose_near = min((_pose_rmse(t["cams"], res["cams"]) for t in twins), key=lambda rt: rt[0] / max(pose_spread[0], 1e-30) + rt[1] / max(pose_spread[1], 1e-30))
+    print("%s: iterations of the %d CPU twins %s / engine %d; deterministic prefix %d iterations; final cost: engine %.8e, twins %s "
+          "(spread %.3e, engine to nearest twin %.3e); pose RMSE engine to nearest twin rot %.3e rad trans %.3e m (twins' spread %.3e / %.3e)"
+          % (tag, len(twins), [len(t["iterations"]) - 1 for t in twins], len(gi) - 1, prefix, res["final_cost"],
+             ["%.8e" % f for f in fcs], fc_spread, fc_near, pose_near[0], pose_near[1], pose_spread[0], pose_spread[1]))
+    assert res["termination_type"] == ref["termination_type"], (res["message"], ref["message"])
+    assert fc_near <= 2.0 * fc_spread + 1e-9 or res["final_cost"] <= fcs.min()
+    assert pose_near[0] <= 2.0 * pose_spread[0] + 1e-5 and pose_near[1] <= 2.0 * pose_spread[1] + 1e-5
     return prefix
 
 
@@ -195,11 +208,12 @@ def test_configs1_parity_to_convergence(full_window):
     from gpu_util import make_engine
     p = full_window
     ref = oracle.solve(p, oracle.default_options(num_threads=8, use_autodiff=1))
-    alt = oracle.solve(p, oracle.default_options(num_threads=8, use_autodiff=0))
+    o0 = oracle.default_options(num_threads=8, use_autodiff=0)
+    alts = [oracle.solve(p, o0), oracle.solve(p, o0, xyz=np.nextafter(p.xyz, np.inf)), oracle.solve(p, o0, xyz=np.nextafter(p.xyz, -np.inf))]
     assert ref["termination_type"] == 0 and len(ref["iterations"]) >= 10, ref["message"]
     with make_engine(p, keep_reduced_system=False) as e:
         res = e.solve(default_solver_options())
-    _noise_floor_parity(ref, alt, res, "configs[1] to convergence")
+    _noise_floor_parity(ref, alts, res, "configs[1] to convergence")
 
 
 @pytest.mark.timeout(1800)
@@ -212,10 +226,11 @@ def test_configs1_well_initialised_window_to_convergence():
     from gpu_util import make_engine
     p = synthetic.make_window(n_frames=8, n_points=50000, radius=2, rot_deg=0.02, trans=0.003, depth_noise=0.002)
     ref = oracle.solve(p, oracle.default_options(num_threads=8, use_autodiff=1))
-    alt = oracle.solve(p, oracle.default_options(num_threads=8, use_autodiff=0))
+    o0 = oracle.default_options(num_threads=8, use_autodiff=0)
+    alts = [oracle.solve(p, o0), oracle.solve(p, o0, xyz=np.nextafter(p.xyz, np.inf)), oracle.solve(p, o0, xyz=np.nextafter(p.xyz, -np.inf))]
     with make_engine(p, keep_reduced_system=False) as e:
         res = e.solve(default_solver_options())
-        prefix = _noise_floor_parity(ref, alt, res, "configs[1], well initialised, to convergence")
+        prefix = _noise_floor_parity(ref, alts, res, "configs[1], well initialised, to convergence")
         n_it = min(30, prefix - 1)
         assert n_it >= 10
         e.load(p)
@@ -237,11 +252,11 @@ def test_configs4_ten_iterations_against_oracle():
     n_it = 10
     o = oracle.default_options(max_num_iterations=n_it, num_threads=8, use_autodiff=0)
     ref = oracle.solve(p, o)
-    alt = oracle.solve(p, o, xyz=np.nextafter(p.xyz, np.inf))
+    alts = [oracle.solve(p, o, xyz=np.nextafter(p.xyz, np.inf)), oracle.solve(p, o, xyz=np.nextafter(p.xyz, -np.inf))]
     with make_engine(p, keep_reduced_system=False) as e:
         res = e.solve(default_solver_options(max_num_iterations=n_it))
     assert len(ref["iterations"]) == n_it + 1 == len(res["iterations"])
-    _noise_floor_parity(ref, alt, res, "configs[4] 10 iterations")
+    _noise_floor_parity(ref, alts, res, "configs[4] 10 iterations")
     for a, b in zip(ref["iterations"], res["iterations"]):
         assert a["step_is_successful"] == b["step_is_successful"]
 
