@@ -156,6 +156,9 @@ const char* pba_last_error(const pba_engine* e);
 void pba_default_solver_options(pba_solver_options* o);
 
 /* ---- lifetime ------------------------------------------------------------------------------------------ */
+/* Allocates the device state for cfg->max_frames frames of cfg->rows x cfg->cols, loads the library's code object and
+ * runs one frame-sized host -> device transfer, so that the first pba_set_frame_* / pba_solve of a process see the
+ * steady-state latency (the runtime's lazy set-up costs ~10 ms each otherwise).  ~30 ms. */
 int pba_create(const pba_config* cfg, pba_engine** out);
 void pba_destroy(pba_engine* e);
 
