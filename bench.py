@@ -255,7 +255,15 @@ def main():
         "k_sample<cost> (cost pass)": (ctr["cost_ms"], ctr["cost_launches"], ab["b_cost"]),
         "k_schur (point elimination)": (ctr["schur_ms"], ctr["schur_launches"], ab["schur"]),
     }
-    dom = max(kern, key=lambda k: kern[k][0] / max(1, kern[k][1]))      # largest average launch
+    # Largest average launch -- with one proviso: an event after every kernel makes the kernel END with a system-scope
+    # release, i.e. a write-back of the dirty lines it leaves in the L2 (k_schur: its 9 MB of partial sums), which the
+    # pipelined run of the timed region does not pay (rocprofv3 on the same build: k_sample 45.2 us, k_schur 41.0 us;
+    # event brackets: 46.8 / 46.7).  Kernels whose bracket is within 12 % of the longest count as tied, and the tie goes
+    # to the one that moves more algorithmic bytes per launch -- the one the HBM roofline is about.
+    avg_ms = {k: v[0] / max(1, v[1]) for k, v in kern.items()}
+    longest = max(avg_ms.values())
+    tied = [k for k in kern if avg_ms[k] >= 0.88 * longest and avg_ms[k] > 0]
+    dom = max(tied, key=lambda k: kern[k][2]) if tied else max(kern, key=lambda k: avg_ms[k])
     ms, launches, bytes_per_obs = kern[dom]
     avg_s = (ms / max(1, launches)) * 1e-3
     achieved = n_obs_local * bytes_per_obs / avg_s if avg_s > 0 else 0.0
