@@ -2309,11 +2309,12 @@ __global__ __launch_bounds__(256) void k_solve_wave(SolveParams p_in) {
       const bool below = rem > 0, here = rem == 0;       // row r is below / on the diagonal of column j
       // operands of the NEXT column's prefix (row j + 1 of L, entries k < j: all in LDS since the end of the previous
       // step) are requested first, so that their LDS latency runs under the dependent chain of this column
-      double2 rw[(N + 1) / 2];
+      typedef double v2d __attribute__((ext_vector_type(2)));      // one register quad per operand pair (see the pin below)
+      v2d rw[(N + 1) / 2];
       const double a_next = (j + 1 < N) ? S[r * LD + j + 1] : 0.0;
       if (j + 1 < N) {
 #pragma unroll
-        for (int k = 0; k + 1 < j; k += 2) rw[k / 2] = *reinterpret_cast<const double2*>(&LT[(j + 1) * LE + k]);
+        for (int k = 0; k + 1 < j; k += 2) rw[k / 2] = *reinterpret_cast<const v2d*>(&LT[(j + 1) * LE + k]);
         if (j & 1) rw[j / 2].x = LT[(j + 1) * LE + j - 1];
       }
       asm volatile("" ::: "memory");     // the requests stay here, ahead of the chain (the compiler would sink them next to their uses)
@@ -2341,7 +2342,7 @@ __global__ __launch_bounds__(256) void k_solve_wave(SolveParams p_in) {
         // of the row instead of one per operand pair
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int k = 0; k < (j + 1) / 2; ++k) asm volatile("" : "+v"(rw[k].x), "+v"(rw[k].y));   // the sums start here, not earlier
+        for (int k = 0; k < (j + 1) / 2; ++k) asm volatile("" : "+v"(rw[k]));   // the sums start here, not earlier (the PAIR is pinned: pinning the halves separately cost a register move per operand)
         pre0 = a_next; pre1 = 0.0;
         double pre2 = 0.0, pre3 = 0.0;
 #pragma unroll
