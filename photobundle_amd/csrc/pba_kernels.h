@@ -654,7 +654,7 @@ void k_sample(SampleParams p_in) {
   __shared__ __attribute__((aligned(16))) char s_raw[kTexBytes > kPreBytes ? kTexBytes : kPreBytes];
   uint32_t (*s_tex)[FF * LSTRIDE] = reinterpret_cast<uint32_t (*)[FF * LSTRIDE]>(s_raw);
   __shared__ int32_t s_base[WAVES][64];
-  __shared__ int32_t s_irr[(sample_rows_per_batch(R) == 2 * R + 2) ? WAVES : 1][64];   // (by0 << 16) | bx0 of windowed irregular observations
+  __shared__ int32_t s_irr[WAVES][64];   // (by0 << 16) | bx0: window anchor of the observations staged with clamped coordinates
   __shared__ double s_red[4 * WAVES];
   __shared__ int32_t s_fail;
 
@@ -843,7 +843,7 @@ void k_sample(SampleParams p_in) {
     // staged with clamped coordinates once the weights of those columns / rows are forced to 1 (both texels are the same
     // pixel, 1 a + 0 a is exact).  About half of the border observations; the rest (left / top: the truncation toward
     // zero maps two taps to pixel 0) keeps the per-tap pass.
-    reg_clamped = (RB == F) && reg && !inside && bx < 65536 && by < 32768 && p.rows < 32768 && p.cols < 65536;
+    reg_clamped = !FAST && reg && !inside && bx < 65536 && by < 32768 && p.rows < 32768 && p.cols < 65536;
   }
   if (PBA_EXPERIMENT_SKIP_IRREGULAR == 2 && p.n_obs > 0) active = active && regular;   // timing experiment (WRONG results): paths compiled in, never taken
   // Irregular observations (patch over the image border, clamped taps: sample_eigen.h:38-51) whose taps all fall into
@@ -855,7 +855,7 @@ void k_sample(SampleParams p_in) {
   constexpr bool kWindow = (RB == F);
   bool win_irr = false;
   int by0 = 0, bx0 = 0;
-  if (kWindow && reg_clamped) { by0 = by; bx0 = bx; }
+  if (reg_clamped) { by0 = by; bx0 = bx; }
   if (kWindow && active && !regular && !reg_clamped && p.rows < 32768 && p.cols < 65536) {
     int a1, a2, l1, l2; float dd;
     linear_init_axis(yf[0], p.rows, a1, a2, dd);
@@ -879,7 +879,7 @@ void k_sample(SampleParams p_in) {
   }
   // >= 0: regular, linear texel index of the footprint origin;  -1: nothing to stage;  <= -2: windowed irregular, slot
   s_base[wave][lane] = (active && regular) ? (int32_t)(slot * (p.rows * p.cols) + by * p.cols + bx) : ((win_irr || reg_clamped) ? -2 - slot : -1);
-  if (kWindow) s_irr[wave][lane] = (by0 << 16) | bx0;
+  s_irr[wave][lane] = (by0 << 16) | bx0;
   lds_barrier();
   PBA_STK(2);
 
@@ -946,14 +946,16 @@ void k_sample(SampleParams p_in) {
             for (int j = 0; j < CW; ++j) tx[gg][rr][j] = 0;
             if (bs[gg] >= 0) __builtin_memcpy(tx[gg][rr], fbytes + (boff + (uint32_t)((r0 + rr) * p.cols) * 4u), sizeof(uint32_t) * CW);
           }
-          if (kWindow && bs[gg] <= -2) {
-            // windowed irregular observation: the same F x F window, every texel at its clamped coordinates
+          if (bs[gg] <= -2) {
+            // clamped window (per-tap pass at R <= 2, right / bottom overhang at every radius): the same rows of the
+            // F x F window, every texel at its clamped coordinates
             const int ir = s_irr[wave][o & 63];
             const int wy = ir >> 16, wx = ir & 0xffff;
             const uint32_t* fr = p.frames + (size_t)(-2 - bs[gg]) * p.rows * p.cols;
 #pragma unroll
             for (int rr = 0; rr < RB; ++rr) {
-              const int row = min(wy + rr, p.rows - 1);
+              if (rr >= nr) continue;
+              const int row = min(wy + r0 + rr, p.rows - 1);
 #pragma unroll
               for (int j = 0; j < CW; ++j) tx[gg][rr][j] = fr[(size_t)row * p.cols + min(wx + ch * CW + j, p.cols - 1)];
             }
@@ -1016,7 +1018,7 @@ void k_sample(SampleParams p_in) {
             if (JAC) { fHp[NPL > 1 ? 1 : 0][j] = h1; fHp[NPL > 2 ? 2 : 0][j] = h2; }
           }
         } else {
-          const float dy = kLean ? __fsub_rn((float)(by + (r >= 1 ? i : 0) + 1), (float)(v + (double)((r >= 1 ? i : 0) - R))) : dys[kLean ? 0 : (r >= 1 ? i : 0)];
+          const float dy = kLean ? (((r >= 1 ? i : 0) > jy_clamp) ? 1.0f : __fsub_rn((float)(by + (r >= 1 ? i : 0) + 1), (float)(v + (double)((r >= 1 ? i : 0) - R)))) : dys[kLean ? 0 : (r >= 1 ? i : 0)];
           const float omdy = __fsub_rn(1.0f, dy);
           // PBA_WALK_ROWWISE: all horizontal lerps of the row first (independent work for the scheduler), then the
           // pixels; otherwise column by column (a third fewer live registers).  Same sums in the same order.
