@@ -655,6 +655,7 @@ void k_sample(SampleParams p_in) {
   uint32_t (*s_tex)[FF * LSTRIDE] = reinterpret_cast<uint32_t (*)[FF * LSTRIDE]>(s_raw);
   __shared__ int32_t s_base[WAVES][64];
   __shared__ int32_t s_irr[WAVES][64];   // (by0 << 16) | bx0: window anchor of the observations staged with clamped coordinates
+  __shared__ uint32_t s_win[(sample_rows_per_batch(R) == 2 * R + 2) ? 1 : WAVES][(sample_rows_per_batch(R) == 2 * R + 2) ? 1 : (2 * R + 2) * (2 * R + 2)];   // large radii: the clamped window of ONE irregular observation per wave
   __shared__ double s_red[4 * WAVES];
   __shared__ int32_t s_fail;
 
@@ -856,7 +857,7 @@ void k_sample(SampleParams p_in) {
   bool win_irr = false;
   int by0 = 0, bx0 = 0;
   if (reg_clamped) { by0 = by; bx0 = bx; }
-  if (kWindow && active && !regular && !reg_clamped && p.rows < 32768 && p.cols < 65536) {
+  if (!FAST && active && !regular && !reg_clamped && p.rows < 32768 && p.cols < 65536) {
     int a1, a2, l1, l2; float dd;
     linear_init_axis(yf[0], p.rows, a1, a2, dd);
     linear_init_axis(yf[W - 1], p.rows, l1, l2, dd);
@@ -878,7 +879,7 @@ void k_sample(SampleParams p_in) {
     win_irr = fits;
   }
   // >= 0: regular, linear texel index of the footprint origin;  -1: nothing to stage;  <= -2: windowed irregular, slot
-  s_base[wave][lane] = (active && regular) ? (int32_t)(slot * (p.rows * p.cols) + by * p.cols + bx) : ((win_irr || reg_clamped) ? -2 - slot : -1);
+  s_base[wave][lane] = (active && regular) ? (int32_t)(slot * (p.rows * p.cols) + by * p.cols + bx) : (((kWindow && win_irr) || reg_clamped) ? -2 - slot : -1);
   s_irr[wave][lane] = (by0 << 16) | bx0;
   lds_barrier();
   PBA_STK(2);
@@ -1195,6 +1196,60 @@ void k_sample(SampleParams p_in) {
       }
       if (lane == src) { cc = q_cc; m11 = q11; m12 = q12; m22 = q22; b1 = q1; b2 = q2; }
       }
+    }
+  }
+  if constexpr (!kWindow) {
+    // The same per-tap pass at patch radius > 2, where only RB rows of the footprints are ever staged: the wave loads the
+    // clamped F x F window of ONE irregular observation into its own LDS buffer (F^2 texels, F^2 / 64 loads per lane),
+    // then lane = pixel over ceil(W^2 / 64) rounds and six wave sums.  (These observations used to take the per-pixel
+    // path from global memory -- 11 dependent rounds of 44 loads at 11x11 -- with the whole workgroup waiting.)
+    unsigned long long im = FAST ? 0ull : __ballot(win_irr);
+    while (im) {
+      const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)im) - 1);
+      im &= im - 1;
+      const double us = readlane_f64(u, src), vs = readlane_f64(v, src);
+      const int wy = __builtin_amdgcn_readlane(by0, src), wx = __builtin_amdgcn_readlane(bx0, src);
+      const int sl = __builtin_amdgcn_readlane(slot, src), pts = __builtin_amdgcn_readlane(pt, src);
+      const uint32_t* fr = p.frames + (size_t)sl * p.rows * p.cols;
+      constexpr int NPX = (W * W + 63) / 64;
+      float dsc[NPX];
+#pragma unroll
+      for (int q = 0; q < NPX; ++q) dsc[q] = (q * 64 + lane < W * W) ? p.desc[(size_t)pts * (W * W) + q * 64 + lane] : 0.f;
+      for (int t = lane; t < F * F; t += 64) {
+        const int wr = t / F, wc = t - wr * F;
+        s_win[wave][t] = fr[(size_t)min(wy + wr, p.rows - 1) * p.cols + min(wx + wc, p.cols - 1)];
+      }
+      wave_lds_sync();
+      double q6[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int q = 0; q < NPX; ++q) {
+        const int pix = q * 64 + lane;
+        if (pix < W * W) {
+          const int i = pix / W, j = pix - i * W;
+          const float yfi = (float)(vs + (double)(i - R)), xfj = (float)(us + (double)(j - R));
+          int y1, y2, x1, x2; float dy, dx;
+          linear_init_axis(yfi, p.rows, y1, y2, dy);
+          linear_init_axis(xfj, p.cols, x1, x2, dx);
+          const float omdy = __fsub_rn(1.0f, dy);
+          const double omdxj = __dsub_rn(1.0, (double)dx);
+          const uint32_t* tw = &s_win[wave][0];
+          const int o1 = (y1 - wy) * F - wx, o2 = (y2 - wy) * F - wx;
+          const uint32_t t11 = tw[o1 + x1], t12 = tw[o1 + x2], t21 = tw[o2 + x1], t22 = tw[o2 + x2];
+          const float sI = vlerp_exact(dy, omdy, hlerp_exact(dx, omdxj, tex_I(t11), tex_I(t12)), hlerp_exact(dx, omdxj, tex_I(t21), tex_I(t22)));
+          const double e = (double)dsc[q] - (double)sI;
+          const double w2 = UNITW ? 1.0 : p.w2[pix];
+          q6[0] += w2 * e * e;
+          if (JAC) {
+            const double gx = (double)(0.5f * vlerp_exact(dy, omdy, hlerp_exact(dx, omdxj, tex_gx2(t11), tex_gx2(t12)), hlerp_exact(dx, omdxj, tex_gx2(t21), tex_gx2(t22))));
+            const double gy = (double)(0.5f * vlerp_exact(dy, omdy, hlerp_exact(dx, omdxj, tex_gy2(t11), tex_gy2(t12)), hlerp_exact(dx, omdxj, tex_gy2(t21), tex_gy2(t22))));
+            const double wgx = w2 * gx, wgy = w2 * gy;
+            q6[1] += wgx * gx; q6[2] += wgx * gy; q6[3] += wgy * gy; q6[4] += wgx * e; q6[5] += wgy * e;
+          }
+        }
+      }
+      wave_sum_n<6>(q6);
+      if (lane == src) { cc = q6[0]; m11 = q6[1]; m12 = q6[2]; m22 = q6[3]; b1 = q6[4]; b2 = q6[5]; }
+      wave_lds_sync();      // the next observation overwrites the window
     }
   }
   PBA_STK(4);
