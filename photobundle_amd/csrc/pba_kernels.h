@@ -1221,9 +1221,11 @@ void k_sample(SampleParams p_in) {
       }
       wave_lds_sync();
       double q6[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-#pragma unroll
+      static_assert(NPX <= 2, "descriptor select below");
+#pragma unroll 1     // (code size: the kernel is ~90 KB at 11x11 as it is)
       for (int q = 0; q < NPX; ++q) {
         const int pix = q * 64 + lane;
+        const float dsc_q = (NPX > 1 && q == 1) ? dsc[NPX > 1 ? 1 : 0] : dsc[0];
         if (pix < W * W) {
           const int i = pix / W, j = pix - i * W;
           const float yfi = (float)(vs + (double)(i - R)), xfj = (float)(us + (double)(j - R));
@@ -1236,7 +1238,7 @@ void k_sample(SampleParams p_in) {
           const int o1 = (y1 - wy) * F - wx, o2 = (y2 - wy) * F - wx;
           const uint32_t t11 = tw[o1 + x1], t12 = tw[o1 + x2], t21 = tw[o2 + x1], t22 = tw[o2 + x2];
           const float sI = vlerp_exact(dy, omdy, hlerp_exact(dx, omdxj, tex_I(t11), tex_I(t12)), hlerp_exact(dx, omdxj, tex_I(t21), tex_I(t22)));
-          const double e = (double)dsc[q] - (double)sI;
+          const double e = (double)dsc_q - (double)sI;
           const double w2 = UNITW ? 1.0 : p.w2[pix];
           q6[0] += w2 * e * e;
           if (JAC) {
