@@ -357,6 +357,10 @@ __device__ inline void lm_decide(LmState* st, const double* s, pba_iteration_sum
     else if (gmax <= st->gradient_tolerance) { st->done = kLmGradientTolerance; st->last_value[0] = gmax; }
     else if (st->radius <= st->min_radius) st->done = kLmMinRadius;
     if (st->done) return;
+    // the record of iteration zero is out; iteration one starts from a clean one (its step_is_successful / step_is_valid
+    // flags used to survive into a REJECTED first step's log entry)
+    memset(&it, 0, sizeof(it));
+    it.eta = 1e-1;
   } else if (st->pending_grad >= 0) {
     // gradient norms of the point accepted by the previous iteration + its deferred termination checks
     if (st->pending_grad < max_log) { log[st->pending_grad].gradient_max_norm = gmax; log[st->pending_grad].gradient_norm = gnorm; }

@@ -175,3 +175,27 @@ def test_solve_call_order_is_checked_before_anything_is_launched():
         e.close()
     for r in (b, c, d):
         assert r["final_cost"] == a["final_cost"] and np.array_equal(r["cams"], a["cams"]) and np.array_equal(r["xyz"], a["xyz"])
+
+
+def test_rejected_first_step_is_logged_as_rejected():
+    """A window whose FIRST trust-region step is rejected (case 66 of the seeded sweep in test_gpu_random_shapes.py): the
+    asynchronous driver logs iteration zero and decides iteration one in the same device call, and the iteration-one
+    record used to inherit step_is_successful = 1 from iteration zero when that step was rejected (the trajectory itself
+    was right).  Both drivers against the oracle, flag by flag."""
+    import test_gpu_random_shapes as sweep
+    p = sweep._make(sweep._draw_cases(67)[66])
+    ref = oracle.solve(p, oracle.default_options(max_num_iterations=5))
+    assert ref["iterations"][1]["step_is_successful"] == 0 and ref["iterations"][1]["step_is_valid"] == 1
+    for async_on in ("1", "0"):
+        os.environ["PBA_ASYNC"] = async_on
+        try:
+            with make_engine(p) as e:
+                res = e.solve(default_solver_options(max_num_iterations=5))
+        finally:
+            os.environ.pop("PBA_ASYNC", None)
+        assert len(res["iterations"]) == len(ref["iterations"])
+        for a, b in zip(ref["iterations"], res["iterations"]):
+            assert (a["step_is_valid"], a["step_is_successful"]) == (b["step_is_valid"], b["step_is_successful"]), (async_on, a["iteration"])
+            assert np.isclose(a["cost"], b["cost"], rtol=1e-9) and np.isclose(a["relative_decrease"], b["relative_decrease"], rtol=1e-6, atol=1e-12)
+        assert res["num_successful_steps"] == ref["num_successful_steps"]
+
