@@ -41,7 +41,7 @@ class Options(C.Structure):
         ("min_trust_region_radius", C.c_double), ("min_relative_decrease", C.c_double),
         ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double),
         ("max_num_consecutive_invalid_steps", C.c_int32), ("jacobi_scaling", C.c_int32),
-        ("use_autodiff", C.c_int32), ("reserved", C.c_int32),
+        ("use_autodiff", C.c_int32), ("extended_precision", C.c_int32),
     ]
 
 

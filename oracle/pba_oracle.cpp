@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstring>
 #include <limits>
+#include <type_traits>
 #include <vector>
 
 #ifdef _OPENMP
@@ -361,13 +362,15 @@ void EvalBlock(const oracle_problem* p, int obs, bool autodiff, double* r, doubl
 }
 
 // ceres::HuberLoss::Evaluate (loss_function.cc)
-inline void HuberEvaluate(double a, double s, double rho[3]) {
-  const double b = a * a;
+template <class Real>
+inline void HuberEvaluate(double a_, Real s, Real rho[3]) {
+  const Real a = a_;
+  const Real b = a * a;
   if (s > b) {
-    const double r = std::sqrt(s);
-    rho[0] = 2.0 * a * r - b;
-    rho[1] = std::max(std::numeric_limits<double>::min(), a / r);
-    rho[2] = -rho[1] / (2.0 * s);
+    const Real r = std::sqrt(s);
+    rho[0] = (Real)2.0 * a * r - b;
+    rho[1] = std::max((Real)std::numeric_limits<double>::min(), a / r);
+    rho[2] = -rho[1] / ((Real)2.0 * s);
   } else {
     rho[0] = s; rho[1] = 1.0; rho[2] = 0.0;
   }
@@ -380,7 +383,8 @@ inline void HuberEvaluate(double a, double s, double rho[3]) {
 // partial sums are combined in chunk order, which makes every result independent of the thread count.
 constexpr int kChunkPoints = 1024;
 
-struct Program {
+template <class Real>
+struct ProgramT {
   const oracle_problem* p;
   int P, n_c, n_p, n_obs;
   std::vector<int> cam_col;      // slot -> first column among free camera params, -1 if constant
@@ -392,7 +396,7 @@ struct Program {
   bool autodiff;
   int threads;
   // materialised (corrected, and after ScaleColumns: scaled) residuals + Jacobian
-  std::vector<double> r, Jc, Jp;
+  std::vector<Real> r, Jc, Jp;
   int64_t jac_passes = 0, cost_passes = 0;
 
   void init(const oracle_problem* prob, bool ad, int nthreads) {
@@ -412,11 +416,11 @@ struct Program {
   }
   // |x| over the parameter blocks of the Ceres program: the free cameras WITH residual blocks and every point.  (The
   // columns of an unobserved free camera stay in this restatement's x -- zero Jacobian, zero step -- but not in |x|.)
-  double programNorm(const std::vector<double>& x) const {
-    double s = 0.0;
+  Real programNorm(const std::vector<double>& x) const {
+    Real s = 0.0;
     for (int c = 0; c < n_c; ++c)
       if (cam_col[c] >= 0 && cam_in_program[c]) for (int k = 0; k < 6; ++k) s += x[cam_col[c] + k] * x[cam_col[c] + k];
-    for (int i = n_cam_params; i < n_params; ++i) s += x[i] * x[i];
+    for (int i = n_cam_params; i < n_params; ++i) s += (Real)x[i] * (Real)x[i];
     return std::sqrt(s);
   }
 
@@ -432,46 +436,63 @@ struct Program {
   }
 
   // Evaluator::Evaluate.  With want_jac: fills r/Jc/Jp (loss-corrected, unscaled) and gradient = J^T r.
-  bool evaluate(const std::vector<double>& x, double* cost, bool want_jac, std::vector<double>* gradient,
+  // The residual block itself (projection, fp32 sampler, dual-number / analytic Jacobian rows) is always evaluated in
+  // double: that IS the function the reference minimises.  Every sum over rows / blocks runs in Real.
+  bool evaluate(const std::vector<double>& x, Real* cost, bool want_jac, std::vector<Real>* gradient,
                 std::vector<double>* block_sqnorm = nullptr) {
     std::vector<double> cams(p->cams, p->cams + 6 * n_c), xyz(3 * (size_t)n_p);
     unpack(x, cams.data(), xyz.data());
     oracle_problem q = *p; q.cams = cams.data(); q.xyz = xyz.data();
     if (want_jac) { r.resize((size_t)n_obs * P); Jc.resize((size_t)n_obs * P * 6); Jp.resize((size_t)n_obs * P * 3); ++jac_passes; }
     else ++cost_passes;
-    std::vector<double> block_cost(n_obs);
+    std::vector<Real> block_cost(n_obs);
     if (block_sqnorm) block_sqnorm->resize(n_obs);
     bool ok = true;
+    constexpr bool kSame = std::is_same<Real, double>::value;
 #pragma omp parallel for num_threads(threads) schedule(static)
     for (int o = 0; o < n_obs; ++o) {
-      std::vector<double> rl;
+      std::vector<double> rl, jcl, jpl;
       double* rb; double* jc = nullptr; double* jp = nullptr;
-      if (want_jac) { rb = &r[(size_t)o * P]; jc = &Jc[(size_t)o * P * 6]; jp = &Jp[(size_t)o * P * 3]; }
-      else { rl.resize(P); rb = rl.data(); }
+      if (want_jac && kSame) {
+        rb = reinterpret_cast<double*>(&r[(size_t)o * P]); jc = reinterpret_cast<double*>(&Jc[(size_t)o * P * 6]); jp = reinterpret_cast<double*>(&Jp[(size_t)o * P * 3]);
+      } else {
+        rl.resize(P); rb = rl.data();
+        if (want_jac) { jcl.resize((size_t)P * 6); jpl.resize((size_t)P * 3); jc = jcl.data(); jp = jpl.data(); }
+      }
       EvalBlock(&q, o, autodiff, rb, jc, jp);
-      double s = 0.0;
-      for (int i = 0; i < P; ++i) s += rb[i] * rb[i];
-      if (block_sqnorm) (*block_sqnorm)[o] = s;
-      if (!std::isfinite(s)) {
+      Real s = 0.0;
+      for (int i = 0; i < P; ++i) s += (Real)rb[i] * (Real)rb[i];
+      if (block_sqnorm) (*block_sqnorm)[o] = (double)s;
+      if (!std::isfinite((double)s)) {
 #pragma omp critical
         ok = false;
       }
+      Real k = 1.0;
       if (p->huber > 0.0) {
         // ResidualBlock::Evaluate + Corrector (corrector.cc): rho'' <= 0 for Huber => plain sqrt(rho') scaling
-        double rho[3];
-        HuberEvaluate(p->huber, s, rho);
-        block_cost[o] = 0.5 * rho[0];
-        if (want_jac) {
-          const double k = std::sqrt(rho[1]);
-          for (int i = 0; i < P * 6; ++i) jc[i] *= k;
-          for (int i = 0; i < P * 3; ++i) jp[i] *= k;
-          for (int i = 0; i < P; ++i) rb[i] *= k;
-        }
+        Real rho[3];
+        HuberEvaluate<Real>(p->huber, s, rho);
+        block_cost[o] = (Real)0.5 * rho[0];
+        k = std::sqrt(rho[1]);
       } else {
-        block_cost[o] = 0.5 * s;
+        block_cost[o] = (Real)0.5 * s;
+      }
+      if (want_jac) {
+        if (kSame) {
+          if (p->huber > 0.0) {
+            for (int i = 0; i < P * 6; ++i) jc[i] *= (double)k;
+            for (int i = 0; i < P * 3; ++i) jp[i] *= (double)k;
+            for (int i = 0; i < P; ++i) rb[i] *= (double)k;
+          }
+        } else {
+          Real* ro = &r[(size_t)o * P]; Real* jco = &Jc[(size_t)o * P * 6]; Real* jpo = &Jp[(size_t)o * P * 3];
+          for (int i = 0; i < P * 6; ++i) jco[i] = (Real)jc[i] * k;
+          for (int i = 0; i < P * 3; ++i) jpo[i] = (Real)jp[i] * k;
+          for (int i = 0; i < P; ++i) ro[i] = (Real)rb[i] * k;
+        }
       }
     }
-    double c = 0.0;
+    Real c = 0.0;
     for (int o = 0; o < n_obs; ++o) c += block_cost[o];
     *cost = c;
     if (want_jac && gradient) {
@@ -479,17 +500,17 @@ struct Program {
       // camera part reduced in chunk order, so the result does not depend on the thread count
       gradient->assign(n_params, 0.0);
       const int n_chunks = (n_p + kChunkPoints - 1) / kChunkPoints;
-      std::vector<double> part((size_t)n_chunks * n_cam_params, 0.0);
+      std::vector<Real> part((size_t)n_chunks * n_cam_params, 0.0);
 #pragma omp parallel for num_threads(threads) schedule(dynamic, 1)
       for (int ch = 0; ch < n_chunks; ++ch) {
-        double* gc = part.data() + (size_t)ch * n_cam_params;
+        Real* gc = part.data() + (size_t)ch * n_cam_params;
         const int o0 = pt_begin[ch * kChunkPoints], o1 = pt_begin[std::min(n_p, (ch + 1) * kChunkPoints)];
         for (int o = o0; o < o1; ++o) {
           const int cc = cam_col[p->obs_slot[o]];
-          double* gp = gradient->data() + n_cam_params + 3 * (size_t)p->obs_point[o];
-          const double* rb = &r[(size_t)o * P];
-          const double* jc = &Jc[(size_t)o * P * 6];
-          const double* jp = &Jp[(size_t)o * P * 3];
+          Real* gp = gradient->data() + n_cam_params + 3 * (size_t)p->obs_point[o];
+          const Real* rb = &r[(size_t)o * P];
+          const Real* jc = &Jc[(size_t)o * P * 6];
+          const Real* jp = &Jp[(size_t)o * P * 3];
           for (int i = 0; i < P; ++i) {
             if (cc >= 0) for (int k = 0; k < 6; ++k) gc[cc + k] += jc[6 * i + k] * rb[i];
             for (int k = 0; k < 3; ++k) gp[k] += jp[3 * i + k] * rb[i];
@@ -503,19 +524,19 @@ struct Program {
   }
 
   // BlockSparseMatrix::SquaredColumnNorm
-  void squared_column_norm(std::vector<double>& out) const {
+  void squared_column_norm(std::vector<Real>& out) const {
     out.assign(n_params, 0.0);
     const int n_chunks = (n_p + kChunkPoints - 1) / kChunkPoints;
-    std::vector<double> part((size_t)n_chunks * n_cam_params, 0.0);
+    std::vector<Real> part((size_t)n_chunks * n_cam_params, 0.0);
 #pragma omp parallel for num_threads(threads) schedule(dynamic, 1)
     for (int ch = 0; ch < n_chunks; ++ch) {
-      double* oc = part.data() + (size_t)ch * n_cam_params;
+      Real* oc = part.data() + (size_t)ch * n_cam_params;
       const int o0 = pt_begin[ch * kChunkPoints], o1 = pt_begin[std::min(n_p, (ch + 1) * kChunkPoints)];
       for (int o = o0; o < o1; ++o) {
         const int cc = cam_col[p->obs_slot[o]];
-        double* np = out.data() + n_cam_params + 3 * (size_t)p->obs_point[o];
-        const double* jc = &Jc[(size_t)o * P * 6];
-        const double* jp = &Jp[(size_t)o * P * 3];
+        Real* np = out.data() + n_cam_params + 3 * (size_t)p->obs_point[o];
+        const Real* jc = &Jc[(size_t)o * P * 6];
+        const Real* jp = &Jp[(size_t)o * P * 3];
         for (int i = 0; i < P; ++i) {
           if (cc >= 0) for (int k = 0; k < 6; ++k) oc[cc + k] += jc[6 * i + k] * jc[6 * i + k];
           for (int k = 0; k < 3; ++k) np[k] += jp[3 * i + k] * jp[3 * i + k];
@@ -526,13 +547,13 @@ struct Program {
       for (int k = 0; k < n_cam_params; ++k) out[k] = (ch == 0) ? part[k] : out[k] + part[(size_t)ch * n_cam_params + k];
   }
   // BlockSparseMatrix::ScaleColumns
-  void scale_columns(const std::vector<double>& scale) {
+  void scale_columns(const std::vector<Real>& scale) {
 #pragma omp parallel for num_threads(threads) schedule(static)
     for (int o = 0; o < n_obs; ++o) {
       const int cc = cam_col[p->obs_slot[o]];
-      const double* sp = scale.data() + n_cam_params + 3 * (size_t)p->obs_point[o];
-      double* jc = &Jc[(size_t)o * P * 6];
-      double* jp = &Jp[(size_t)o * P * 3];
+      const Real* sp = scale.data() + n_cam_params + 3 * (size_t)p->obs_point[o];
+      Real* jc = &Jc[(size_t)o * P * 6];
+      Real* jp = &Jp[(size_t)o * P * 3];
       for (int i = 0; i < P; ++i) {
         if (cc >= 0) for (int k = 0; k < 6; ++k) jc[6 * i + k] *= scale[cc + k];
         for (int k = 0; k < 3; ++k) jp[3 * i + k] *= sp[k];
@@ -540,17 +561,17 @@ struct Program {
     }
   }
   // y = J x
-  void right_multiply(const std::vector<double>& x, std::vector<double>& y) const {
+  void right_multiply(const std::vector<Real>& x, std::vector<Real>& y) const {
     y.assign((size_t)n_obs * P, 0.0);
 #pragma omp parallel for num_threads(threads) schedule(static)
     for (int o = 0; o < n_obs; ++o) {
       const int cc = cam_col[p->obs_slot[o]];
-      const double* xp = x.data() + n_cam_params + 3 * (size_t)p->obs_point[o];
-      const double* jc = &Jc[(size_t)o * P * 6];
-      const double* jp = &Jp[(size_t)o * P * 3];
-      double* yb = &y[(size_t)o * P];
+      const Real* xp = x.data() + n_cam_params + 3 * (size_t)p->obs_point[o];
+      const Real* jc = &Jc[(size_t)o * P * 6];
+      const Real* jp = &Jp[(size_t)o * P * 3];
+      Real* yb = &y[(size_t)o * P];
       for (int i = 0; i < P; ++i) {
-        double acc = 0.0;
+        Real acc = 0.0;
         if (cc >= 0) for (int k = 0; k < 6; ++k) acc += jc[6 * i + k] * x[cc + k];
         for (int k = 0; k < 3; ++k) acc += jp[3 * i + k] * xp[k];
         yb[i] = acc;
@@ -560,76 +581,79 @@ struct Program {
 };
 
 // 3x3 SPD inverse through Cholesky (Ceres InvertPSDMatrix -> Eigen LLT solve against identity).
-bool InvertPSD3(const double* m /*row-major sym*/, double* inv) {
-  double L[9] = {0};
+template <class Real>
+bool InvertPSD3(const Real* m /*row-major sym*/, Real* inv) {
+  Real L[9] = {0};
   for (int i = 0; i < 3; ++i) {
     for (int j = 0; j <= i; ++j) {
-      double s = m[3 * i + j];
+      Real s = m[3 * i + j];
       for (int k = 0; k < j; ++k) s -= L[3 * i + k] * L[3 * j + k];
       if (i == j) { if (!(s > 0.0)) return false; L[3 * i + i] = std::sqrt(s); }
       else L[3 * i + j] = s / L[3 * j + j];
     }
   }
   for (int c = 0; c < 3; ++c) {
-    double y[3], x[3];
-    for (int i = 0; i < 3; ++i) { double s = (i == c) ? 1.0 : 0.0; for (int k = 0; k < i; ++k) s -= L[3 * i + k] * y[k]; y[i] = s / L[3 * i + i]; }
-    for (int i = 2; i >= 0; --i) { double s = y[i]; for (int k = i + 1; k < 3; ++k) s -= L[3 * k + i] * x[k]; x[i] = s / L[3 * i + i]; }
+    Real y[3], x[3];
+    for (int i = 0; i < 3; ++i) { Real s = (i == c) ? 1.0 : 0.0; for (int k = 0; k < i; ++k) s -= L[3 * i + k] * y[k]; y[i] = s / L[3 * i + i]; }
+    for (int i = 2; i >= 0; --i) { Real s = y[i]; for (int k = i + 1; k < 3; ++k) s -= L[3 * k + i] * x[k]; x[i] = s / L[3 * i + i]; }
     for (int i = 0; i < 3; ++i) inv[3 * i + c] = x[i];
   }
   return true;
 }
 
 // Dense Cholesky solve (the reduced camera system; SPARSE_SCHUR factorises exactly).
-bool CholeskySolve(std::vector<double>& A, int n, std::vector<double>& b) {
+template <class Real>
+bool CholeskySolve(std::vector<Real>& A, int n, std::vector<Real>& b) {
   for (int j = 0; j < n; ++j) {
-    double s = A[(size_t)j * n + j];
+    Real s = A[(size_t)j * n + j];
     for (int k = 0; k < j; ++k) s -= A[(size_t)j * n + k] * A[(size_t)j * n + k];
-    if (!(s > 0.0) || !std::isfinite(s)) return false;
-    const double d = std::sqrt(s);
+    if (!(s > 0.0) || !std::isfinite((double)s)) return false;
+    const Real d = std::sqrt(s);
     A[(size_t)j * n + j] = d;
     for (int i = j + 1; i < n; ++i) {
-      double t = A[(size_t)i * n + j];
+      Real t = A[(size_t)i * n + j];
       for (int k = 0; k < j; ++k) t -= A[(size_t)i * n + k] * A[(size_t)j * n + k];
       A[(size_t)i * n + j] = t / d;
     }
   }
-  for (int i = 0; i < n; ++i) { double s = b[i]; for (int k = 0; k < i; ++k) s -= A[(size_t)i * n + k] * b[k]; b[i] = s / A[(size_t)i * n + i]; }
-  for (int i = n - 1; i >= 0; --i) { double s = b[i]; for (int k = i + 1; k < n; ++k) s -= A[(size_t)k * n + i] * b[k]; b[i] = s / A[(size_t)i * n + i]; }
+  for (int i = 0; i < n; ++i) { Real s = b[i]; for (int k = 0; k < i; ++k) s -= A[(size_t)i * n + k] * b[k]; b[i] = s / A[(size_t)i * n + i]; }
+  for (int i = n - 1; i >= 0; --i) { Real s = b[i]; for (int k = i + 1; k < n; ++k) s -= A[(size_t)k * n + i] * b[k]; b[i] = s / A[(size_t)i * n + i]; }
   return true;
 }
 
 // SchurComplementSolver::Solve: min |J y - r|^2 + |D y|^2, points eliminated (SchurEliminator::Eliminate /
 // ::BackSubstitute), reduced system by Cholesky.  Returns false on LINEAR_SOLVER_FAILURE.
-bool SchurSolve(const Program& g, const std::vector<double>& D, std::vector<double>& y) {
+template <class Real>
+bool SchurSolve(const ProgramT<Real>& g, const std::vector<Real>& D, std::vector<Real>& y) {
   const oracle_problem* p = g.p;
   const int n = g.n_cam_params, P = g.P;
-  std::vector<double> S((size_t)n * n, 0.0), rhs(n, 0.0);
-  std::vector<double> inv_ete((size_t)g.n_p * 9), gvec((size_t)g.n_p * 3);
+  std::vector<Real> S((size_t)n * n, 0.0), rhs(n, 0.0);
+  std::vector<Real> inv_ete((size_t)g.n_p * 9), gvec((size_t)g.n_p * 3);
   bool ok = true;
   // SchurEliminator::Eliminate runs its chunks on num_linear_solver_threads threads (photobundle.cc:754) with per-thread
   // buffers; here every chunk of kChunkPoints points accumulates into its own S / rhs and the chunks are added in order
   const int n_chunks = (g.n_p + kChunkPoints - 1) / kChunkPoints;
-  std::vector<double> S_part((size_t)n_chunks * n * n, 0.0), rhs_part((size_t)n_chunks * n, 0.0);
+  std::vector<Real> S_part((size_t)n_chunks * n * n, 0.0), rhs_part((size_t)n_chunks * n, 0.0);
   std::vector<char> chunk_ok(n_chunks, 1);
   for (int i = 0; i < n; ++i) S_part[(size_t)i * n + i] = D[i] * D[i];     // chunk 0 starts from the LM diagonal
 #pragma omp parallel for num_threads(g.threads) schedule(dynamic, 1)
   for (int ch = 0; ch < n_chunks; ++ch) {
-  double* S = S_part.data() + (size_t)ch * n * n;
-  double* rhs = rhs_part.data() + (size_t)ch * n;
-  std::vector<double> buf((size_t)g.n_c * 18 + 64);
+  Real* S = S_part.data() + (size_t)ch * n * n;
+  Real* rhs = rhs_part.data() + (size_t)ch * n;
+  std::vector<Real> buf((size_t)g.n_c * 18 + 64);
   for (int pt = ch * kChunkPoints; pt < std::min(g.n_p, (ch + 1) * kChunkPoints); ++pt) {
     const int b = g.pt_begin[pt], e = g.pt_begin[pt + 1];
     if (b == e) continue;
-    const double* Dp = D.data() + n + 3 * (size_t)pt;
-    double ete[9] = {Dp[0] * Dp[0], 0, 0, 0, Dp[1] * Dp[1], 0, 0, 0, Dp[2] * Dp[2]};
-    double ge[3] = {0, 0, 0};
+    const Real* Dp = D.data() + n + 3 * (size_t)pt;
+    Real ete[9] = {Dp[0] * Dp[0], 0, 0, 0, Dp[1] * Dp[1], 0, 0, 0, Dp[2] * Dp[2]};
+    Real ge[3] = {0, 0, 0};
     if ((int)buf.size() < (e - b) * 18) buf.resize((size_t)(e - b) * 18);
     for (int o = b; o < e; ++o) {
       const int cc = g.cam_col[p->obs_slot[o]];
-      const double* rb = &g.r[(size_t)o * P];
-      const double* jc = &g.Jc[(size_t)o * P * 6];
-      const double* jp = &g.Jp[(size_t)o * P * 3];
-      double* etf = &buf[(size_t)(o - b) * 18];  // 3 x 6
+      const Real* rb = &g.r[(size_t)o * P];
+      const Real* jc = &g.Jc[(size_t)o * P * 6];
+      const Real* jp = &g.Jp[(size_t)o * P * 3];
+      Real* etf = &buf[(size_t)(o - b) * 18];  // 3 x 6
       for (int k = 0; k < 18; ++k) etf[k] = 0.0;
       for (int i = 0; i < P; ++i) {
         for (int a = 0; a < 3; ++a) {
@@ -642,29 +666,29 @@ bool SchurSolve(const Program& g, const std::vector<double>& D, std::vector<doub
         }
       }
     }
-    double* inv = &inv_ete[(size_t)pt * 9];
+    Real* inv = &inv_ete[(size_t)pt * 9];
     if (!InvertPSD3(ete, inv)) { chunk_ok[ch] = 0; break; }
     for (int a = 0; a < 3; ++a) gvec[(size_t)pt * 3 + a] = ge[a];
-    double ig[3];
+    Real ig[3];
     for (int a = 0; a < 3; ++a) ig[a] = inv[3 * a] * ge[0] + inv[3 * a + 1] * ge[1] + inv[3 * a + 2] * ge[2];
     for (int o = b; o < e; ++o) {
       const int cc = g.cam_col[p->obs_slot[o]];
       if (cc < 0) continue;
-      const double* rb = &g.r[(size_t)o * P];
-      const double* jc = &g.Jc[(size_t)o * P * 6];
-      const double* jp = &g.Jp[(size_t)o * P * 3];
+      const Real* rb = &g.r[(size_t)o * P];
+      const Real* jc = &g.Jc[(size_t)o * P * 6];
+      const Real* jp = &g.Jp[(size_t)o * P * 3];
       for (int i = 0; i < P; ++i) {
-        const double sj = rb[i] - (jp[3 * i] * ig[0] + jp[3 * i + 1] * ig[1] + jp[3 * i + 2] * ig[2]);
+        const Real sj = rb[i] - (jp[3 * i] * ig[0] + jp[3 * i + 1] * ig[1] + jp[3 * i + 2] * ig[2]);
         for (int a = 0; a < 6; ++a) rhs[cc + a] += jc[6 * i + a] * sj;
       }
-      const double* etf1 = &buf[(size_t)(o - b) * 18];
-      double t[18];  // (E^T F_1)^T inv  : 6 x 3
+      const Real* etf1 = &buf[(size_t)(o - b) * 18];
+      Real t[18];  // (E^T F_1)^T inv  : 6 x 3
       for (int a = 0; a < 6; ++a) for (int c = 0; c < 3; ++c)
         t[3 * a + c] = etf1[a] * inv[c] + etf1[6 + a] * inv[3 + c] + etf1[12 + a] * inv[6 + c];
       for (int o2 = b; o2 < e; ++o2) {
         const int c2 = g.cam_col[p->obs_slot[o2]];
         if (c2 < 0) continue;
-        const double* etf2 = &buf[(size_t)(o2 - b) * 18];
+        const Real* etf2 = &buf[(size_t)(o2 - b) * 18];
         for (int a = 0; a < 6; ++a) for (int c = 0; c < 6; ++c)
           S[(size_t)(cc + a) * n + c2 + c] -= t[3 * a] * etf2[c] + t[3 * a + 1] * etf2[6 + c] + t[3 * a + 2] * etf2[12 + c];
       }
@@ -673,14 +697,14 @@ bool SchurSolve(const Program& g, const std::vector<double>& D, std::vector<doub
   }
   for (int ch = 0; ch < n_chunks; ++ch) {
     if (!chunk_ok[ch]) ok = false;
-    const double* Sc = S_part.data() + (size_t)ch * n * n;
-    const double* rc = rhs_part.data() + (size_t)ch * n;
+    const Real* Sc = S_part.data() + (size_t)ch * n * n;
+    const Real* rc = rhs_part.data() + (size_t)ch * n;
     for (size_t k = 0; k < (size_t)n * n; ++k) S[k] = (ch == 0) ? Sc[k] : S[k] + Sc[k];
     for (int k = 0; k < n; ++k) rhs[k] = (ch == 0) ? rc[k] : rhs[k] + rc[k];
   }
   if (n_chunks == 0) for (int i = 0; i < n; ++i) S[(size_t)i * n + i] = D[i] * D[i];
   if (!ok) return false;
-  std::vector<double> yc = rhs;
+  std::vector<Real> yc = rhs;
   if (n > 0 && !CholeskySolve(S, n, yc)) return false;
   y.assign(g.n_params, 0.0);
   for (int i = 0; i < n; ++i) y[i] = yc[i];
@@ -689,33 +713,234 @@ bool SchurSolve(const Program& g, const std::vector<double>& D, std::vector<doub
   for (int pt = 0; pt < g.n_p; ++pt) {
     const int b = g.pt_begin[pt], e = g.pt_begin[pt + 1];
     if (b == e) continue;
-    double acc[3] = {0, 0, 0};
+    Real acc[3] = {0, 0, 0};
     for (int o = b; o < e; ++o) {
       const int cc = g.cam_col[p->obs_slot[o]];
-      const double* rb = &g.r[(size_t)o * P];
-      const double* jc = &g.Jc[(size_t)o * P * 6];
-      const double* jp = &g.Jp[(size_t)o * P * 3];
+      const Real* rb = &g.r[(size_t)o * P];
+      const Real* jc = &g.Jc[(size_t)o * P * 6];
+      const Real* jp = &g.Jp[(size_t)o * P * 3];
       for (int i = 0; i < P; ++i) {
-        double sj = rb[i];
+        Real sj = rb[i];
         if (cc >= 0) for (int a = 0; a < 6; ++a) sj -= jc[6 * i + a] * yc[cc + a];
         for (int a = 0; a < 3; ++a) acc[a] += jp[3 * i + a] * sj;
       }
     }
-    const double* inv = &inv_ete[(size_t)pt * 9];
+    const Real* inv = &inv_ete[(size_t)pt * 9];
     for (int a = 0; a < 3; ++a) y[n + 3 * (size_t)pt + a] = inv[3 * a] * acc[0] + inv[3 * a + 1] * acc[1] + inv[3 * a + 2] * acc[2];
   }
-  for (double v : y) if (!std::isfinite(v)) return false;
+  for (Real v : y) if (!std::isfinite((double)v)) return false;
   return true;
 }
 
-double Norm(const std::vector<double>& v) { double s = 0; for (double x : v) s += x * x; return std::sqrt(s); }
-double MaxAbs(const std::vector<double>& v) { double s = 0; for (double x : v) s = std::max(s, std::fabs(x)); return s; }
+template <class Real>
+Real Norm(const std::vector<Real>& v) { Real s = 0; for (Real x : v) s += x * x; return std::sqrt(s); }
+template <class Real>
+Real MaxAbs(const std::vector<Real>& v) { Real s = 0; for (Real x : v) s = std::max(s, std::fabs(x)); return s; }
+
+
+using Program = ProgramT<double>;
 
 double Now() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
 }  // namespace
+
+// ceres::Solve (photobundle.cc:829) -> TrustRegionMinimizer::Minimize, in the accumulation type Real
+template <class Real>
+int SolveT(oracle_problem* p, const oracle_options* opt, oracle_summary* sum, oracle_iteration* its, int max_its_out) {
+  // ceres::Solve (photobundle.cc:829) -> TrustRegionMinimizer::Minimize (Ceres >= 1.12 control flow, SURVEY 8c)
+  const double t_start = Now();
+  ProgramT<Real> g; g.init(p, opt->use_autodiff != 0, opt->num_threads);
+  std::memset(sum, 0, sizeof(*sum));
+  sum->num_residual_blocks = g.n_obs;
+  sum->num_residuals = g.n_obs * g.P;
+  sum->fixed_cost = 0.0;  // every block has a free point (SURVEY 8c "Constant camera 0")
+  sum->termination_type = 1;
+  std::snprintf(sum->message, sizeof(sum->message), "Maximum number of iterations reached.");
+
+  std::vector<double> x, candidate_x;
+  std::vector<Real> gradient, scale, diagonal, D, step, delta, model_residuals;
+  g.pack(p->cams, p->xyz, x);
+  Real x_cost = 0.0, candidate_cost = 0.0, x_norm = g.programNorm(x);
+  double radius = opt->initial_trust_region_radius, decrease_factor = 2.0;
+  bool reuse_diagonal = false;
+  int num_consecutive_invalid_steps = 0;
+  int n_it = 0;
+  Real minimum_cost;
+  std::vector<double> best_x = x;
+
+  oracle_iteration it;
+  std::memset(&it, 0, sizeof(it));
+  auto push_iteration = [&](const oracle_iteration& s) {
+    if (n_it < max_its_out && its) its[n_it] = s;
+    ++n_it;
+  };
+  auto eval_grad_jac = [&]() -> bool {
+    // TrustRegionMinimizer::EvaluateGradientAndJacobian
+    if (!g.evaluate(x, &x_cost, true, &gradient)) return false;
+    it.cost = (double)x_cost + sum->fixed_cost;
+    if (opt->jacobi_scaling) {
+      if (it.iteration == 0) {
+        g.squared_column_norm(scale);
+        for (Real& s : scale) s = (Real)1.0 / ((Real)1.0 + std::sqrt(s));
+      }
+      g.scale_columns(scale);
+    } else if (scale.empty()) scale.assign(g.n_params, 1.0);
+    it.gradient_max_norm = (double)MaxAbs(gradient);   // Euclidean Plus: |x - (x - g)|_inf
+    it.gradient_norm = (double)Norm(gradient);
+    return true;
+  };
+
+  // IterationZero
+  double t_iter = Now();
+  it.iteration = 0; it.eta = 1e-1;
+  if (!eval_grad_jac()) {
+    sum->termination_type = 2;
+    std::snprintf(sum->message, sizeof(sum->message), "Initial residual and Jacobian evaluation failed.");
+    sum->total_time_in_seconds = Now() - t_start;
+    return 2;
+  }
+  sum->initial_cost = (double)x_cost + sum->fixed_cost;
+  minimum_cost = x_cost;
+  it.step_is_valid = 1; it.step_is_successful = 1;
+
+  bool done = false;
+  auto finalize = [&]() -> bool {
+    // FinalizeIterationAndCheckIfMinimizerCanContinue
+    if (it.step_is_successful) {
+      ++sum->num_successful_steps;
+      if (x_cost < minimum_cost || it.iteration == 0) { minimum_cost = x_cost; best_x = x; it.step_is_nonmonotonic = 0; }
+      else it.step_is_nonmonotonic = 1;
+    } else ++sum->num_unsuccessful_steps;
+    it.trust_region_radius = radius;
+    const double now = Now();
+    it.iteration_time_in_seconds = now - t_iter;
+    it.cumulative_time_in_seconds = now - t_start;
+    push_iteration(it);
+    if (it.iteration >= opt->max_num_iterations) {
+      sum->termination_type = 1; std::snprintf(sum->message, sizeof(sum->message), "Maximum number of iterations reached. Number of iterations: %d.", it.iteration); return false; }
+    if (it.step_is_successful && it.gradient_max_norm <= opt->gradient_tolerance) {
+      sum->termination_type = 0; std::snprintf(sum->message, sizeof(sum->message), "Gradient tolerance reached. Gradient max norm: %e <= %e", it.gradient_max_norm, opt->gradient_tolerance); return false; }
+    if (radius <= opt->min_trust_region_radius) {
+      sum->termination_type = 0; std::snprintf(sum->message, sizeof(sum->message), "Minimum trust region radius reached. Trust region radius: %e <= %e", radius, opt->min_trust_region_radius); return false; }
+    return true;
+  };
+  auto step_rejected = [&]() { radius = radius / decrease_factor; decrease_factor *= 2.0; reuse_diagonal = true; };
+
+  while (!done && finalize()) {
+    t_iter = Now();
+    const int iteration = it.iteration + 1;
+    const double prev_gmax = it.gradient_max_norm, prev_gnorm = it.gradient_norm;
+    std::memset(&it, 0, sizeof(it));
+    it.iteration = iteration; it.eta = 1e-1;
+    it.gradient_max_norm = prev_gmax; it.gradient_norm = prev_gnorm;
+
+    // ComputeTrustRegionStep -> LevenbergMarquardtStrategy::ComputeStep
+    const double t_solve = Now();
+    if (!reuse_diagonal) {
+      g.squared_column_norm(diagonal);
+      for (Real& d : diagonal) d = std::min(std::max(d, (Real)opt->min_lm_diagonal), (Real)opt->max_lm_diagonal);
+    }
+    D.resize(g.n_params);
+    for (int i = 0; i < g.n_params; ++i) D[i] = std::sqrt(diagonal[i] / (Real)radius);
+    bool solved = SchurSolve(g, D, step);
+    reuse_diagonal = true;
+    bool step_is_valid = false;
+    Real model_cost_change = 0.0;
+    if (solved) {
+      for (Real& s : step) s *= (Real)-1.0;
+      // model_cost_change = -(J step)^T (r + J step / 2)
+      g.right_multiply(step, model_residuals);
+      Real acc = 0.0;
+      for (size_t i = 0; i < model_residuals.size(); ++i) acc += model_residuals[i] * (g.r[i] + model_residuals[i] / (Real)2.0);
+      model_cost_change = -acc;
+      step_is_valid = model_cost_change > 0.0;
+    }
+    it.step_solver_time_in_seconds = Now() - t_solve;
+    it.model_cost_change = (double)model_cost_change;
+    it.linear_solver_iterations = 1;
+    if (!step_is_valid) {
+      // HandleInvalidStep
+      ++num_consecutive_invalid_steps;
+      if (num_consecutive_invalid_steps >= opt->max_num_consecutive_invalid_steps) {
+        sum->termination_type = 2;
+        std::snprintf(sum->message, sizeof(sum->message), "Number of consecutive invalid steps more than Solver::Options::max_num_consecutive_invalid_steps: %d", opt->max_num_consecutive_invalid_steps);
+        it.cost = (double)x_cost + sum->fixed_cost; it.trust_region_radius = radius;
+        push_iteration(it);
+        done = true; break;
+      }
+      step_rejected();  // LevenbergMarquardtStrategy::StepIsInvalid == StepRejected(0)
+      it.cost = (double)x_cost + sum->fixed_cost;
+      it.cost_change = 0.0; it.step_norm = 0.0; it.relative_decrease = 0.0;
+      it.step_is_valid = 0; it.step_is_successful = 0;
+      continue;
+    }
+    it.step_is_valid = 1;
+    num_consecutive_invalid_steps = 0;
+    delta.resize(g.n_params);
+    for (int i = 0; i < g.n_params; ++i) delta[i] = step[i] * scale[i];
+
+    // ComputeCandidatePointAndEvaluateCost
+    candidate_x.resize(g.n_params);
+    for (int i = 0; i < g.n_params; ++i) candidate_x[i] = (double)((Real)x[i] + delta[i]);
+    if (!g.evaluate(candidate_x, &candidate_cost, false, nullptr)) candidate_cost = std::numeric_limits<double>::max();
+    it.candidate_cost = (double)candidate_cost;
+
+    // ParameterToleranceReached
+    Real step_norm;
+    { Real s = 0; for (int i = 0; i < g.n_params; ++i) { const Real d = x[i] - candidate_x[i]; s += d * d; } step_norm = std::sqrt(s); it.step_norm = (double)step_norm; }
+    const Real step_size_tolerance = (Real)opt->parameter_tolerance * (x_norm + (Real)opt->parameter_tolerance);
+    if (step_norm <= step_size_tolerance) {
+      sum->termination_type = 0;
+      std::snprintf(sum->message, sizeof(sum->message), "Parameter tolerance reached. Relative step_norm: %e <= %e.", (double)(step_norm / (x_norm + (Real)opt->parameter_tolerance)), opt->parameter_tolerance);
+      it.cost = (double)x_cost; it.trust_region_radius = radius;
+      done = true; break;
+    }
+    // FunctionToleranceReached
+    const Real cost_change = x_cost - candidate_cost;
+    it.cost_change = (double)cost_change;
+    const Real absolute_function_tolerance = (Real)opt->function_tolerance * x_cost;
+    if (std::fabs(cost_change) <= absolute_function_tolerance) {
+      sum->termination_type = 0;
+      std::snprintf(sum->message, sizeof(sum->message), "Function tolerance reached. |cost_change|/cost: %e <= %e", (double)(std::fabs(cost_change) / x_cost), opt->function_tolerance);
+      it.cost = (double)x_cost; it.trust_region_radius = radius;
+      done = true; break;
+    }
+    // IsStepSuccessful (monotonic TrustRegionStepEvaluator::StepQuality)
+    const Real relative_decrease = (x_cost - candidate_cost) / model_cost_change;
+    it.relative_decrease = (double)relative_decrease;
+    if (relative_decrease > (Real)opt->min_relative_decrease) {
+      // HandleSuccessfulStep
+      x = candidate_x; x_norm = g.programNorm(x);
+      if (!eval_grad_jac()) {
+        sum->termination_type = 2; std::snprintf(sum->message, sizeof(sum->message), "Residual and Jacobian evaluation failed.");
+        done = true; break;
+      }
+      it.step_is_successful = 1;
+      // LevenbergMarquardtStrategy::StepAccepted
+      radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * it.relative_decrease - 1.0, 3));
+      radius = std::min(opt->max_trust_region_radius, radius);
+      decrease_factor = 2.0; reuse_diagonal = false;
+    } else {
+      // HandleUnsuccessfulStep
+      it.step_is_successful = 0;
+      step_rejected();
+      it.cost = (double)candidate_cost + sum->fixed_cost;
+    }
+  }
+  if (done && sum->termination_type == 0 && n_it <= it.iteration) {
+    // convergence detected inside the loop body: Ceres returns without pushing this iteration's summary
+  }
+  g.unpack(best_x, p->cams, p->xyz);
+  sum->final_cost = (double)minimum_cost + sum->fixed_cost;
+  sum->num_iterations = std::min(n_it, max_its_out);
+  sum->num_jacobian_passes = g.jac_passes;
+  sum->num_cost_passes = g.cost_passes;
+  sum->total_time_in_seconds = Now() - t_start;
+  return sum->termination_type;
+}
+
 
 // =============================================================================================
 // C interface
@@ -741,7 +966,7 @@ void oracle_default_options(oracle_options* o) {
   o->max_num_consecutive_invalid_steps = 5;
   o->jacobi_scaling = 1;
   o->use_autodiff = 1;
-  o->reserved = 0;
+  o->extended_precision = 0;
 }
 
 void oracle_imgradient_f32(const float* src, int rows, int cols, float* Ix, float* Iy) {
@@ -978,7 +1203,7 @@ void oracle_block_products(const oracle_problem* p, int use_autodiff, int num_th
     for (int i = 0; i < P; ++i) s += r[i] * r[i];
     if (p->huber > 0.0) {
       double rho[3];
-      HuberEvaluate(p->huber, s, rho);
+      HuberEvaluate<double>(p->huber, s, rho);
       const double k = std::sqrt(rho[1]);
       for (double& v : jc) v *= k;
       for (double& v : jp) v *= k;
@@ -997,192 +1222,13 @@ void oracle_block_products(const oracle_problem* p, int use_autodiff, int num_th
 }
 
 int oracle_solve(oracle_problem* p, const oracle_options* opt, oracle_summary* sum, oracle_iteration* its, int max_its_out) {
-  // ceres::Solve (photobundle.cc:829) -> TrustRegionMinimizer::Minimize (Ceres >= 1.12 control flow, SURVEY 8c)
-  const double t_start = Now();
-  Program g; g.init(p, opt->use_autodiff != 0, opt->num_threads);
-  std::memset(sum, 0, sizeof(*sum));
-  sum->num_residual_blocks = g.n_obs;
-  sum->num_residuals = g.n_obs * g.P;
-  sum->fixed_cost = 0.0;  // every block has a free point (SURVEY 8c "Constant camera 0")
-  sum->termination_type = 1;
-  std::snprintf(sum->message, sizeof(sum->message), "Maximum number of iterations reached.");
-
-  std::vector<double> x, candidate_x, gradient, scale, diagonal, D, step, delta, model_residuals;
-  g.pack(p->cams, p->xyz, x);
-  double x_cost = 0.0, candidate_cost = 0.0, x_norm = g.programNorm(x);
-  double radius = opt->initial_trust_region_radius, decrease_factor = 2.0;
-  bool reuse_diagonal = false;
-  int num_consecutive_invalid_steps = 0;
-  int n_it = 0;
-  double minimum_cost;
-  std::vector<double> best_x = x;
-
-  oracle_iteration it;
-  std::memset(&it, 0, sizeof(it));
-  auto push_iteration = [&](const oracle_iteration& s) {
-    if (n_it < max_its_out && its) its[n_it] = s;
-    ++n_it;
-  };
-  auto eval_grad_jac = [&]() -> bool {
-    // TrustRegionMinimizer::EvaluateGradientAndJacobian
-    if (!g.evaluate(x, &x_cost, true, &gradient)) return false;
-    it.cost = x_cost + sum->fixed_cost;
-    if (opt->jacobi_scaling) {
-      if (it.iteration == 0) {
-        g.squared_column_norm(scale);
-        for (double& s : scale) s = 1.0 / (1.0 + std::sqrt(s));
-      }
-      g.scale_columns(scale);
-    } else if (scale.empty()) scale.assign(g.n_params, 1.0);
-    it.gradient_max_norm = MaxAbs(gradient);   // Euclidean Plus: |x - (x - g)|_inf
-    it.gradient_norm = Norm(gradient);
-    return true;
-  };
-
-  // IterationZero
-  double t_iter = Now();
-  it.iteration = 0; it.eta = 1e-1;
-  if (!eval_grad_jac()) {
-    sum->termination_type = 2;
-    std::snprintf(sum->message, sizeof(sum->message), "Initial residual and Jacobian evaluation failed.");
-    sum->total_time_in_seconds = Now() - t_start;
-    return 2;
-  }
-  sum->initial_cost = x_cost + sum->fixed_cost;
-  minimum_cost = x_cost;
-  it.step_is_valid = 1; it.step_is_successful = 1;
-
-  bool done = false;
-  auto finalize = [&]() -> bool {
-    // FinalizeIterationAndCheckIfMinimizerCanContinue
-    if (it.step_is_successful) {
-      ++sum->num_successful_steps;
-      if (x_cost < minimum_cost || it.iteration == 0) { minimum_cost = x_cost; best_x = x; it.step_is_nonmonotonic = 0; }
-      else it.step_is_nonmonotonic = 1;
-    } else ++sum->num_unsuccessful_steps;
-    it.trust_region_radius = radius;
-    const double now = Now();
-    it.iteration_time_in_seconds = now - t_iter;
-    it.cumulative_time_in_seconds = now - t_start;
-    push_iteration(it);
-    if (it.iteration >= opt->max_num_iterations) {
-      sum->termination_type = 1; std::snprintf(sum->message, sizeof(sum->message), "Maximum number of iterations reached. Number of iterations: %d.", it.iteration); return false; }
-    if (it.step_is_successful && it.gradient_max_norm <= opt->gradient_tolerance) {
-      sum->termination_type = 0; std::snprintf(sum->message, sizeof(sum->message), "Gradient tolerance reached. Gradient max norm: %e <= %e", it.gradient_max_norm, opt->gradient_tolerance); return false; }
-    if (radius <= opt->min_trust_region_radius) {
-      sum->termination_type = 0; std::snprintf(sum->message, sizeof(sum->message), "Minimum trust region radius reached. Trust region radius: %e <= %e", radius, opt->min_trust_region_radius); return false; }
-    return true;
-  };
-  auto step_rejected = [&]() { radius = radius / decrease_factor; decrease_factor *= 2.0; reuse_diagonal = true; };
-
-  while (!done && finalize()) {
-    t_iter = Now();
-    const int iteration = it.iteration + 1;
-    const double prev_gmax = it.gradient_max_norm, prev_gnorm = it.gradient_norm;
-    std::memset(&it, 0, sizeof(it));
-    it.iteration = iteration; it.eta = 1e-1;
-    it.gradient_max_norm = prev_gmax; it.gradient_norm = prev_gnorm;
-
-    // ComputeTrustRegionStep -> LevenbergMarquardtStrategy::ComputeStep
-    const double t_solve = Now();
-    if (!reuse_diagonal) {
-      g.squared_column_norm(diagonal);
-      for (double& d : diagonal) d = std::min(std::max(d, opt->min_lm_diagonal), opt->max_lm_diagonal);
-    }
-    D.resize(g.n_params);
-    for (int i = 0; i < g.n_params; ++i) D[i] = std::sqrt(diagonal[i] / radius);
-    bool solved = SchurSolve(g, D, step);
-    reuse_diagonal = true;
-    bool step_is_valid = false;
-    double model_cost_change = 0.0;
-    if (solved) {
-      for (double& s : step) s *= -1.0;
-      // model_cost_change = -(J step)^T (r + J step / 2)
-      g.right_multiply(step, model_residuals);
-      double acc = 0.0;
-      for (size_t i = 0; i < model_residuals.size(); ++i) acc += model_residuals[i] * (g.r[i] + model_residuals[i] / 2.0);
-      model_cost_change = -acc;
-      step_is_valid = model_cost_change > 0.0;
-    }
-    it.step_solver_time_in_seconds = Now() - t_solve;
-    it.model_cost_change = model_cost_change;
-    it.linear_solver_iterations = 1;
-    if (!step_is_valid) {
-      // HandleInvalidStep
-      ++num_consecutive_invalid_steps;
-      if (num_consecutive_invalid_steps >= opt->max_num_consecutive_invalid_steps) {
-        sum->termination_type = 2;
-        std::snprintf(sum->message, sizeof(sum->message), "Number of consecutive invalid steps more than Solver::Options::max_num_consecutive_invalid_steps: %d", opt->max_num_consecutive_invalid_steps);
-        it.cost = x_cost + sum->fixed_cost; it.trust_region_radius = radius;
-        push_iteration(it);
-        done = true; break;
-      }
-      step_rejected();  // LevenbergMarquardtStrategy::StepIsInvalid == StepRejected(0)
-      it.cost = x_cost + sum->fixed_cost;
-      it.cost_change = 0.0; it.step_norm = 0.0; it.relative_decrease = 0.0;
-      it.step_is_valid = 0; it.step_is_successful = 0;
-      continue;
-    }
-    it.step_is_valid = 1;
-    num_consecutive_invalid_steps = 0;
-    delta.resize(g.n_params);
-    for (int i = 0; i < g.n_params; ++i) delta[i] = step[i] * scale[i];
-
-    // ComputeCandidatePointAndEvaluateCost
-    candidate_x.resize(g.n_params);
-    for (int i = 0; i < g.n_params; ++i) candidate_x[i] = x[i] + delta[i];
-    if (!g.evaluate(candidate_x, &candidate_cost, false, nullptr)) candidate_cost = std::numeric_limits<double>::max();
-    it.candidate_cost = candidate_cost;
-
-    // ParameterToleranceReached
-    { double s = 0; for (int i = 0; i < g.n_params; ++i) { const double d = x[i] - candidate_x[i]; s += d * d; } it.step_norm = std::sqrt(s); }
-    const double step_size_tolerance = opt->parameter_tolerance * (x_norm + opt->parameter_tolerance);
-    if (it.step_norm <= step_size_tolerance) {
-      sum->termination_type = 0;
-      std::snprintf(sum->message, sizeof(sum->message), "Parameter tolerance reached. Relative step_norm: %e <= %e.", it.step_norm / (x_norm + opt->parameter_tolerance), opt->parameter_tolerance);
-      it.cost = x_cost; it.trust_region_radius = radius;
-      done = true; break;
-    }
-    // FunctionToleranceReached
-    it.cost_change = x_cost - candidate_cost;
-    const double absolute_function_tolerance = opt->function_tolerance * x_cost;
-    if (std::fabs(it.cost_change) <= absolute_function_tolerance) {
-      sum->termination_type = 0;
-      std::snprintf(sum->message, sizeof(sum->message), "Function tolerance reached. |cost_change|/cost: %e <= %e", std::fabs(it.cost_change) / x_cost, opt->function_tolerance);
-      it.cost = x_cost; it.trust_region_radius = radius;
-      done = true; break;
-    }
-    // IsStepSuccessful (monotonic TrustRegionStepEvaluator::StepQuality)
-    it.relative_decrease = (x_cost - candidate_cost) / model_cost_change;
-    if (it.relative_decrease > opt->min_relative_decrease) {
-      // HandleSuccessfulStep
-      x = candidate_x; x_norm = g.programNorm(x);
-      if (!eval_grad_jac()) {
-        sum->termination_type = 2; std::snprintf(sum->message, sizeof(sum->message), "Residual and Jacobian evaluation failed.");
-        done = true; break;
-      }
-      it.step_is_successful = 1;
-      // LevenbergMarquardtStrategy::StepAccepted
-      radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * it.relative_decrease - 1.0, 3));
-      radius = std::min(opt->max_trust_region_radius, radius);
-      decrease_factor = 2.0; reuse_diagonal = false;
-    } else {
-      // HandleUnsuccessfulStep
-      it.step_is_successful = 0;
-      step_rejected();
-      it.cost = candidate_cost + sum->fixed_cost;
-    }
-  }
-  if (done && sum->termination_type == 0 && n_it <= it.iteration) {
-    // convergence detected inside the loop body: Ceres returns without pushing this iteration's summary
-  }
-  g.unpack(best_x, p->cams, p->xyz);
-  sum->final_cost = minimum_cost + sum->fixed_cost;
-  sum->num_iterations = std::min(n_it, max_its_out);
-  sum->num_jacobian_passes = g.jac_passes;
-  sum->num_cost_passes = g.cost_passes;
-  sum->total_time_in_seconds = Now() - t_start;
-  return sum->termination_type;
+  // opt->extended_precision: the REFEREE -- the same program with every accumulation (block norms, cost, gradient,
+  // column norms, Schur elimination, Cholesky, back-substitution, model cost change, step norms) in x87 extended
+  // precision (64-bit significand: rounding noise 2^-11 of the double program's); residual blocks and their Jacobian
+  // rows are still evaluated in double with the fp32 sampler (they define the function).  Used by the tests to tell
+  // rounding noise from drift (tests/test_gpu_fullsize.py).
+  if (opt->extended_precision) return SolveT<long double>(p, opt, sum, its, max_its_out);
+  return SolveT<double>(p, opt, sum, its, max_its_out);
 }
 
 }  // extern "C"

@@ -63,7 +63,7 @@ typedef struct oracle_options {
   int32_t max_num_consecutive_invalid_steps; /* 5 */
   int32_t jacobi_scaling;          /* 1 */
   int32_t use_autodiff;            /* 1: 9-wide dual numbers (reference path); 0: analytic J (faster CPU line) */
-  int32_t reserved;                /* (a Ceres <= 1.11 ordering switch was planned and dropped: DESIGN.md, oracle section) */
+  int32_t extended_precision;      /* 1: the REFEREE -- every accumulation / the linear algebra in x87 extended precision (long double) */
 } oracle_options;
 
 /* ceres::IterationSummary subset (ceres_cereal.h:13-30). */

@@ -56,13 +56,16 @@ static void dumpResult(const std::string& fn, int frame, const PhotometricBundle
 int main(int argc, char** argv) {
   signal(SIGINT, sigHandler);
   // -r (not in the reference's driver): text dump of every Result the class hands back (reference photobundle.cc:857-875)
+  // -p (not in the reference's driver): poses with round-trip precision instead of the reference's 6 significant digits
   std::string config = "../config/kitti_stereo.cfg", output = "refined_poses.txt", results;
+  bool full_precision = false;
   for (int i = 1; i < argc; ++i) {
     const std::string a = argv[i];
     if ((a == "-c" || a == "--config") && i + 1 < argc) config = argv[++i];
     else if ((a == "-o" || a == "--output") && i + 1 < argc) output = argv[++i];
     else if ((a == "-r" || a == "--results") && i + 1 < argc) results = argv[++i];
-    else { std::fprintf(stderr, "usage: %s [-c config] [-o output] [-r result-dump]\n", argv[0]); return 1; }
+    else if (a == "-p" || a == "--full-precision") full_precision = true;
+    else { std::fprintf(stderr, "usage: %s [-c config] [-o output] [-r result-dump] [-p]\n", argv[0]); return 1; }
   }
   try {
     utils::ConfigFile cf(config);
@@ -106,7 +109,8 @@ int main(int argc, char** argv) {
       if (!results.empty() && result.initialCost >= 0.0) dumpResult(results, f_i, result);
     }
     std::fprintf(stderr, "Writing refined poses to %s\n", output.c_str());
-    writePosesKittiFormat(output, result.poses);
+    if (full_precision) writePosesKittiFormatFullPrecision(output, result.poses);
+    else writePosesKittiFormat(output, result.poses);   // reference format (src/pose_utils.cc:43-59)
   } catch (const std::exception& ex) {
     std::fprintf(stderr, "error: %s\n", ex.what());
     return 1;

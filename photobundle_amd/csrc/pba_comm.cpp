@@ -15,6 +15,7 @@ struct Rccl {
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   std::string err;
@@ -26,6 +27,7 @@ struct Rccl {
     GetUniqueId = reinterpret_cast<decltype(GetUniqueId)>(dlsym(lib, "ncclGetUniqueId"));
     CommInitRank = reinterpret_cast<decltype(CommInitRank)>(dlsym(lib, "ncclCommInitRank"));
     CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+    CommAbort = reinterpret_cast<decltype(CommAbort)>(dlsym(lib, "ncclCommAbort"));   // optional
     AllReduce = reinterpret_cast<decltype(AllReduce)>(dlsym(lib, "ncclAllReduce"));
     GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
     if (!GetUniqueId || !CommInitRank || !CommDestroy || !AllReduce || !GetErrorString) { err = "librccl misses a required symbol"; return false; }
@@ -108,8 +110,13 @@ int Comm::allreduce_host(double* h, int n, int op) {
   return 1;
 }
 
-void Comm::shutdown() {
-  if (kind == 1 && nccl_comm) { rccl().CommDestroy(static_cast<ncclComm_t>(nccl_comm)); nccl_comm = nullptr; }
+void Comm::shutdown(bool abort) {
+  if (kind == 1 && nccl_comm) {
+    // a communicator with a collective that will never complete must be aborted: ncclCommDestroy would wait for it
+    if (abort && rccl().CommAbort) rccl().CommAbort(static_cast<ncclComm_t>(nccl_comm));
+    else if (!abort) rccl().CommDestroy(static_cast<ncclComm_t>(nccl_comm));
+    nccl_comm = nullptr;
+  }
   if (h_stage) { (void)hipHostFree(h_stage); h_stage = nullptr; stage_cap = 0; }
   if (d_small) { (void)hipFree(d_small); d_small = nullptr; }
   kind = 0; world = 1; rank = 0; fn = nullptr; ctx = nullptr; force = false;

@@ -36,7 +36,8 @@ struct Comm {
   // in-place all-reduce of n (<= 64) host doubles
   int allreduce_host(double* h, int n, int op);
   bool multi() const { return world > 1 || (force && kind != 0); }
-  void shutdown();
+  // abort: the communicator holds a collective that never completed (ncclCommAbort instead of ncclCommDestroy)
+  void shutdown(bool abort = false);
 };
 
 }  // namespace pba

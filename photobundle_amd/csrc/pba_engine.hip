@@ -99,6 +99,8 @@ struct pba_engine {
   int async_cur = 0;                // parity assumed at enqueue time
   bool use_async = true;            // PBA_ASYNC=0 disables
   double wait_timeout_s = 120.0;    // PBA_WAIT_TIMEOUT_S: watchdog of the publication waits
+  bool poisoned = false;            // a publication wait timed out: the stream still holds the stalled work, every later
+                                    // call fails fast and pba_destroy neither waits for the stream nor for the collective
   unsigned long long* d_dbg = nullptr;   // PBA_SCHUR_TIMING diagnostics
   int dbg_left = 0;
   int n_pairs = 0, part_stride = 0;
@@ -134,6 +136,10 @@ int fail(pba_engine* e, int code, const char* fmt, ...) {
     if (_r != hipSuccess) return fail((e), PBA_ERR_HIP, "%s: %s", #call, hipGetErrorString(_r)); \
   } while (0)
 
+// A timed-out publication wait leaves the stream stalled: every later call returns at once instead of hanging on it.
+#define PBA_NOT_POISONED(e) \
+  do { if ((e)->poisoned) return fail((e), PBA_ERR_STATE, "the engine is unusable after a timed-out step (stalled stream / collective); destroy it"); } while (0)
+
 // Grow-only device buffers: a sliding-window caller re-submits a problem of similar size for every frame, and a
 // hipFree + hipMalloc pair per buffer per frame is pure overhead.  Contents are undefined after the call (every user
 // overwrites or uploads the whole buffer).
@@ -154,6 +160,7 @@ void dev_free(T** p) { if (*p) { (void)hipFree(*p); *p = nullptr; } }
 
 // Call-order / consistency check before any pass touches the device (include/pba.h: PBA_ERR_STATE).
 int check_ready(pba_engine* e, const char* who) {
+  if (e->poisoned) return fail(e, PBA_ERR_STATE, "%s: the engine is unusable after a timed-out step (stalled stream / collective); destroy it", who);
   if (!e->have_problem || !e->have_cams)
     return fail(e, PBA_ERR_STATE, "call order violated: %s before set_problem/set_cameras", who);
   for (int s = 0; s < kMaxFrames; ++s) {
@@ -442,6 +449,13 @@ int pba_create(const pba_config* cfg, pba_engine** out) {
 void pba_destroy(pba_engine* e) {
   if (!e) return;
   (void)hipSetDevice(e->cfg.device);
+  if (e->poisoned) {
+    // the stream holds work that will never finish (pba_step / pba_solve timed out): waiting for it, freeing memory it
+    // may still touch or destroying its stream would hang or fault; abort the communicator and leak the device side
+    e->comm.shutdown(true);
+    delete e;
+    return;
+  }
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   e->comm.shutdown();
   dev_free(&e->d_frames); dev_free(&e->d_img_stage); dev_free(&e->d_frames_mc); dev_free(&e->d_ch_stage);
@@ -468,6 +482,7 @@ int pba_set_frame_channels_f32(pba_engine* e, int slot, int32_t n_channels, cons
   if (!e || !channels || slot < 0 || slot >= e->cfg.max_frames) return PBA_ERR_INVALID;
   if (e->channels <= 1 || n_channels != e->channels)
     return fail(e, PBA_ERR_INVALID, "pba_set_frame_channels_f32: the engine was created for %d channel(s), got %d", e->channels, n_channels);
+  PBA_NOT_POISONED(e);
   HIP_TRY(e, hipSetDevice(e->cfg.device));
   const size_t npix = (size_t)e->cfg.rows * e->cfg.cols;
   dim3 grid((e->cfg.cols + 255) / 256, e->cfg.rows);
@@ -486,6 +501,7 @@ int pba_set_frame_channels_f32(pba_engine* e, int slot, int32_t n_channels, cons
 int pba_set_frame_u8(pba_engine* e, int slot, const uint8_t* image) {
   if (!e || !image || slot < 0 || slot >= e->cfg.max_frames) return PBA_ERR_INVALID;
   if (e->channels > 1) return fail(e, PBA_ERR_INVALID, "pba_set_frame_u8: the engine was created for %d channels (pba_set_frame_channels_f32)", e->channels);
+  PBA_NOT_POISONED(e);
   HIP_TRY(e, hipSetDevice(e->cfg.device));
   const size_t npix = (size_t)e->cfg.rows * e->cfg.cols;
   // The caller's buffer is only borrowed for the call: it is copied into a pinned staging buffer here, and the upload +
@@ -507,6 +523,7 @@ int pba_set_frame_u8(pba_engine* e, int slot, const uint8_t* image) {
 int pba_get_frame_planes(pba_engine* e, int slot, float* I, float* Gx, float* Gy) {
   if (!e || slot < 0 || slot >= e->cfg.max_frames || !I || !Gx || !Gy) return PBA_ERR_INVALID;
   if (e->channels > 1) return fail(e, PBA_ERR_INVALID, "pba_get_frame_planes reads the single-channel planes");
+  PBA_NOT_POISONED(e);
   HIP_TRY(e, hipSetDevice(e->cfg.device));
   const size_t npix = (size_t)e->cfg.rows * e->cfg.cols;
   float* d = nullptr;
@@ -525,6 +542,7 @@ int pba_get_frame_planes(pba_engine* e, int slot, float* I, float* Gx, float* Gy
 int pba_set_problem(pba_engine* e, int32_t n_points, const double* xyz, const double* desc, int32_t n_obs,
                     const int32_t* obs_point, const int32_t* obs_slot, const double* weights) {
   if (!e || n_points <= 0 || n_obs <= 0 || !xyz || !desc || !obs_point || !obs_slot || !weights) return PBA_ERR_INVALID;
+  PBA_NOT_POISONED(e);
   HIP_TRY(e, hipSetDevice(e->cfg.device));
   const int P = (2 * e->cfg.radius + 1) * (2 * e->cfg.radius + 1);     // pixels of one patch (weights)
   const int PD = P * e->channels;                                       // descriptor entries per point
@@ -625,6 +643,7 @@ int pba_set_problem(pba_engine* e, int32_t n_points, const double* xyz, const do
 
 int pba_set_cameras(pba_engine* e, const double* cams6, int32_t n_frames, int32_t fixed_slot) {
   if (!e || !cams6 || n_frames < 2 || n_frames > e->cfg.max_frames || fixed_slot >= n_frames) return PBA_ERR_INVALID;
+  PBA_NOT_POISONED(e);
   HIP_TRY(e, hipSetDevice(e->cfg.device));
   e->n_frames = n_frames;
   e->fixed_slot = fixed_slot < 0 ? -1 : fixed_slot;
@@ -647,6 +666,7 @@ int pba_set_cameras(pba_engine* e, const double* cams6, int32_t n_frames, int32_
 }
 
 static int fetch_state(pba_engine* e, double* cams6, double* xyz) {
+  PBA_NOT_POISONED(e);
   HIP_TRY(e, hipSetDevice(e->cfg.device));
   // through the engine's host-mapped pinned buffer, written by a kernel: the runtime's copy call blocks for 8 ms the
   // first time a process moves a few hundred KB device -> host (seen in the drop-in class, pinned or pageable
@@ -664,6 +684,7 @@ static int fetch_state(pba_engine* e, double* cams6, double* xyz) {
 
 int pba_get_state(pba_engine* e, double* cams6, double* xyz) {
   if (!e) return PBA_ERR_INVALID;
+  if (e->poisoned) return fail(e, PBA_ERR_STATE, "pba_get_state: the engine is unusable after a timed-out step; destroy it");
   if (!e->have_problem || !e->have_cams) return fail(e, PBA_ERR_STATE, "call order violated: pba_get_state before set_problem/set_cameras");
   return fetch_state(e, cams6, xyz);
 }
@@ -671,6 +692,7 @@ int pba_get_state(pba_engine* e, double* cams6, double* xyz) {
 int pba_set_inverse_depth(pba_engine* e, const double* rays6, const double* rho) {
   if (!e || !rays6 || !rho) return PBA_ERR_INVALID;
   if (!e->have_problem) return fail(e, PBA_ERR_STATE, "call order violated: pba_set_inverse_depth before pba_set_problem");
+  PBA_NOT_POISONED(e);
   HIP_TRY(e, hipSetDevice(e->cfg.device));
   const int n = e->n_points;
   std::vector<double> prm((size_t)3 * n, 0.0);
@@ -693,6 +715,7 @@ int pba_set_inverse_depth(pba_engine* e, const double* rays6, const double* rho)
 int pba_get_points_world(pba_engine* e, double* xyz) {
   if (!e || !xyz) return PBA_ERR_INVALID;
   if (!e->have_problem) return fail(e, PBA_ERR_STATE, "call order violated: pba_get_points_world before pba_set_problem");
+  PBA_NOT_POISONED(e);
   HIP_TRY(e, hipSetDevice(e->cfg.device));
   { const int rc = fetch_state(e, nullptr, xyz); if (rc) return rc; }
   if (e->inverse_depth) {
@@ -708,6 +731,7 @@ int pba_get_points_world(pba_engine* e, double* xyz) {
 int pba_linearize(pba_engine* e, double* cost) {
   if (!e) return PBA_ERR_INVALID;
   { const int rc0 = check_ready(e, "pba_linearize"); if (rc0) return rc0; }
+  PBA_NOT_POISONED(e);
   HIP_TRY(e, hipSetDevice(e->cfg.device));
   if (!e->lin_valid[e->cur]) {
     SampleParams sp = make_sample_params(e, e->cur);
@@ -744,6 +768,7 @@ int pba_internal_step(pba_engine* e, double radius, int32_t init_scale, const pb
                       int grad_only) {
   if (!e || !o || !out || !(radius > 0.0)) return PBA_ERR_INVALID;
   if (!e->have_lin) return fail(e, PBA_ERR_STATE, "call order violated: pba_step before pba_linearize");
+  PBA_NOT_POISONED(e);
   HIP_TRY(e, hipSetDevice(e->cfg.device));
   const int cur = e->cur, cand = 1 - e->cur;
   const int n = 6 * e->n_free;
@@ -925,8 +950,10 @@ int pba_internal_step(pba_engine* e, double radius, int32_t init_scale, const pb
         if (q == hipSuccess && *h_seq != seq) return fail(e, PBA_ERR_HIP, "step finished without publishing its scalars");
         const double t = wall_seconds();
         if (t_first < 0.0) t_first = t;
-        else if (t - t_first > e->wait_timeout_s)
+        else if (t - t_first > e->wait_timeout_s) {
+          e->poisoned = true;
           return fail(e, multi ? PBA_ERR_COMM : PBA_ERR_HIP, "timed out after %.0f s waiting for step %llu", e->wait_timeout_s, seq);
+        }
       }
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
@@ -959,6 +986,7 @@ int pba_accept(pba_engine* e) {
 int pba_get_reduced_system(pba_engine* e, double* S, double* rhs, int32_t* n_out) {
   if (!e || !n_out) return PBA_ERR_INVALID;
   if (!(e->cfg.flags & 1)) return fail(e, PBA_ERR_STATE, "call order violated: pba_get_reduced_system needs pba_config.flags bit 0 (keep reduced system)");
+  PBA_NOT_POISONED(e);
   HIP_TRY(e, hipSetDevice(e->cfg.device));
   const int n = 6 * e->n_free;
   *n_out = n;
@@ -971,6 +999,7 @@ int pba_get_reduced_system(pba_engine* e, double* S, double* rhs, int32_t* n_out
 int pba_get_obs_records(pba_engine* e, double* rec6) {
   if (!e || !rec6) return PBA_ERR_INVALID;
   if (!e->have_problem) return fail(e, PBA_ERR_STATE, "no problem");
+  PBA_NOT_POISONED(e);
   HIP_TRY(e, hipSetDevice(e->cfg.device));
   std::vector<double> tmp((size_t)6 * e->rec_stride);
   HIP_TRY(e, hipMemcpyAsync(tmp.data(), e->d_rec[e->cur], sizeof(double) * tmp.size(), hipMemcpyDeviceToHost, e->stream));
@@ -984,6 +1013,7 @@ int pba_comm_unique_id(void* id128) { return Comm::unique_id(id128) ? PBA_ERR_CO
 
 int pba_comm_init_rccl(pba_engine* e, const void* id128, int32_t rank, int32_t world) {
   if (!e || !id128 || world < 1 || rank < 0 || rank >= world) return PBA_ERR_INVALID;
+  PBA_NOT_POISONED(e);
   HIP_TRY(e, hipSetDevice(e->cfg.device));
   if (e->comm.init_rccl(id128, rank, world)) return fail(e, PBA_ERR_COMM, "%s", e->comm.err.c_str());
   return PBA_OK;
@@ -991,6 +1021,7 @@ int pba_comm_init_rccl(pba_engine* e, const void* id128, int32_t rank, int32_t w
 
 int pba_comm_init_callback(pba_engine* e, pba_allreduce_fn fn, void* ctx, int32_t rank, int32_t world) {
   if (!e || !fn || world < 1 || rank < 0 || rank >= world) return PBA_ERR_INVALID;
+  PBA_NOT_POISONED(e);
   HIP_TRY(e, hipSetDevice(e->cfg.device));
   if (e->comm.init_callback(fn, ctx, rank, world)) return fail(e, PBA_ERR_COMM, "%s", e->comm.err.c_str());
   return PBA_OK;
@@ -1029,6 +1060,7 @@ int pba_internal_ready(pba_engine* e) { return check_ready(e, "pba_solve"); }
 
 int pba_internal_async_begin(pba_engine* e, const pba_solver_options* o) {
   { const int rc0 = check_ready(e, "pba_solve"); if (rc0) return rc0; }
+  PBA_NOT_POISONED(e);
   HIP_TRY(e, hipSetDevice(e->cfg.device));
   LmState st;
   std::memset(&st, 0, sizeof(st));
@@ -1163,9 +1195,11 @@ int pba_internal_async_wait(pba_engine* e, unsigned long long seq) {
       // otherwise spin forever: bounded by PBA_WAIT_TIMEOUT_S (default 120 s) of wall-clock per awaited step
       const double t = wall_seconds();
       if (t_first < 0.0) t_first = t;
-      else if (t - t_first > e->wait_timeout_s)
+      else if (t - t_first > e->wait_timeout_s) {
+        e->poisoned = true;
         return fail(e, e->comm.multi() ? PBA_ERR_COMM : PBA_ERR_HIP, "timed out after %.0f s waiting for step %llu (last published %llu)",
                     e->wait_timeout_s, seq, (unsigned long long)*h_seq);
+      }
     }
   }
   __atomic_thread_fence(__ATOMIC_ACQUIRE);

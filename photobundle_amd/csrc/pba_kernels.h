@@ -813,6 +813,9 @@ void k_sample(SampleParams p_in) {
   }
 
   if (rays && active) {          // inverse-depth variant: parameters -> world point
+    // a candidate with rho <= 0 (a step through the camera centre) mirrors the point behind the ray origin but stays
+    // finite: flagged as an evaluation failure so that the trust-region loop rejects the step
+    if (!(X[0] > 0.0)) atomicOr(&s_fail, 1);
     double Xw[3], qd[3];
     point_world(rays, pt, X, Xw, qd);
     X[0] = Xw[0]; X[1] = Xw[1]; X[2] = Xw[2];

@@ -469,6 +469,29 @@ void PhotometricBundleAdjustment::optimize(Result* result) {
   }
   std::fprintf(stderr, "Using %d points (%d residual blocks) [id start %d]\n", (int)selected.size(), (int)obs_point.size(), (int)frame_id_start);
 
+  // Test hook (PBA_DUMP_WINDOWS=<dir>): the problem exactly as it is handed to the engine, so that a test can solve the
+  // SAME window independently on the CPU (tests/test_gpu_configs0.py).  Not part of the reference.
+  if (const char* dump_dir = std::getenv("PBA_DUMP_WINDOWS")) {
+    char fn[1024];
+    std::snprintf(fn, sizeof(fn), "%s/window_%06u.bin", dump_dir, (unsigned)frame_id_end);
+    if (std::FILE* f = std::fopen(fn, "wb")) {
+      const Options& op = *_options_ptr;
+      const int32_t hdr[12] = {window, (int32_t)selected.size(), (int32_t)obs_point.size(), P, op.patchRadius,
+                               (int32_t)(frame_id_start % window), (int32_t)frame_id_start, (int32_t)frame_id_end,
+                               op.maxNumPoints, (int32_t)op.descriptorType, op.doGaussianWeighting ? 1 : 0, (int32_t)patch_weights.size()};
+      const double dopt[4] = {op.minScore, op.robustThreshold, op.minValidDepth, op.maxValidDepth};
+      std::fwrite(hdr, sizeof(hdr), 1, f);
+      std::fwrite(dopt, sizeof(dopt), 1, f);
+      std::fwrite(cams.data(), sizeof(double), cams.size(), f);
+      std::fwrite(xyz.data(), sizeof(double), xyz.size(), f);
+      std::fwrite(desc.data(), sizeof(double), desc.size(), f);
+      std::fwrite(obs_point.data(), sizeof(int32_t), obs_point.size(), f);
+      std::fwrite(obs_slot.data(), sizeof(int32_t), obs_slot.size(), f);
+      std::fwrite(patch_weights.data(), sizeof(double), patch_weights.size(), f);
+      std::fclose(f);
+    }
+  }
+
   lap_o(0);
   pba_solver_summary summary;
   std::memset(&summary, 0, sizeof(summary));
@@ -477,11 +500,16 @@ void PhotometricBundleAdjustment::optimize(Result* result) {
     check(_engine, pba_set_problem(_engine, (int32_t)selected.size(), xyz.data(), desc.data(), (int32_t)obs_point.size(),
                                   obs_point.data(), obs_slot.data(), patch_weights.data()), "pba_set_problem");
     lap_o(1);
-    // "set the first camera constant" only if it is part of the problem (reference :809-815, HasParameterBlock)
+    // "set the first camera constant" only if it is part of the problem (reference :809-815, HasParameterBlock).  When it
+    // is not, the reference only warns: no camera is constant and the first one is not a parameter block of the program.
+    // The engine gets the first slot as its constant slot in BOTH cases: a constant camera without residual blocks is the
+    // same problem as a camera that is absent from it (it has no columns in the reduced system, and the engine's
+    // column-is-live flags keep it out of |x|), and the number of free cameras stays <= window - 1 -- with -1 here a
+    // 16-frame window had 16 free cameras = 136 pair blocks, more than the Schur tile holds (PBA_ERR_INVALID).
     const int32_t first_slot = (int32_t)(frame_id_start % window);
     const bool first_in_bundle = std::find(obs_slot.begin(), obs_slot.end(), first_slot) != obs_slot.end();
     if (!first_in_bundle) std::fprintf(stderr, "first camera is not in bundle\n");
-    check(_engine, pba_set_cameras(_engine, cams.data(), window, first_in_bundle ? first_slot : -1), "pba_set_cameras");
+    check(_engine, pba_set_cameras(_engine, cams.data(), window, first_slot), "pba_set_cameras");
     lap_o(2);
     pba_solver_options so;
     pba_default_solver_options(&so);     // GetSolverOptions (:738-761)

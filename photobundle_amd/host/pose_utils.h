@@ -24,7 +24,21 @@ inline EigenAlignedContainer_<Mat44> loadPosesKittiFormat(const std::string& fil
   return ret;
 }
 
+// Byte-compatible with the reference writer (src/pose_utils.cc:43-59): `ofs << T(r, c) << " "` = default ostream
+// formatting of a double (%g, 6 significant digits), a blank after EVERY number including the last, then '\n'.
 inline bool writePosesKittiFormat(const std::string& filename, const EigenAlignedContainer_<Mat44>& poses) {
+  FILE* fp = fopen(filename.c_str(), "w");
+  if (!fp) return false;
+  for (const auto& T : poses) {
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) fprintf(fp, "%g ", T(r, c));
+    fputc('\n', fp);
+  }
+  fclose(fp);
+  return true;
+}
+
+// Same layout with round-trip precision (%.17g, no trailing blank): not the reference's format; run_kitti -p.
+inline bool writePosesKittiFormatFullPrecision(const std::string& filename, const EigenAlignedContainer_<Mat44>& poses) {
   FILE* fp = fopen(filename.c_str(), "w");
   if (!fp) return false;
   for (const auto& T : poses) {

@@ -74,7 +74,7 @@ def test_run_kitti_matches_emulated_reference_pipeline(tmp_path):
                 % (max_points, window, radius))
     out = os.path.join(tmp, "refined.txt")
     dump = os.path.join(tmp, "results.txt")
-    r = subprocess.run([RUN, "-c", cfg, "-o", out, "-r", dump], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([RUN, "-c", cfg, "-o", out, "-r", dump, "-p"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     refined = np.loadtxt(out).reshape(-1, 3, 4)
     assert refined.shape[0] == n_frames
@@ -131,7 +131,7 @@ def test_pyramid_path_matches_emulation(tmp_path):
         f.write("numLevels = 2\nmaxNumPoints = %d\nslidingWindowSize = %d\npatchRadius = %d\nminScore = 0.65\nrobustThreshold = 0.05\nverbose = 0\n"
                 % (max_points, window, radius))
     out = os.path.join(tmp, "refined.txt")
-    r = subprocess.run([RUN, "-c", cfg, "-o", out], capture_output=True, text=True, timeout=900)
+    r = subprocess.run([RUN, "-c", cfg, "-o", out, "-p"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     assert r.stderr.count("Pyramid level 1") == n_frames and r.stderr.count("Pyramid level 0") == n_frames
     refined = np.loadtxt(out).reshape(-1, 3, 4)
@@ -157,7 +157,7 @@ def test_pyramid_three_levels_matches_emulation(tmp_path):
         f.write("numLevels = 3\nmaxNumPoints = %d\nslidingWindowSize = %d\npatchRadius = %d\nminScore = 0.65\nrobustThreshold = 0.05\nverbose = 0\n"
                 % (max_points, window, radius))
     out = os.path.join(tmp, "refined.txt")
-    r = subprocess.run([RUN, "-c", cfg, "-o", out], capture_output=True, text=True, timeout=1200)
+    r = subprocess.run([RUN, "-c", cfg, "-o", out, "-p"], capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stderr[-2000:]
     for lvl in range(3):
         assert r.stderr.count("Pyramid level %d" % lvl) == n_frames
@@ -204,7 +204,7 @@ def test_configs2_full_size_three_level_pyramid(tmp_path):
     for k in range(2):
         out = os.path.join(tmp, "refined%d.txt" % k)
         dump = os.path.join(tmp, "results%d.txt" % k)
-        r = subprocess.run([RUN, "-c", cfg, "-o", out, "-r", dump], capture_output=True, text=True, timeout=1000)
+        r = subprocess.run([RUN, "-c", cfg, "-o", out, "-r", dump, "-p"], capture_output=True, text=True, timeout=1000)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append((open(out).read(), open(dump).read(), r.stderr))
     assert outs[0][0] == outs[1][0] and outs[0][1] == outs[1][1]          # run-to-run determinism of the whole pipeline
@@ -246,7 +246,7 @@ def test_multichannel_descriptor_types_match_emulation(tmp_path, descriptor):
         f.write("maxNumPoints = %d\nslidingWindowSize = %d\npatchRadius = %d\nminScore = 0.65\nrobustThreshold = 0.05\nverbose = 0\n"
                 % (max_points, window, radius))
     out, dump = os.path.join(tmp, "refined.txt"), os.path.join(tmp, "results.txt")
-    r = subprocess.run([RUN, "-c", cfg, "-o", out, "-r", dump], capture_output=True, text=True, timeout=1200)
+    r = subprocess.run([RUN, "-c", cfg, "-o", out, "-r", dump, "-p"], capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stderr[-2000:]
     refined = np.loadtxt(out).reshape(-1, 3, 4)
     emu = Emulator(K, size, window, radius, max_points, min_score=0.65, huber=0.05, descriptor_type=descriptor)
