@@ -31,10 +31,10 @@ if ROOT not in sys.path:
 HBM_PEAK = 8.0e12   # bytes/s, MI355X HBM3E spec (MI355X_MICROARCH.md)
 
 
-def algorithmic_bytes(radius, n_bar):
-    """SURVEY.md 8d byte model per observation (C = 1)."""
-    F = (2 * radius + 2) ** 2
-    P = (2 * radius + 1) ** 2
+def algorithmic_bytes(radius, n_bar, channels=1):
+    """SURVEY.md 8d byte model per observation (C channels)."""
+    F = (2 * radius + 2) ** 2 * channels
+    P = (2 * radius + 1) ** 2 * channels
     sample_jac = 12 * F + 4 * P + 24 + 8          # footprint (I, Gx, Gy fp32) + descriptor + XYZ + obs index
     schur = 144 + 72.0 / n_bar                    # W_pc write + V_p, g_p per point
     b_jac = sample_jac + schur
@@ -59,6 +59,11 @@ def main():
     ap.add_argument("--visibility", choices=("dense", "causal"), default="dense")
     ap.add_argument("--precision", choices=("exact", "fp32", "bf16"), default="exact",
                     help="sampler precision (configs[4] tolerance sweep); only \"exact\" has reference parity")
+    ap.add_argument("--channels", type=int, default=1, choices=(1, 3, 8),
+                    help="descriptor channels of a residual block (reference Options::descriptorType): 1 Intensity (the headline), "
+                         "3 IntensityAndGradient, 8 BitPlanes")
+    ap.add_argument("--inverse-depth", action="store_true",
+                    help="the north star's SE(3) x inverse-depth parameterisation (pba_set_inverse_depth; no reference counterpart)")
     ap.add_argument("--repeats", type=int, default=25,
                     help="the K-step solve is timed this many times (each bracketed by barrier + synchronize, state reset outside "
                          "the bracket); `value` / `ms_per_step` come from the MEDIAN repeat, min / max are reported beside it")
@@ -102,24 +107,30 @@ def main():
 
     # ---- synthetic window: identical frames/cameras on every rank, rank-specific points ----------------------
     t0 = time.time()
-    default_shape = not explicit and (args.visibility, args.precision) == ("dense", "exact")
+    default_shape = not explicit and (args.visibility, args.precision, args.channels, args.inverse_depth) == ("dense", "exact", 1, False)
+    ch_fn = synthetic.channel_fn({3: "IntensityAndGradient", 8: "BitPlanes"}[args.channels]) if args.channels > 1 else None
     if strong:
         # the SAME window on every rank (same seeds), each rank keeps its contiguous shard of whole points
         whole = synthetic.make_window(n_frames=args.frames, n_points=args.points, radius=args.radius, huber=args.huber,
-                                      visibility=args.visibility, dense_births=(0, 8) if args.frames > 8 else (0,))
+                                      visibility=args.visibility, dense_births=(0, 8) if args.frames > 8 else (0,), channel_fn=ch_fn)
         prob = whole.shard(rank, world) if world > 1 else whole
         del whole
     else:
         prob = synthetic.make_window(n_frames=args.frames, n_points=args.points, radius=args.radius, huber=args.huber,
-                                     visibility=args.visibility, point_seed_offset=rank)
+                                     visibility=args.visibility, point_seed_offset=rank, channel_fn=ch_fn)
     t_gen = time.time() - t0
     rows, cols = prob.images.shape[1:]
-    P = prob.patch_len
+    P = prob.patch_len * args.channels          # residuals of one block
     n_obs_local = prob.n_obs
     n_bar = n_obs_local / prob.n_points
 
-    eng = Engine(rows, cols, prob.K, prob.radius, prob.n_frames, huber=prob.huber, device=local_rank, precision=args.precision)
+    eng = Engine(rows, cols, prob.K, prob.radius, prob.n_frames, huber=prob.huber, device=local_rank, precision=args.precision,
+                 channels=args.channels)
     eng.load(prob)
+    rays = rho0 = None
+    if args.inverse_depth:
+        rays, rho0 = synthetic.inverse_depth_rays(prob)
+        eng.set_inverse_depth(rays, rho0)
     transport = "RCCL all-reduce of the reduced camera system"
     if world > 1:
         uid = torch.zeros(129, dtype=torch.uint8, device=ctl)     # 128-byte ncclUniqueId + "valid" byte
@@ -149,8 +160,10 @@ def main():
             if rccl_ok:          # mixed outcome: rebuild the engine so that every rank uses the same transport
                 eng.close()
                 eng = Engine(rows, cols, prob.K, prob.radius, prob.n_frames, huber=prob.huber, device=local_rank,
-                             precision=args.precision)
+                             precision=args.precision, channels=args.channels)
                 eng.load(prob)
+                if args.inverse_depth:
+                    eng.set_inverse_depth(rays, rho0)
             eng.comm_init_callback(_allreduce, rank, world)
     elif os.environ.get("PBA_FORCE_MULTI") == "1":
         # diagnostics: the multi-rank code path (RCCL all-reduces on the engine's stream, k_decide) at world = 1
@@ -159,6 +172,8 @@ def main():
     def reset_state():
         eng.set_problem(prob.xyz, prob.desc, prob.obs_point, prob.obs_slot, prob.weights)
         eng.set_cameras(prob.cams, prob.fixed_slot)
+        if args.inverse_depth:
+            eng.set_inverse_depth(rays, rho0)
 
     def barrier():
         torch.cuda.synchronize()
@@ -219,7 +234,10 @@ def main():
     barrier()
     t2 = time.perf_counter()
     for s_ in range(prob.n_frames):
-        eng.set_frame(s_, prob.images[s_])
+        if args.channels > 1:
+            eng.set_frame_channels(s_, prob.channel_images[s_])
+        else:
+            eng.set_frame(s_, prob.images[s_])
     reset_state()
     upload_s = time.perf_counter() - t2
     # measured device-copy bandwidth (SURVEY.md 8d asks for it next to the 8 TB/s spec figure): 1 GiB device-to-device
@@ -254,7 +272,7 @@ def main():
     value = iters_per_sec if strong else world * iters_per_sec
     residuals_per_sec = n_obs_global * P * (n_jac + n_cost) / elapsed   # residuals actually evaluated by the engine
 
-    ab = algorithmic_bytes(prob.radius, n_bar)
+    ab = algorithmic_bytes(prob.radius, n_bar, args.channels)
     # SURVEY.md 8d accounting rule, "with the actual pass counts of the run": the engine fuses the candidate cost pass into
     # a speculative Jacobian pass, so a successful iteration is ONE Jacobian pass (and no cost pass); a rejected one is
     # followed by a re-solve from the stored linearisation.
@@ -318,7 +336,8 @@ def main():
                                   " sharded over the ranks" if strong else "/GPU", 2 * prob.radius + 1,
                                   2 * prob.radius + 1, args.visibility),
                    "image": "%dx%d u8" % (cols, rows), "observations": int(n_obs_global), "huber": prob.huber,
-                   "sampler_precision": args.precision,
+                   "sampler_precision": args.precision, "channels": args.channels,
+                   "point_parameterisation": "inverse depth on fixed rays (no reference counterpart)" if args.inverse_depth else "free world points (reference)",
                    "parallelism": "points sharded x%d, cameras+frames replicated, %s" % (world, transport)},
         "iters_per_sec": iters_per_sec, "residuals_per_sec": residuals_per_sec,
         "lm": {"iterations": iters_done, "successful": n_succ, "solves": -(-args.steps // CHUNK), "jacobian_passes": n_jac,
@@ -332,9 +351,9 @@ def main():
     }
 
     # ---- CPU baseline: the oracle ("restated Ceres-equivalent CPU path") on a bounded sample, rank 0, N = 1 ----
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.cpu_steps > 0:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.cpu_steps > 0 and not args.inverse_depth:
         from oracle import oracle
-        n_cpu = min(args.cpu_points, prob.n_points, max(1000, int(400000 / n_bar)))     # bounded: <= 400k residual blocks
+        n_cpu = min(args.cpu_points, prob.n_points, max(1000, int(400000 / n_bar / args.channels)))     # bounded: <= 400k single-channel residual blocks
         sub = prob.shard(0, 1)
         hi = int(np.searchsorted(prob.obs_point, n_cpu, side="left"))
         sub.xyz, sub.desc = prob.xyz[:n_cpu].copy(), prob.desc[:n_cpu]

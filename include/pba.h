@@ -220,6 +220,15 @@ int pba_comm_init_rccl(pba_engine* e, const void* id128, int32_t rank, int32_t w
 typedef int (*pba_allreduce_fn)(double* buf, int64_t n, int32_t op, void* ctx);
 int pba_comm_init_callback(pba_engine* e, pba_allreduce_fn fn, void* ctx, int32_t rank, int32_t world);
 
+/* Device-side exchange (optional, after pba_comm_init_rccl / pba_comm_init_callback, collective: every rank calls it):
+ * the two per-step all-reduces become flag-and-slot reads of peer-mapped mailboxes (hipIpc*, fine-grained device memory)
+ * inside small kernels on the engine's stream -- no collective launch per LM step, sums in rank order (bit-identical on all
+ * ranks).  The base transport carries the IPC handles and stays the fallback: the call returns PBA_OK whether or not the
+ * mapping succeeded (every rank takes the same decision); pba_comm_transport names what is in use ("rccl", "rccl+peer",
+ * "callback", "callback+peer", "none").  Waits are bounded by PBA_WAIT_TIMEOUT_S -> PBA_ERR_COMM. */
+int pba_comm_enable_peer_exchange(pba_engine* e);
+const char* pba_comm_transport(const pba_engine* e);
+
 int pba_get_counters(pba_engine* e, pba_counters* c);
 int pba_reset_counters(pba_engine* e);
 

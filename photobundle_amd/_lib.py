@@ -70,7 +70,8 @@ SYMBOLS = [
     "pba_status_string", "pba_last_error", "pba_default_solver_options", "pba_create", "pba_destroy",
     "pba_set_frame_u8", "pba_set_frame_channels_f32", "pba_get_frame_planes", "pba_set_problem", "pba_set_cameras", "pba_set_inverse_depth", "pba_get_points_world", "pba_get_state",
     "pba_linearize", "pba_step", "pba_accept", "pba_get_reduced_system", "pba_get_obs_records", "pba_solve",
-    "pba_comm_unique_id", "pba_comm_init_rccl", "pba_comm_init_callback", "pba_get_counters", "pba_reset_counters",
+    "pba_comm_unique_id", "pba_comm_init_rccl", "pba_comm_init_callback", "pba_comm_enable_peer_exchange", "pba_comm_transport",
+    "pba_get_counters", "pba_reset_counters",
 ]
 
 
@@ -112,6 +113,9 @@ def lib():
     L.pba_comm_unique_id.argtypes = [C.c_void_p]
     L.pba_comm_init_rccl.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
     L.pba_comm_init_callback.argtypes = [C.c_void_p, ALLREDUCE_FN, C.c_void_p, C.c_int32, C.c_int32]
+    L.pba_comm_enable_peer_exchange.argtypes = [C.c_void_p]
+    L.pba_comm_transport.argtypes = [C.c_void_p]
+    L.pba_comm_transport.restype = C.c_char_p
     L.pba_get_counters.argtypes = [C.c_void_p, C.POINTER(Counters)]
     L.pba_reset_counters.argtypes = [C.c_void_p]
     _LIB = L

@@ -6,6 +6,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 namespace pba {
 
@@ -110,7 +111,62 @@ int Comm::allreduce_host(double* h, int n, int op) {
   return 1;
 }
 
+int Comm::enable_peer() {
+  if (kind == 0 || world < 1 || world > kMaxPeers) { err = "peer exchange needs an initialised transport and <= 8 ranks"; return 1; }
+  if (peer) return 0;
+  // 1. own mailbox: fine-grained device memory (stores reach memory without waiting for the end of a kernel, remote
+  //    reads never see a stale L2 line), zeroed, exported
+  int ok = 1;
+  hipIpcMemHandle_t mine;
+  std::memset(&mine, 0, sizeof(mine));
+  if (hipExtMallocWithFlags(reinterpret_cast<void**>(&mb_own), kMailboxDoubles * sizeof(double), hipDeviceMallocFinegrained) != hipSuccess) {
+    (void)hipGetLastError(); mb_own = nullptr; ok = 0;
+  }
+  if (ok && (hipMemset(mb_own, 0, kMailboxDoubles * sizeof(double)) != hipSuccess || hipDeviceSynchronize() != hipSuccess)) ok = 0;
+  if (ok && hipIpcGetMemHandle(&mine, mb_own) != hipSuccess) { (void)hipGetLastError(); ok = 0; }
+  // 2. all-gather of the handles: one byte per double (exact under summation), 64 doubles = one rank's handle per call
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "one handle per allreduce_host call");
+  std::vector<hipIpcMemHandle_t> all(world);
+  for (int q = 0; q < world; ++q) {
+    double buf[64];
+    const unsigned char* b = reinterpret_cast<const unsigned char*>(&mine);
+    for (int i = 0; i < 64; ++i) buf[i] = (q == rank && ok) ? (double)b[i] : 0.0;
+    if (allreduce_host(buf, 64, 0)) { ok = 0; break; }
+    unsigned char* o = reinterpret_cast<unsigned char*>(&all[q]);
+    for (int i = 0; i < 64; ++i) o[i] = (unsigned char)buf[i];
+  }
+  // 3. map the peers
+  if (ok) {
+    for (int q = 0; q < world && ok; ++q) {
+      if (q == rank) { mb_peer[q] = mb_own; continue; }
+      void* ptr = nullptr;
+      if (hipIpcOpenMemHandle(&ptr, all[q], hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); ok = 0; break; }
+      mb_peer[q] = static_cast<double*>(ptr);
+    }
+  }
+  // 4. unanimous or not at all
+  double flag = ok ? 0.0 : 1.0;
+  if (allreduce_host(&flag, 1, 1)) flag = 1.0;
+  if (flag != 0.0) {
+    close_peer();
+    err = "peer exchange unavailable (fine-grained allocation or IPC mapping failed on some rank): staying on the base transport";
+    return 1;
+  }
+  peer = true; seq_a = seq_b = 0;
+  return 0;
+}
+
+void Comm::close_peer() {
+  for (int q = 0; q < kMaxPeers; ++q) {
+    if (mb_peer[q] && mb_peer[q] != mb_own) (void)hipIpcCloseMemHandle(mb_peer[q]);
+    mb_peer[q] = nullptr;
+  }
+  if (mb_own) { (void)hipFree(mb_own); mb_own = nullptr; }
+  peer = false;
+}
+
 void Comm::shutdown(bool abort) {
+  close_peer();
   if (kind == 1 && nccl_comm) {
     // a communicator with a collective that will never complete must be aborted: ncclCommDestroy would wait for it
     if (abort && rccl().CommAbort) rccl().CommAbort(static_cast<ncclComm_t>(nccl_comm));

@@ -3,6 +3,10 @@
 //              engine loads on boxes / processes that never go multi-rank, and so that a process that already
 //              carries a librccl (torch) shares that copy.
 //   callback : host-staged all-reduce supplied by the caller (gloo / MPI / tests).
+//   peer     : (on top of either) the two per-step exchanges as flag-and-slot reads of peer-mapped mailboxes
+//              (hipIpcGetMemHandle / hipIpcOpenMemHandle, fine-grained device memory) inside small kernels on the
+//              engine's stream: no collective launch per step.  The base transport bootstraps it (the IPC handles
+//              travel through its host all-reduce) and stays the fallback.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -27,6 +31,24 @@ struct Comm {
   double* h_stage = nullptr;   // pinned
   size_t stage_cap = 0;
   double* d_small = nullptr;   // 64 doubles, for host-scalar reductions over RCCL
+
+  // ---- peer exchange (optional) ------------------------------------------------------------------------------------
+  // Mailbox of every rank (doubles): [0, kFlagDoubles) flags (u64: A slot 0, A slot 1, B slot 0, B slot 1) |
+  // A: 2 x kCapA  (the packed reduced camera system) | B: 2 x kCapB (the step scalars).  A rank writes only its OWN
+  // mailbox and reads everybody's; slot = sequence number & 1 (a slot is rewritten two exchanges later, when every peer
+  // has provably finished reading it: it raised its flag for the exchange in between).
+  static constexpr int kMaxPeers = 8;
+  static constexpr size_t kFlagDoubles = 16, kCapA = 4608, kCapB = 64;
+  static constexpr size_t kMailboxDoubles = kFlagDoubles + 2 * kCapA + 2 * kCapB;
+  bool peer = false;
+  double* mb_own = nullptr;
+  double* mb_peer[kMaxPeers] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  unsigned long long seq_a = 0, seq_b = 0;      // exchanges enqueued so far (identical on every rank)
+  // all-gathers the IPC handles through allreduce_host, maps the peers; every rank ends with the same answer
+  int enable_peer();
+  void close_peer();
+  static size_t flag_index(int kind, unsigned long long seq) { return (size_t)(2 * kind + (int)(seq & 1)); }
+  static size_t data_offset(int kind, unsigned long long seq) { return kFlagDoubles + (kind == 0 ? (seq & 1) * kCapA : 2 * kCapA + (seq & 1) * kCapB); }
 
   static int unique_id(void* id128);
   int init_rccl(const void* id128, int rank, int world);

@@ -88,6 +88,8 @@ struct pba_engine {
   bool unit_weights = false;        // all patch weights are exactly 1 (MakePatchWeights without the Gaussian)
   bool fuse = true;                 // back-substitution + finalisation fused into the candidate pass (radius <= 3)
   unsigned int* d_ticket = nullptr;
+  unsigned int* d_ticket_solve = nullptr;   // arrival counter of k_reduce_solve
+  int solve_kind = 0;               // PBA_SOLVE: 0 blocked workgroup Cholesky (fused with the reduction at one rank), 1 one/two-wave kernels, 2 generic
   // asynchronous driver (device-side trust-region decisions)
   LmState* d_lm = nullptr;          // device state
   LmState* h_lm = nullptr;          // host-mapped mirror, written at every publish
@@ -107,6 +109,8 @@ struct pba_engine {
   static constexpr int kChunks = 32;
 
   Comm comm;
+  unsigned int* h_comm_err = nullptr;      // host-mapped: a peer-exchange wait timed out (k_peer_allreduce)
+  unsigned int* h_comm_err_dev = nullptr;
 
   // counters
   bool profile = false;
@@ -187,22 +191,20 @@ void launch_sample_r(pba_engine* e, const SampleParams& sp) {
     else hipLaunchKernelGGL((k_sample<R, JAC, kSampleWaves, false, false, false>), dim3(grid), block, 0, e->stream, sp);
   }
 }
-template <int R, bool JAC>
+template <int R, bool JAC, bool FUSED>
 void launch_sample_mc_r(pba_engine* e, const SampleParams& sp) {
-  hipLaunchKernelGGL((k_sample_mc<R, JAC, kSampleWaves>), dim3(e->sample_grid), dim3(kSampleWaves * 64), 0, e->stream, sp,
-                     (const float4*)e->d_frames_mc, e->channels);
+  hipLaunchKernelGGL((k_sample_mc<R, JAC, kSampleWaves, FUSED>), dim3(FUSED ? e->fused_grid : e->sample_grid), dim3(kSampleWaves * 64), 0,
+                     e->stream, sp, (const float4*)e->d_frames_mc, e->channels);
 }
 template <bool JAC, bool FUSED = false>
 void launch_sample(pba_engine* e, const SampleParams& sp) {
   if (e->channels > 1) {
-    if constexpr (!FUSED) {
-      switch (e->cfg.radius) {
-        case 1: launch_sample_mc_r<1, JAC>(e, sp); break;
-        case 2: launch_sample_mc_r<2, JAC>(e, sp); break;
-        case 3: launch_sample_mc_r<3, JAC>(e, sp); break;
-        case 4: launch_sample_mc_r<4, JAC>(e, sp); break;
-        default: launch_sample_mc_r<5, JAC>(e, sp); break;
-      }
+    switch (e->cfg.radius) {
+      case 1: launch_sample_mc_r<1, JAC, FUSED>(e, sp); break;
+      case 2: launch_sample_mc_r<2, JAC, FUSED>(e, sp); break;
+      case 3: launch_sample_mc_r<3, JAC, FUSED>(e, sp); break;
+      case 4: launch_sample_mc_r<4, JAC, FUSED>(e, sp); break;
+      default: launch_sample_mc_r<5, JAC, FUSED>(e, sp); break;
     }
     return;
   }
@@ -216,7 +218,7 @@ void launch_sample(pba_engine* e, const SampleParams& sp) {
 }
 // one kernel for back-substitution + candidate pass + step finalisation, at every patch radius; the opt-in
 // reduced-precision sampler modes (pba_config.flags bits 1-2) keep the unfused kernels
-bool fused_capable(const pba_engine* e) { return e->fuse && ((e->cfg.flags >> 1) & 3) == 0 && e->channels == 1 && !e->inverse_depth; }
+bool fused_capable(const pba_engine* e) { return e->fuse && ((e->cfg.flags >> 1) & 3) == 0; }
 int sample_waves_for_radius(int) { return kSampleWaves; }
 
 template <int NF>
@@ -224,6 +226,12 @@ void launch_solve_wave(pba_engine* e, const SolveParams& so) {
   hipLaunchKernelGGL((k_solve_wave<NF>), dim3(1), dim3(256), 0, e->stream, so);
 }
 void launch_solve(pba_engine* e, const SolveParams& so, int n) {
+  if (e->solve_kind == 0) {
+    if (e->n_free > kSolveNarrowFree) hipLaunchKernelGGL((k_solve_blocked<1024>), dim3(1), dim3(1024), solve_blocked_smem_bytes(n), e->stream, so);
+    else hipLaunchKernelGGL((k_solve_blocked<kSolveBlockedThreads>), dim3(1), dim3(kSolveBlockedThreads), solve_blocked_smem_bytes(n), e->stream, so);
+    return;
+  }
+  if (e->solve_kind == 1) {
   switch (e->n_free) {
     case 1: launch_solve_wave<1>(e, so); return;
     case 2: launch_solve_wave<2>(e, so); return;
@@ -242,8 +250,65 @@ void launch_solve(pba_engine* e, const SolveParams& so, int n) {
     case 15: hipLaunchKernelGGL((k_solve_wave2<15>), dim3(1), dim3(128), 0, e->stream, so); return;
     default: break;
   }
+  }
   const size_t solve_smem = sizeof(double) * ((size_t)n * (n + 1) + 5 * n);
   hipLaunchKernelGGL(k_solve_generic, dim3(1), dim3(kSolveThreads), solve_smem, e->stream, so);
+}
+
+// ---- peer exchange (pba_comm.h): kind 0 = packed reduced system, 1 = step scalars -------------------------------------
+PeerParams peer_params(const pba_engine* e) {
+  PeerParams pp{};
+  for (int q = 0; q < Comm::kMaxPeers; ++q) pp.mb[q] = e->comm.mb_peer[q];
+  pp.own = e->comm.mb_own; pp.world = e->comm.world; pp.rank = e->comm.rank;
+  return pp;
+}
+// where the producer of the NEXT exchange of `kind` writes this rank's contribution
+double* peer_slot(pba_engine* e, int kind) {
+  const unsigned long long x = (kind == 0 ? e->comm.seq_a : e->comm.seq_b) + 1;
+  return e->comm.mb_own + Comm::data_offset(kind, x);
+}
+// the exchange itself: flags + rank-ordered sum of n doubles into `out` (device memory of this rank)
+int peer_allreduce(pba_engine* e, int kind, int n, double* out) {
+  const unsigned long long x = ++(kind == 0 ? e->comm.seq_a : e->comm.seq_b);
+  const unsigned long long ticks = (unsigned long long)(e->wait_timeout_s * 1e8);
+  const int grid = std::max(1, std::min(32, (n + 255) / 256));
+  hipLaunchKernelGGL(k_peer_allreduce, dim3(grid), dim3(256), 0, e->stream, peer_params(e), (int)Comm::flag_index(kind, x),
+                     (unsigned long long)Comm::data_offset(kind, x), n, x, out, ticks, e->h_comm_err_dev);
+  HIP_TRY(e, hipGetLastError());
+  return PBA_OK;
+}
+
+// Reduction of the Schur partials + reduced solve.  One launch (k_reduce_solve) at a single rank; with more ranks the
+// all-reduce of the packed sums sits between the two, so they stay separate kernels.
+int launch_reduce_and_solve(pba_engine* e, const SolveParams& so, int n, int cur, int cand, const LmState* lm, int final_pass, int n_cost_blocks) {
+  const bool multi = e->comm.multi();
+  const int grid = (e->part_stride + kReduceEntries - 1) / kReduceEntries + 1;
+  if (!multi && e->solve_kind == 0 && !(PBA_PHASE_TIMING && getenv("PBA_SPLIT_SOLVE"))) {
+    ReduceSolveParams rp{};
+    rp.partial = e->d_partial; rp.n_blocks = e->schur_grid; rp.stride = e->part_stride;
+    rp.block_cost = e->d_block_cost[cur]; rp.block_fail = e->d_block_fail[cur]; rp.n_cost_blocks = n_cost_blocks;
+    rp.block_cost_alt = e->d_block_cost[cand]; rp.block_fail_alt = e->d_block_fail[cand];
+    rp.packed = e->d_packed; rp.scal = e->d_scal; rp.ticket = e->d_ticket_solve; rp.so = so;
+    hipLaunchKernelGGL(k_reduce_solve, dim3(grid), dim3(1024), solve_blocked_smem_bytes(n), e->stream, rp);
+    HIP_TRY(e, hipGetLastError());
+    return PBA_OK;
+  }
+  const bool peer = multi && e->comm.peer;
+  if (peer && (size_t)e->part_stride > Comm::kCapA) return fail(e, PBA_ERR_COMM, "reduced system of %d doubles exceeds the peer mailbox", e->part_stride);
+  hipLaunchKernelGGL(k_reduce_final, dim3(grid), dim3(1024), 0, e->stream, e->d_partial, e->schur_grid, e->part_stride,
+                     e->d_block_cost[cur], e->d_block_fail[cur], n_cost_blocks, peer ? peer_slot(e, 0) : e->d_packed, e->d_scal, lm, cur,
+                     (const double*)e->d_block_cost[cand], (const int32_t*)e->d_block_fail[cand], final_pass, peer ? 1 : 0);
+  HIP_TRY(e, hipGetLastError());
+  if (peer) {
+    const int rcp = peer_allreduce(e, 0, e->part_stride - 1, e->d_packed);
+    if (rcp) return rcp;
+  } else if (multi) {
+    if (e->comm.allreduce_device(e->d_packed, (size_t)e->part_stride - 1, 0, e->stream))
+      return fail(e, PBA_ERR_COMM, "allreduce(reduced system) failed: %s", e->comm.err.c_str());
+  }
+  launch_solve(e, so, n);
+  HIP_TRY(e, hipGetLastError());
+  return PBA_OK;
 }
 
 void launch_schur(pba_engine* e, const SchurParams& sp) {
@@ -288,9 +353,11 @@ int exchange_step_scalars(pba_engine* e, bool packed) {
   int rc = ensure_xchg(e);
   if (rc) return rc;
   if (!packed) {
-    hipLaunchKernelGGL(k_xchg_pack, dim3(1), dim3(64), 0, e->stream, e->d_scal, e->d_xchg, e->comm.rank, world);
+    hipLaunchKernelGGL(k_xchg_pack, dim3(1), dim3(64), 0, e->stream, e->d_scal, e->comm.peer ? peer_slot(e, 1) : e->d_xchg, e->comm.rank, world,
+                       e->comm.peer ? 1 : 0);
     HIP_TRY(e, hipGetLastError());
   }
+  if (e->comm.peer) return peer_allreduce(e, 1, (int)n, e->d_xchg);
   if (e->comm.allreduce_device(e->d_xchg, n, 0, e->stream))
     return fail(e, PBA_ERR_COMM, "allreduce(step scalars) failed: %s", e->comm.err.c_str());
   return PBA_OK;
@@ -431,6 +498,12 @@ int pba_create(const pba_config* cfg, pba_engine** out) {
   }
   if ((rc = dev_alloc(e, &e->d_ticket, (size_t)1))) return bail(rc);
   if (hipMemsetAsync(e->d_ticket, 0, sizeof(unsigned int), e->stream) != hipSuccess) return bail(PBA_ERR_HIP);
+  if (hipHostMalloc(reinterpret_cast<void**>(&e->h_comm_err), sizeof(unsigned int), hipHostMallocMapped) != hipSuccess) return bail(PBA_ERR_HIP);
+  *e->h_comm_err = 0;
+  if (hipHostGetDevicePointer(reinterpret_cast<void**>(&e->h_comm_err_dev), e->h_comm_err, 0) != hipSuccess) return bail(PBA_ERR_HIP);
+  if ((rc = dev_alloc(e, &e->d_ticket_solve, (size_t)1))) return bail(rc);
+  if (hipMemsetAsync(e->d_ticket_solve, 0, sizeof(unsigned int), e->stream) != hipSuccess) return bail(PBA_ERR_HIP);
+  if (const char* sv = getenv("PBA_SOLVE")) e->solve_kind = atoi(sv);
   for (int k = 0; k < 6; ++k)
     if (hipEventCreate(&e->ev[k]) != hipSuccess) return bail(PBA_ERR_HIP);
   e->sample_waves = sample_waves_for_radius(cfg->radius);
@@ -464,9 +537,10 @@ void pba_destroy(pba_engine* e) {
   dev_free(&e->d_desc); dev_free(&e->d_w2); dev_free(&e->d_obs_point); dev_free(&e->d_obs_slot); dev_free(&e->d_pt_begin);
   dev_free(&e->d_tile_info); dev_free(&e->d_obs_l0); dev_free(&e->d_obs_cnt); dev_free(&e->d_rec[0]); dev_free(&e->d_rec[1]); dev_free(&e->d_sp); dev_free(&e->d_ptrec); dev_free(&e->d_sc);
   dev_free(&e->d_delta_c); dev_free(&e->d_partial); dev_free(&e->d_red); dev_free(&e->d_packed); dev_free(&e->d_S);
-  dev_free(&e->d_rhs); dev_free(&e->d_bs_out); dev_free(&e->d_scal); dev_free(&e->d_xchg); dev_free(&e->d_ticket);
+  dev_free(&e->d_rhs); dev_free(&e->d_bs_out); dev_free(&e->d_scal); dev_free(&e->d_xchg); dev_free(&e->d_ticket); dev_free(&e->d_ticket_solve);
   if (e->h_scal) (void)hipHostFree(e->h_scal);
   if (e->h_lm) (void)hipHostFree(e->h_lm);
+  if (e->h_comm_err) (void)hipHostFree(e->h_comm_err);
   if (e->h_img_stage) (void)hipHostFree(e->h_img_stage);
   if (e->h_state_stage) (void)hipHostFree(e->h_state_stage);
   if (e->ev_img_stage) (void)hipEventDestroy(e->ev_img_stage);
@@ -810,14 +884,6 @@ int pba_internal_step(pba_engine* e, double radius, int32_t init_scale, const pb
     }
     --e->dbg_left;
   }
-  hipLaunchKernelGGL(k_reduce_final, dim3((e->part_stride + kReduceEntries - 1) / kReduceEntries + 1), dim3(1024), 0, e->stream, e->d_partial,
-                     e->schur_grid, e->part_stride, e->d_block_cost[cur], e->d_block_fail[cur], e->cost_blocks[cur], e->d_packed,
-                     e->d_scal, (const LmState*)nullptr, 0, (const double*)nullptr, (const int32_t*)nullptr, 0);
-  HIP_TRY(e, hipGetLastError());
-  if (multi) {
-    if (e->comm.allreduce_device(e->d_packed, (size_t)e->part_stride - 1, 0, e->stream))
-      return fail(e, PBA_ERR_COMM, "allreduce(reduced system) failed: %s", e->comm.err.c_str());
-  }
   SolveParams so{};
   so.packed = e->d_packed;
   so.cams = e->d_cams[cur]; so.cams_cand = e->d_cams[cand]; so.delta_c = e->d_delta_c;
@@ -829,7 +895,7 @@ int pba_internal_step(pba_engine* e, double radius, int32_t init_scale, const pb
   so.max_diag = o->max_lm_diagonal;
   so.lm = nullptr;
   so.dbg = (e->dbg_left > 0) ? 1 : 0;
-  launch_solve(e, so, n);
+  { const int rcs = launch_reduce_and_solve(e, so, n, cur, cand, nullptr, 0, e->cost_blocks[cur]); if (rcs) return rcs; }
   const unsigned long long seq = ++e->seq;
   unsigned long long* h_seq_dev = reinterpret_cast<unsigned long long*>(e->h_scal_dev + kNumScal);
   bool xchg_packed = false;
@@ -844,7 +910,8 @@ int pba_internal_step(pba_engine* e, double radius, int32_t init_scale, const pb
     if (multi) {
       int rcx = ensure_xchg(e);
       if (rcx) return rcx;
-      sp.xchg = e->d_xchg; sp.xchg_rank = e->comm.rank; sp.xchg_world = e->comm.world; xchg_packed = true;
+      sp.xchg = e->comm.peer ? peer_slot(e, 1) : e->d_xchg; sp.xchg_sys = e->comm.peer ? 1 : 0;
+      sp.xchg_rank = e->comm.rank; sp.xchg_world = e->comm.world; xchg_packed = true;
     }
     if (e->speculate) {
       ev_begin(e, 0);
@@ -942,6 +1009,9 @@ int pba_internal_step(pba_engine* e, double radius, int32_t init_scale, const pb
     unsigned long spins = 0;
     double t_first = -1.0;
     while (*h_seq != seq) {
+      if (*reinterpret_cast<volatile unsigned int*>(e->h_comm_err))
+        return fail(e, PBA_ERR_COMM, "peer exchange timed out after %.0f s waiting for rank %u", e->wait_timeout_s,
+                    *reinterpret_cast<volatile unsigned int*>(e->h_comm_err) - 1);
       // hipStreamQuery is not free for the device (it showed up as a ~6 us bubble in front of the next kernel), so it only
       // serves as a watchdog here: roughly every 50 ms of spinning
       if ((++spins & 0x3ffffff) == 0) {
@@ -1027,6 +1097,22 @@ int pba_comm_init_callback(pba_engine* e, pba_allreduce_fn fn, void* ctx, int32_
   return PBA_OK;
 }
 
+int pba_comm_enable_peer_exchange(pba_engine* e) {
+  if (!e) return PBA_ERR_INVALID;
+  if (e->comm.kind == 0) return fail(e, PBA_ERR_STATE, "call order violated: pba_comm_enable_peer_exchange before pba_comm_init_*");
+  PBA_NOT_POISONED(e);
+  HIP_TRY(e, hipSetDevice(e->cfg.device));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  if (e->comm.enable_peer()) e->err = e->comm.err;      // not an error: the base transport keeps serving (pba_comm_transport tells)
+  return PBA_OK;
+}
+
+const char* pba_comm_transport(const pba_engine* e) {
+  if (!e || e->comm.kind == 0) return "none";
+  if (e->comm.kind == 1) return e->comm.peer ? "rccl+peer" : "rccl";
+  return e->comm.peer ? "callback+peer" : "callback";
+}
+
 int pba_get_counters(pba_engine* e, pba_counters* c) {
   if (!e || !c) return PBA_ERR_INVALID;
   *c = e->ctr;
@@ -1053,7 +1139,7 @@ int64_t pba_internal_local_blocks(const pba_engine* e) { return e->n_obs; }
 int pba_internal_patch_len(const pba_engine* e) { return e->channels * (2 * e->cfg.radius + 1) * (2 * e->cfg.radius + 1); }
 // ---- asynchronous driver ----------------------------------------------------------------------------------------
 int pba_internal_async_capable(const pba_engine* e, const pba_solver_options* o) {
-  return e->use_async && fused_capable(e) && e->comm.kind != 2 && o->max_num_iterations < pba_engine::kMaxLog - 2 && !e->profile;
+  return e->use_async && fused_capable(e) && (e->comm.kind != 2 || e->comm.peer) && o->max_num_iterations < pba_engine::kMaxLog - 2 && !e->profile;
 }
 
 int pba_internal_ready(pba_engine* e) { return check_ready(e, "pba_solve"); }
@@ -1127,14 +1213,6 @@ int pba_internal_async_enqueue(pba_engine* e, int kind, int init_scale, const pb
   sc.min_diag = o->min_lm_diagonal; sc.max_diag = o->max_lm_diagonal; sc.dbg = nullptr;
   sc.lm = e->d_lm; sc.enq_cur = cur; sc.final_pass = (kind == 2) ? 1 : 0; sc.xyz_alt = e->d_xyz[cand]; sc.geom_alt = e->d_geom[cand]; sc.rec_alt = e->d_rec[cand];
   launch_schur(e, sc);
-  hipLaunchKernelGGL(k_reduce_final, dim3((e->part_stride + kReduceEntries - 1) / kReduceEntries + 1), dim3(1024), 0, e->stream, e->d_partial,
-                     e->schur_grid, e->part_stride, e->d_block_cost[cur], e->d_block_fail[cur], e->fused_grid, e->d_packed,
-                     e->d_scal, (const LmState*)e->d_lm, cur, (const double*)e->d_block_cost[cand], (const int32_t*)e->d_block_fail[cand], kind == 2 ? 1 : 0);
-  HIP_TRY(e, hipGetLastError());
-  if (multi) {
-    if (e->comm.allreduce_device(e->d_packed, (size_t)e->part_stride - 1, 0, e->stream))
-      return fail(e, PBA_ERR_COMM, "allreduce(reduced system) failed: %s", e->comm.err.c_str());
-  }
   SolveParams so{};
   so.packed = e->d_packed; so.cams = e->d_cams[cur]; so.cams_cand = e->d_cams[cand]; so.delta_c = e->d_delta_c;
   so.sc = e->d_sc; so.S_dbg = (e->cfg.flags & 1) ? e->d_S : nullptr; so.rhs_dbg = e->d_rhs; so.scal = e->d_scal; so.geom = e->d_geom[cur];
@@ -1143,7 +1221,7 @@ int pba_internal_async_enqueue(pba_engine* e, int kind, int init_scale, const pb
   so.init_scale = init_scale; so.jacobi = o->jacobi_scaling; so.radius = 1.0; so.min_diag = o->min_lm_diagonal; so.max_diag = o->max_lm_diagonal;
   so.lm = e->d_lm; so.enq_cur = cur; so.final_pass = (kind == 2) ? 1 : 0; so.cams_alt = e->d_cams[cand]; so.cams_cand_alt = e->d_cams[cur]; so.geom_alt = e->d_geom[cand];
   so.geom_cand_alt = e->d_geom[cur];
-  launch_solve(e, so, n);
+  { const int rcs = launch_reduce_and_solve(e, so, n, cur, cand, e->d_lm, kind == 2 ? 1 : 0, e->fused_grid); if (rcs) return rcs; }
   const unsigned long long seq = ++e->seq;
   if (kind == 1) {
     SampleParams sp = sample_params(false);
@@ -1153,7 +1231,8 @@ int pba_internal_async_enqueue(pba_engine* e, int kind, int init_scale, const pb
     if (multi) {
       int rcx = ensure_xchg(e);
       if (rcx) return rcx;
-      sp.xchg = e->d_xchg; sp.xchg_rank = e->comm.rank; sp.xchg_world = e->comm.world;
+      sp.xchg = e->comm.peer ? peer_slot(e, 1) : e->d_xchg; sp.xchg_sys = e->comm.peer ? 1 : 0;
+      sp.xchg_rank = e->comm.rank; sp.xchg_world = e->comm.world;
     }
     launch_sample<true, true>(e, sp);
     e->jac_passes++;
@@ -1181,6 +1260,10 @@ int pba_internal_async_wait(pba_engine* e, unsigned long long seq) {
   unsigned long spins = 0;
   double t_first = -1.0;
   while (*h_seq < seq) {
+    if (*reinterpret_cast<volatile unsigned int*>(e->h_comm_err)) {
+      const unsigned int who = *reinterpret_cast<volatile unsigned int*>(e->h_comm_err) - 1;
+      return fail(e, PBA_ERR_COMM, "peer exchange timed out after %.0f s waiting for rank %u", e->wait_timeout_s, who);
+    }
     // hipStreamQuery is not free for the device (it showed up as a ~6 us bubble in front of the next kernel), so it only
     // serves as a watchdog here: roughly every 50 ms of spinning
     if ((++spins & 0x3ffffff) == 0) {

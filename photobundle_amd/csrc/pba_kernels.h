@@ -169,6 +169,36 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
 // =====================================================================================================
 // camera geometry
 // =====================================================================================================
+// Sine and cosine of the rotation angle.  Window cameras rotate by a fraction of a radian, and for |x| <= pi / 4 the
+// library entry points spend most of their ~2 x 150 instructions on an argument reduction that is the identity there:
+// this is the reduced-range core alone (the fdlibm __kernel_sin / __kernel_cos minimax polynomials, error < 1 ulp),
+// with the library as the fallback for larger angles.  The candidate-camera geometry sits on the serial stretch of every
+// LM iteration (solve epilogue).
+__device__ __forceinline__ void sincos_angle(double x, double& sn, double& cs) {
+  const double ax = fabs(x);
+  if (ax <= 0.78539816339744828) {
+    const double z = x * x;
+    const double v = z * x;
+    const double rs = 8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 + z * (2.75573137070700676789e-06 +
+                      z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
+    sn = x + v * (-1.66666666666666324348e-01 + z * rs);
+    const double rc = z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 +
+                      z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
+    if (ax < 0.3) {
+      cs = 1.0 - (0.5 * z - z * rc);
+    } else {
+      // qx ~ |x| / 4 with a zeroed low word, so that 1 - qx and 0.5 z - qx are exact
+      const double qx = (ax > 0.78125) ? 0.28125 : __hiloint2double(__double2hiint(ax) - 0x00200000, 0);
+      const double hz = 0.5 * z - qx;
+      const double a = 1.0 - qx;
+      cs = a - (hz - z * rc);
+    }
+  } else {
+    sn = sin(x);
+    cs = cos(x);
+  }
+}
+
 __device__ inline void cam_geom_one(const double* __restrict__ cams, CamGeom* __restrict__ geom, int c, int fixed_slot) {
   CamGeom g;
   const double* p = cams + 6 * c;
@@ -181,7 +211,8 @@ __device__ inline void cam_geom_one(const double* __restrict__ cams, CamGeom* __
   g.pad = 0;
   if (g.rodrigues) {
     const double theta = sqrt(theta2);
-    const double ct = cos(theta), st = sin(theta);
+    double ct, st;
+    sincos_angle(theta, st, ct);
     const double ti = 1.0 / theta;
     const double ax = wx * ti, ay = wy * ti, az = wz * ti;
     g.w[0] = ax; g.w[1] = ay; g.w[2] = az; g.ct = ct; g.st = st;
@@ -470,15 +501,63 @@ __device__ inline void lm_publish(const LmState* st, LmState* host_state, const 
 // ---- multi-rank exchange of the step scalars in ONE sum all-reduce -----------------------------------------------
 // xchg = [ sum group (kSumBCount) | world x max group (kMaxCount) ]: every rank writes its max-group values into its
 // own slot and zeros into the others, so the SUM all-reduce doubles as an all-gather; the max is taken afterwards.
-__device__ inline void xchg_pack(const double* scal, double* xchg, int rank, int world, int tid, int nthreads) {
-  for (int i = tid; i < kSumBCount; i += nthreads) xchg[i] = scal[kCandCost + i];
+// System-scope (write-through, cache-bypassing) 8-byte store / load: mailboxes that PEER devices read / that live on a peer.
+__device__ __forceinline__ void store_system_f64(double* p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ double load_system_f64(const double* p) {
+  return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+}
+// sys: the buffer is this rank's peer-exchange mailbox (pba_comm.h)
+__device__ inline void xchg_pack(const double* scal, double* xchg, int rank, int world, int tid, int nthreads, bool sys = false) {
+  for (int i = tid; i < kSumBCount; i += nthreads) { if (sys) store_system_f64(xchg + i, scal[kCandCost + i]); else xchg[i] = scal[kCandCost + i]; }
   for (int k = tid; k < kMaxCount * world; k += nthreads) {
     const int r = k / kMaxCount, j = k - r * kMaxCount;
-    xchg[kSumBCount + k] = (r == rank) ? scal[kGmaxPts + j] : 0.0;
+    const double v = (r == rank) ? scal[kGmaxPts + j] : 0.0;
+    if (sys) store_system_f64(xchg + kSumBCount + k, v); else xchg[kSumBCount + k] = v;
   }
 }
-__global__ void k_xchg_pack(const double* __restrict__ scal, double* __restrict__ xchg, int rank, int world) {
-  xchg_pack(scal, xchg, rank, world, threadIdx.x, blockDim.x);
+__global__ void k_xchg_pack(const double* __restrict__ scal, double* __restrict__ xchg, int rank, int world, int sys) {
+  xchg_pack(scal, xchg, rank, world, threadIdx.x, blockDim.x, sys != 0);
+}
+
+// ---- peer exchange: sum all-reduce of n doubles over the ranks' mailboxes, without a collective launch ----------------
+// Every rank's producer kernel (earlier on the stream) has written its contribution into ITS OWN mailbox slot with
+// system-scope stores.  This kernel raises the rank's flag for exchange `seq` (the producer has retired, so its stores
+// have), waits until every peer's flag shows `seq`, and sums the contributions in RANK ORDER -- the same order on every
+// rank, so all ranks end with bit-identical sums.  Spin-waits are bounded: after `timeout_ticks` of the 100 MHz counter the
+// kernel reports through a host-mapped word and carries on (the host turns that into PBA_ERR_COMM).
+struct PeerParams {
+  const double* mb[8];         // every rank's mailbox as mapped into this process (own at [rank])
+  double* own;
+  int32_t world, rank;
+};
+__global__ __launch_bounds__(256) void k_peer_allreduce(PeerParams pp, int flag_idx, unsigned long long data_off, int n,
+                                                         unsigned long long seq, double* __restrict__ out,
+                                                         unsigned long long timeout_ticks, unsigned int* host_err) {
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(pp.own) + flag_idx, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if ((int)threadIdx.x < pp.world) {
+    const unsigned long long* f = reinterpret_cast<const unsigned long long*>(pp.mb[threadIdx.x]) + flag_idx;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+      if (__builtin_amdgcn_s_memrealtime() - t0 > timeout_ticks) {
+        if (host_err) __hip_atomic_store(host_err, 1u + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(16);
+    }
+  }
+  __syncthreads();
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+    double v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = (q < pp.world) ? load_system_f64(pp.mb[q] + data_off + e) : 0.0;
+    double acc = v[0];
+#pragma unroll
+    for (int q = 1; q < 8; ++q) if (q < pp.world) acc += v[q];
+    out[e] = acc;
+  }
 }
 __device__ inline void xchg_unpack(const double* xchg, double* scal, int world) {   // one thread
   for (int i = 0; i < kSumBCount; ++i) scal[kCandCost + i] = xchg[i];
@@ -599,8 +678,263 @@ struct SampleParams {
   int32_t prec;               // 0: reference-exact sampler (default); 1: fp32 walk; 2: fp32 walk with bf16 operands (sweep)
   double* xchg;               // multi-rank: exchange buffer of the step scalars, packed by the last workgroup
   int32_t xchg_rank, xchg_world;
+  int32_t xchg_sys;           // the exchange buffer is this rank's peer mailbox: system-scope stores
   unsigned long long* dbg;    // optional [gridDim.x][8] per-phase cycle stamps of thread 0 (diagnostics)
 };
+
+// ---- pieces of the FUSED sampling kernels (k_sample, k_sample_mc): the step that leads to the point being sampled -------
+// Compact table of the PREVIOUS cameras for the back-substitution, per slot: R (9) | t (3) | Omega (9) | dt (3) |
+// free index (1): with Omega_a = sum_k dw_k dR_k (the step's rotation part applied to the stored derivative matrices)
+// the camera step enters every observation as  Ac dc = dpi (Omega_a X + dt_a)  and the point side as
+// Ap^T u = R^T (dpi^T u): ~60 fp64 operations per observation instead of the full 2x6 / 2x3 Jacobians
+constexpr int kBk = 26;
+static_assert(kBk * sizeof(double) <= sizeof(CamGeom), "the compact table fits the second camera-table slot");
+
+__device__ __forceinline__ bool fused_resolve_parity(SampleParams& p) {
+  if (p.lm) {
+    if (p.lm->done) return false;
+    if (p.lm->cur != p.enq_cur) {     // the host's parity guess was off by an odd number of accepted steps
+      const double* tx = p.xyz; p.xyz = p.xyz_prev; p.xyz_prev = tx;
+      double* tr = p.rec; p.rec = const_cast<double*>(p.rec_prev); p.rec_prev = tr;
+      const CamGeom* tg = p.geom; p.geom = p.geom_prev; p.geom_prev = tg;
+      double* tc = p.block_cost; p.block_cost = p.block_cost_alt; p.block_cost_alt = tc;
+      int32_t* tf = p.block_fail; p.block_fail = p.block_fail_alt; p.block_fail_alt = tf;
+    }
+  }
+  return true;
+}
+
+// whole-point tiles of <= 128 observations, two per 256-thread workgroup
+struct FusedIdx { int4 ti; int pt, slot, l0, cnt; };
+template <int NT>
+__device__ __forceinline__ FusedIdx fused_prefetch_indices(const SampleParams& p, int bid) {
+  FusedIdx f{make_int4(0, 0, 0, 0), 0, 0, 0, 0};
+  const int tile = bid * (NT / 128) + (int)(threadIdx.x >> 7);
+  if (tile < p.n_tiles) f.ti = p.tile_info[tile];
+  const int lt = threadIdx.x & 127;
+  if (lt < f.ti.y) {
+    const int o = f.ti.x + lt;
+    f.pt = p.obs_point[o];
+    f.slot = p.obs_slot[o];
+    f.l0 = p.obs_l0[o]; f.cnt = p.obs_cnt[o];
+  }
+  return f;
+}
+
+template <int NT>
+__device__ __forceinline__ void fused_stage_step_table(const SampleParams& p, double* s_bk) {
+  if (!p.skip_backsub) {
+    for (int e = threadIdx.x; e < kBk * p.n_frames; e += NT) {
+      const int a = e / kBk, k = e - a * kBk;
+      const CamGeom& gp = p.geom_prev[a];
+      const double* dc = p.delta_c + 6 * a;
+      double val;
+      if (k < 9) val = gp.R[k];
+      else if (k < 12) val = gp.t[k - 9];
+      else if (k < 21) val = dc[0] * gp.dR[k - 12] + dc[1] * gp.dR[9 + k - 12] + dc[2] * gp.dR[18 + k - 12];
+      else if (k < 24) val = dc[3 + k - 21];
+      else val = (double)gp.free_index;
+      s_bk[e] = val;
+    }
+  }
+}
+
+// Phase 0 of the fused kernels: back-substitution (SchurEliminator::BackSubstitute) for the workgroup's whole points; on
+// return X is the CANDIDATE point parameters of the lane's observation.  s_bs: [NT][3] doubles of LDS scratch.
+template <int NT>
+__device__ __forceinline__ void fused_backsub(const SampleParams& p, const double* rays, const FusedIdx& fi, const double* s_bk,
+                                              double* s_bs, int& pt, int& slot, int& obs, bool& active, double (&X)[3],
+                                              double& bs_mcc, double& bs_st2, double& bs_x2) {
+  // delta_p = -P (g_p + sum_l W_l^T delta_c[slot_l]),  W_l^T delta_c = Ap^T M' (Ac delta_c)
+  const int half = threadIdx.x >> 7, lt = threadIdx.x & 127;
+  const int4 ti = fi.ti;
+  active = lt < ti.y;
+  obs = ti.x + lt;
+  int l0 = 0, cnt = 0;
+  double c3[3] = {0.0, 0.0, 0.0};
+  double pr[12], spk[3] = {1.0, 1.0, 1.0};
+#pragma unroll
+  for (int k = 0; k < 12; ++k) pr[k] = 0.0;
+  if (active) {
+    pt = fi.pt;
+    slot = fi.slot;
+    l0 = fi.l0; cnt = fi.cnt;
+    const double* xsrc = p.skip_backsub ? p.xyz : p.xyz_prev;
+    X[0] = xsrc[3 * (size_t)pt]; X[1] = xsrc[3 * (size_t)pt + 1]; X[2] = xsrc[3 * (size_t)pt + 2];
+    // issued here (same dependency level as X) so that they are in flight across the barrier below
+    if (!p.skip_backsub) {
+#pragma unroll
+    for (int k = 0; k < 12; ++k) pr[k] = p.ptrec[12 * (size_t)pt + k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) spk[k] = p.sp[3 * (size_t)pt + k];
+    }
+    const double* bk = s_bk + kBk * slot;
+    if (!p.skip_backsub && bk[24] >= 0.0) {
+      // world point of the parameters (inverse-depth variant: X = o + d / rho, dX/drho = q)
+      double Xw[3] = {X[0], X[1], X[2]}, qd[3] = {0.0, 0.0, 0.0};
+      if (rays) point_world(rays, pt, X, Xw, qd);
+      // xw = R X + t (plain order: this point only feeds the derivative of the projection, not a sampled position)
+      const double xw0 = bk[0] * Xw[0] + bk[1] * Xw[1] + bk[2] * Xw[2] + bk[9];
+      const double xw1 = bk[3] * Xw[0] + bk[4] * Xw[1] + bk[5] * Xw[2] + bk[10];
+      const double xw2 = bk[6] * Xw[0] + bk[7] * Xw[1] + bk[8] * Xw[2] + bk[11];
+      const double iz = fast_rcp(xw2);
+      const double ju0 = p.fx * iz, ju2 = -p.fx * xw0 * iz * iz;
+      const double jv1 = p.fy * iz, jv2 = -p.fy * xw1 * iz * iz;
+      // Ac dc = dpi (Omega X + dt)
+      const double s0 = bk[12] * Xw[0] + bk[13] * Xw[1] + bk[14] * Xw[2] + bk[21];
+      const double s1 = bk[15] * Xw[0] + bk[16] * Xw[1] + bk[17] * Xw[2] + bk[22];
+      const double s2 = bk[18] * Xw[0] + bk[19] * Xw[1] + bk[20] * Xw[2] + bk[23];
+      const double t0 = ju0 * s0 + ju2 * s2, t1 = jv1 * s1 + jv2 * s2;
+      const double m0 = p.rec_prev[0 * p.rec_stride + obs], m1 = p.rec_prev[1 * p.rec_stride + obs], m2 = p.rec_prev[2 * p.rec_stride + obs];
+      const double u0 = m0 * t0 + m1 * t1, u1 = m1 * t0 + m2 * t1;
+      // W_l^T dc = Ap^T u = R^T (dpi^T u)
+      const double w0 = ju0 * u0, w1 = jv1 * u1, w2 = ju2 * u0 + jv2 * u1;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) c3[k] = bk[k] * w0 + bk[3 + k] * w1 + bk[6 + k] * w2;
+      if (rays) { c3[0] = qd[0] * c3[0] + qd[1] * c3[1] + qd[2] * c3[2]; c3[1] = 0.0; c3[2] = 0.0; }   // Ap -> Ap q (point_jacobian)
+    }
+  }
+  s_bs[threadIdx.x * 3 + 0] = c3[0]; s_bs[threadIdx.x * 3 + 1] = c3[1]; s_bs[threadIdx.x * 3 + 2] = c3[2];
+  lds_barrier();
+  if (active && !p.skip_backsub) {
+    double acc[3] = {0.0, 0.0, 0.0};
+    const double* src = s_bs + (half * 128 + l0) * 3;
+    // four observations per trip, their twelve LDS reads in flight together (one dependent read per trip otherwise);
+    // the adds keep the lane order
+    for (int lb = 0; lb < cnt; lb += 4) {
+      double x[4][3];
+#pragma unroll
+      for (int l = 0; l < 4; ++l) {
+        const int li = (lb + l < cnt) ? lb + l : cnt - 1;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) x[l][k] = src[3 * li + k];
+      }
+#pragma unroll
+      for (int l = 0; l < 4; ++l) {
+        const bool in = lb + l < cnt;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) acc[k] += in ? x[l][k] : 0.0;
+      }
+    }
+    const double q0 = pr[6] + acc[0], q1 = pr[7] + acc[1], q2 = pr[8] + acc[2];
+    const double d[3] = {-(pr[0] * q0 + pr[1] * q1 + pr[2] * q2), -(pr[1] * q0 + pr[3] * q1 + pr[4] * q2),
+                         -(pr[2] * q0 + pr[4] * q1 + pr[5] * q2)};
+    const bool head = (lt == l0);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      if (head) {
+        const double sk = spk[k];
+        const double yk = -d[k] * fast_rcp(sk);             // step in Jacobi-scaled coordinates is -y
+        bs_mcc += 0.5 * yk * (sk * pr[6 + k]) + 0.5 * pr[9 + k] * yk * yk;
+        bs_st2 += d[k] * d[k];
+        bs_x2 += X[k] * X[k];
+        const_cast<double*>(p.xyz)[3 * (size_t)pt + k] = X[k] + d[k];
+      }
+      X[k] = X[k] + d[k];
+    }
+  }
+}
+
+// Per-workgroup partials of the fused kernels: cost of the block and the point part of the step statistics, fixed-order
+// sums (butterfly inside each wave, then the waves in order), write-through stores for the last workgroup of the launch.
+template <int WAVES>
+__device__ __forceinline__ void fused_block_partials(const SampleParams& p, int bid, int lane, int wave, double cost_obs,
+                                                     double bs_mcc, double bs_st2, double bs_x2, double* s_red, const int32_t& s_fail) {
+  double q4[4] = {cost_obs, bs_mcc, bs_st2, bs_x2};
+  wave_sum_n<4>(q4);
+  if (lane == 0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s_red[q * WAVES + wave] = q4[q];
+  }
+  lds_barrier();
+  double red_out[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    double a = 0.0;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) a += s_red[q * WAVES + w];
+    red_out[q] = a;
+  }
+  if (threadIdx.x == 0) {
+    // consumed by the last workgroup of THIS launch: write-through stores; a non-finite block poisons its cost
+    store_agent(p.block_cost + bid, s_fail ? __longlong_as_double(0x7ff8000000000000ll) : red_out[0]);
+    store_agent(p.block_bs + 3 * bid, red_out[1]);
+    store_agent(p.block_bs + 3 * bid + 1, red_out[2]);
+    store_agent(p.block_bs + 3 * bid + 2, red_out[3]);
+    p.block_fail[bid] = s_fail;
+  }
+}
+
+// Step finalisation by the last workgroup to arrive (agent-scope release / acquire around the ticket): fixed-order sums
+// of all block partials, the trust-region decision (single rank), the exchange buffer (multi-rank), publication.
+// s_f: [NTH] ints, s_r4: [4][NTH] doubles of LDS scratch that is free by now.
+template <int WAVES>
+__device__ __forceinline__ void fused_finalize(const SampleParams& p, int lane, int wave, int* s_f, double* s_r4, unsigned long long t_begin) {
+  constexpr int NTH = WAVES * 64;
+  __shared__ int s_last;
+  if (threadIdx.x == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the write-through partials have left this CU
+    const unsigned t = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = (t == gridDim.x - 1) ? 1 : 0;
+  }
+  __syncthreads();
+  if (s_last) {
+    const unsigned long long t_fin0 = p.dbg ? __builtin_amdgcn_s_memrealtime() : 0;
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0; int f = 0;
+    // 8 blocks' partials in flight per thread (every load misses this XCD's L2), summed in block order
+    for (int b0 = threadIdx.x; b0 < (int)gridDim.x; b0 += 8 * NTH) {
+      double v0[8], v1[8], v2[8], v3[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int b = b0 + k * NTH;
+        const bool ok = b < (int)gridDim.x;
+        v0[k] = ok ? load_agent(p.block_bs + 3 * b) : 0.0;
+        v1[k] = ok ? load_agent(p.block_bs + 3 * b + 1) : 0.0;
+        v2[k] = ok ? load_agent(p.block_bs + 3 * b + 2) : 0.0;
+        v3[k] = ok ? load_agent(p.block_cost + b) : 0.0;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { a0 += v0[k]; a1 += v1[k]; a2 += v2[k]; a3 += v3[k]; f |= (v3[k] != v3[k]) ? 1 : 0; }
+    }
+    const unsigned long long t_fin1 = p.dbg ? __builtin_amdgcn_s_memrealtime() : 0;
+    a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3);
+    f = __any(f) ? 1 : 0;
+    if (lane == 0) { s_r4[wave] = a0; s_r4[WAVES + wave] = a1; s_r4[2 * WAVES + wave] = a2; s_r4[3 * WAVES + wave] = a3; s_f[wave] = f; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int w = 1; w < WAVES; ++w) {
+        s_r4[0] += s_r4[w]; s_r4[WAVES] += s_r4[WAVES + w]; s_r4[2 * WAVES] += s_r4[2 * WAVES + w]; s_r4[3 * WAVES] += s_r4[3 * WAVES + w];
+        s_f[0] |= s_f[w];
+      }
+    }
+    __syncthreads();
+    unsigned long long t_fin2 = 0, t_fin3 = 0;
+    if (threadIdx.x == 0) {
+      t_fin2 = p.dbg ? __builtin_amdgcn_s_memrealtime() : 0;
+      p.scal[kMccPts] = s_r4[0]; p.scal[kStep2Pts] = s_r4[WAVES]; p.scal[kX2Pts] = s_r4[2 * WAVES];
+      p.scal[kCandCost] = s_r4[3 * WAVES]; p.scal[kEvalFailCand] = (double)s_f[0];
+      *p.ticket = 0;
+      if (p.lm && p.decide) lm_decide(p.lm, p.scal, p.log, p.max_log, 0);
+      if (p.lm && p.decide && p.lm->done && p.lm->done_seq == 0) p.lm->done_seq = p.seq;
+      t_fin3 = p.dbg ? __builtin_amdgcn_s_memrealtime() : 0;
+    }
+    if (p.xchg) {
+      __syncthreads();
+      xchg_pack(p.scal, p.xchg, p.xchg_rank, p.xchg_world, threadIdx.x, NTH, p.xchg_sys != 0);
+    }
+    if (p.host_scal) {
+      __syncthreads();
+      lm_publish(p.lm, (p.lm && p.decide) ? p.host_state : nullptr, p.scal, p.host_scal, p.host_seq, p.seq, threadIdx.x, NTH);
+    }
+    if (p.dbg && threadIdx.x == 0) {
+      p.dbg[(size_t)gridDim.x * 8] = __builtin_amdgcn_s_memrealtime() - t_fin0;
+      p.dbg[(size_t)gridDim.x * 8 + 1] = t_fin0 - t_begin;
+      p.dbg[(size_t)gridDim.x * 8 + 2] = t_fin1 - t_fin0;      // partial loads
+      p.dbg[(size_t)gridDim.x * 8 + 3] = t_fin2 - t_fin1;      // block reduction
+      p.dbg[(size_t)gridDim.x * 8 + 4] = t_fin3 - t_fin2;      // decision
+    }
+  }
+}
 
 // One LANE per observation (residual block); each wave stages the (2R+2)^2 texel footprints of its 64
 // observations through LDS with cooperative row-segment loads (consecutive lanes read consecutive texels of a
@@ -632,18 +966,9 @@ void k_sample(SampleParams p_in) {
   static_assert(!FAST || UNITW, "the reduced-precision walk assumes unit patch weights");
   SampleParams p = p_in;
   if (!PBA_PHASE_TIMING) p.dbg = nullptr;
-  // the inverse-depth variant runs on the unfused kernels only (the fused ones keep their register budget)
-  const double* rays = FUSED ? nullptr : p.rays;
-  if (FUSED && p.lm) {
-    if (p.lm->done) return;
-    if (p.lm->cur != p.enq_cur) {     // the host's parity guess was off by an odd number of accepted steps
-      const double* tx = p.xyz; p.xyz = p.xyz_prev; p.xyz_prev = tx;
-      double* tr = p.rec; p.rec = const_cast<double*>(p.rec_prev); p.rec_prev = tr;
-      const CamGeom* tg = p.geom; p.geom = p.geom_prev; p.geom_prev = tg;
-      double* tc = p.block_cost; p.block_cost = p.block_cost_alt; p.block_cost_alt = tc;
-      int32_t* tf = p.block_fail; p.block_fail = p.block_fail_alt; p.block_fail_alt = tf;
-    }
-  }
+  // inverse-depth variant (point_world): null for the reference's free world points
+  const double* rays = p.rays;
+  if (FUSED && !fused_resolve_parity(p)) return;
   constexpr int W = 2 * R + 1;      // patch side
   constexpr int F = 2 * R + 2;      // footprint side
   constexpr int RB = sample_rows_per_batch(R);   // footprint rows staged per batch
@@ -672,12 +997,6 @@ void k_sample(SampleParams p_in) {
 
   // camera geometry tables -> LDS (the texel region is free until the staging phase)
   CamGeom* s_geom = reinterpret_cast<CamGeom*>(s_raw + sizeof(double) * 3 * WAVES * 64);
-  // compact table of the PREVIOUS cameras for the back-substitution, per slot: R (9) | t (3) | Omega (9) | dt (3) |
-  // free index (1): with Omega_a = sum_k dw_k dR_k (the step's rotation part applied to the stored derivative matrices)
-  // the camera step enters every observation as  Ac dc = dpi (Omega_a X + dt_a)  and the point side as
-  // Ap^T u = R^T (dpi^T u): ~60 fp64 operations per observation instead of the full 2x6 / 2x3 Jacobians
-  constexpr int kBk = 26;
-  static_assert(kBk * sizeof(double) <= sizeof(CamGeom), "the compact table fits the second camera-table slot");
   double* s_bk = reinterpret_cast<double*>(s_geom + kMaxFrames);
   unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tl = p.dbg ? __builtin_amdgcn_s_memtime() : 0;
@@ -685,34 +1004,10 @@ void k_sample(SampleParams p_in) {
 #define PBA_STK(k) do { if (p.dbg) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); tk[k] += tn - tl; tl = tn; } } while (0)
   // fused form: the tile descriptor and the observation's indices do not depend on the tables -- requested first so
   // that their two dependent round trips overlap the table loads instead of following the barrier
-  int4 ti_f = make_int4(0, 0, 0, 0);
-  int pt_f = 0, slot_f = 0, l0_f = 0, cnt_f = 0;
-  if (FUSED) {
-    const int tile = bid * ((WAVES * 64) / 128) + (int)(threadIdx.x >> 7);
-    if (tile < p.n_tiles) ti_f = p.tile_info[tile];
-    const int lt = threadIdx.x & 127;
-    if (lt < ti_f.y) {
-      const int o = ti_f.x + lt;
-      pt_f = p.obs_point[o];
-      slot_f = p.obs_slot[o];
-      l0_f = p.obs_l0[o]; cnt_f = p.obs_cnt[o];
-    }
-  }
+  FusedIdx fi{make_int4(0, 0, 0, 0), 0, 0, 0, 0};
+  if (FUSED) fi = fused_prefetch_indices<WAVES * 64>(p, bid);
   stage_geom<WAVES * 64>(p.geom, s_geom, p.n_frames, threadIdx.x);
-  if (FUSED && !p.skip_backsub) {
-    for (int e = threadIdx.x; e < kBk * p.n_frames; e += WAVES * 64) {
-      const int a = e / kBk, k = e - a * kBk;
-      const CamGeom& gp = p.geom_prev[a];
-      const double* dc = p.delta_c + 6 * a;
-      double val;
-      if (k < 9) val = gp.R[k];
-      else if (k < 12) val = gp.t[k - 9];
-      else if (k < 21) val = dc[0] * gp.dR[k - 12] + dc[1] * gp.dR[9 + k - 12] + dc[2] * gp.dR[18 + k - 12];
-      else if (k < 24) val = dc[3 + k - 21];
-      else val = (double)gp.free_index;
-      s_bk[e] = val;
-    }
-  }
+  if (FUSED) fused_stage_step_table<WAVES * 64>(p, s_bk);
   lds_barrier();
   PBA_STK(0);
 
@@ -720,92 +1015,8 @@ void k_sample(SampleParams p_in) {
   double X[3] = {0.0, 0.0, 0.0};
   double bs_mcc = 0.0, bs_st2 = 0.0, bs_x2 = 0.0;
   if (FUSED) {
-    // ---- phase 0: back-substitution for this workgroup's points ----------------------------------------
-    // delta_p = -P (g_p + sum_l W_l^T delta_c[slot_l]),  W_l^T delta_c = Ap^T M' (Ac delta_c)
-    double* s_bs = reinterpret_cast<double*>(&s_tex[0][0]);       // [WAVES * 64][3], reused before the staging
-    const int half = threadIdx.x >> 7, lt = threadIdx.x & 127;
-    const int4 ti = ti_f;
-    active = lt < ti.y;
-    obs = ti.x + lt;
-    int l0 = 0, cnt = 0;
-    double c3[3] = {0.0, 0.0, 0.0};
-    double pr[12], spk[3] = {1.0, 1.0, 1.0};
-#pragma unroll
-    for (int k = 0; k < 12; ++k) pr[k] = 0.0;
-    if (active) {
-      pt = pt_f;
-      slot = slot_f;
-      l0 = l0_f; cnt = cnt_f;
-      const double* xsrc = p.skip_backsub ? p.xyz : p.xyz_prev;
-      X[0] = xsrc[3 * (size_t)pt]; X[1] = xsrc[3 * (size_t)pt + 1]; X[2] = xsrc[3 * (size_t)pt + 2];
-      // issued here (same dependency level as X) so that they are in flight across the barrier below
-      if (!p.skip_backsub) {
-#pragma unroll
-      for (int k = 0; k < 12; ++k) pr[k] = p.ptrec[12 * (size_t)pt + k];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) spk[k] = p.sp[3 * (size_t)pt + k];
-      }
-      const double* bk = s_bk + kBk * slot;
-      if (!p.skip_backsub && bk[24] >= 0.0) {
-        // xw = R X + t (plain order: this point only feeds the derivative of the projection, not a sampled position)
-        const double xw0 = bk[0] * X[0] + bk[1] * X[1] + bk[2] * X[2] + bk[9];
-        const double xw1 = bk[3] * X[0] + bk[4] * X[1] + bk[5] * X[2] + bk[10];
-        const double xw2 = bk[6] * X[0] + bk[7] * X[1] + bk[8] * X[2] + bk[11];
-        const double iz = fast_rcp(xw2);
-        const double ju0 = p.fx * iz, ju2 = -p.fx * xw0 * iz * iz;
-        const double jv1 = p.fy * iz, jv2 = -p.fy * xw1 * iz * iz;
-        // Ac dc = dpi (Omega X + dt)
-        const double s0 = bk[12] * X[0] + bk[13] * X[1] + bk[14] * X[2] + bk[21];
-        const double s1 = bk[15] * X[0] + bk[16] * X[1] + bk[17] * X[2] + bk[22];
-        const double s2 = bk[18] * X[0] + bk[19] * X[1] + bk[20] * X[2] + bk[23];
-        const double t0 = ju0 * s0 + ju2 * s2, t1 = jv1 * s1 + jv2 * s2;
-        const double m0 = p.rec_prev[0 * p.rec_stride + obs], m1 = p.rec_prev[1 * p.rec_stride + obs], m2 = p.rec_prev[2 * p.rec_stride + obs];
-        const double u0 = m0 * t0 + m1 * t1, u1 = m1 * t0 + m2 * t1;
-        // W_l^T dc = Ap^T u = R^T (dpi^T u)
-        const double w0 = ju0 * u0, w1 = jv1 * u1, w2 = ju2 * u0 + jv2 * u1;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) c3[k] = bk[k] * w0 + bk[3 + k] * w1 + bk[6 + k] * w2;
-      }
-    }
-    s_bs[threadIdx.x * 3 + 0] = c3[0]; s_bs[threadIdx.x * 3 + 1] = c3[1]; s_bs[threadIdx.x * 3 + 2] = c3[2];
-    lds_barrier();
-    if (active && !p.skip_backsub) {
-      double acc[3] = {0.0, 0.0, 0.0};
-      const double* src = s_bs + (half * 128 + l0) * 3;
-      // four observations per trip, their twelve LDS reads in flight together (one dependent read per trip otherwise);
-      // the adds keep the lane order
-      for (int lb = 0; lb < cnt; lb += 4) {
-        double x[4][3];
-#pragma unroll
-        for (int l = 0; l < 4; ++l) {
-          const int li = (lb + l < cnt) ? lb + l : cnt - 1;
-#pragma unroll
-          for (int k = 0; k < 3; ++k) x[l][k] = src[3 * li + k];
-        }
-#pragma unroll
-        for (int l = 0; l < 4; ++l) {
-          const bool in = lb + l < cnt;
-#pragma unroll
-          for (int k = 0; k < 3; ++k) acc[k] += in ? x[l][k] : 0.0;
-        }
-      }
-      const double q0 = pr[6] + acc[0], q1 = pr[7] + acc[1], q2 = pr[8] + acc[2];
-      const double d[3] = {-(pr[0] * q0 + pr[1] * q1 + pr[2] * q2), -(pr[1] * q0 + pr[3] * q1 + pr[4] * q2),
-                           -(pr[2] * q0 + pr[4] * q1 + pr[5] * q2)};
-      const bool head = (lt == l0);
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        if (head) {
-          const double sk = spk[k];
-          const double yk = -d[k] * fast_rcp(sk);             // step in Jacobi-scaled coordinates is -y
-          bs_mcc += 0.5 * yk * (sk * pr[6 + k]) + 0.5 * pr[9 + k] * yk * yk;
-          bs_st2 += d[k] * d[k];
-          bs_x2 += X[k] * X[k];
-          const_cast<double*>(p.xyz)[3 * (size_t)pt + k] = X[k] + d[k];
-        }
-        X[k] = X[k] + d[k];
-      }
-    }
+    // ---- phase 0: back-substitution for this workgroup's points (fused_backsub) ------------------------------
+    fused_backsub<WAVES * 64>(p, rays, fi, s_bk, reinterpret_cast<double*>(&s_tex[0][0]), pt, slot, obs, active, X, bs_mcc, bs_st2, bs_x2);
   } else if (active) {
     pt = p.obs_point[obs];
     slot = p.obs_slot[obs];
@@ -1285,41 +1496,17 @@ void k_sample(SampleParams p_in) {
     }
   }
   // deterministic block reductions: butterfly inside each wave, then the waves in order
-  constexpr int NTH = WAVES * 64;
-  constexpr int NQ = FUSED ? 4 : 1;
-  double red_out[NQ];
-  {
-    double v[NQ];
-    if (FUSED) {
-      double q4[4] = {cost_obs, bs_mcc, bs_st2, bs_x2};
-      wave_sum_n<4>(q4);
-      v[0] = q4[0]; v[NQ > 1 ? 1 : 0] = q4[1]; v[NQ > 2 ? 2 : 0] = q4[2]; v[NQ > 3 ? 3 : 0] = q4[3];
-    } else {
-      v[0] = wave_sum(cost_obs);
-    }
-    if (lane == 0) {
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) s_red[q * WAVES + wave] = v[q];
-    }
+  if (FUSED) {
+    fused_block_partials<WAVES>(p, bid, lane, wave, cost_obs, bs_mcc, bs_st2, bs_x2, s_red, s_fail);
+  } else {
+    const double v = wave_sum(cost_obs);
+    if (lane == 0) s_red[wave] = v;
     lds_barrier();
+    double a = 0.0;
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      double a = 0.0;
-#pragma unroll
-      for (int w = 0; w < WAVES; ++w) a += s_red[q * WAVES + w];
-      red_out[q] = a;
-    }
-  }
-  if (threadIdx.x == 0) {
-    if (FUSED) {
-      // consumed by the last workgroup of THIS launch: write-through stores; a non-finite block poisons its cost
-      store_agent(p.block_cost + bid, s_fail ? __longlong_as_double(0x7ff8000000000000ll) : red_out[0]);
-      store_agent(p.block_bs + 3 * bid, red_out[NQ > 1 ? 1 : 0]);
-      store_agent(p.block_bs + 3 * bid + 1, red_out[NQ > 2 ? 2 : 0]);
-      store_agent(p.block_bs + 3 * bid + 2, red_out[NQ > 3 ? 3 : 0]);
-      p.block_fail[bid] = s_fail;
-    } else {
-      p.block_cost[bid] = red_out[0];
+    for (int w = 0; w < WAVES; ++w) a += s_red[w];
+    if (threadIdx.x == 0) {
+      p.block_cost[bid] = a;
       p.block_fail[bid] = s_fail;
     }
   }
@@ -1328,74 +1515,7 @@ void k_sample(SampleParams p_in) {
   tk[0] |= (unsigned long long)(__builtin_amdgcn_s_getreg(6164) & 15u) << 56;   // HW_REG_XCC_ID[3:0]
   if (p.dbg && threadIdx.x == 0) for (int k = 0; k < 8; ++k) p.dbg[blockIdx.x * 8 + k] = tk[k];
 #undef PBA_STK
-  if (FUSED) {
-    // ---- step finalisation by the last workgroup to arrive (agent-scope release / acquire around the ticket) ----
-    __shared__ int s_last;
-    if (threadIdx.x == 0) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the write-through partials have left this CU
-      const unsigned t = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      s_last = (t == gridDim.x - 1) ? 1 : 0;
-    }
-    __syncthreads();
-    if (s_last) {
-      const unsigned long long t_fin0 = p.dbg ? __builtin_amdgcn_s_memrealtime() : 0;
-      int* s_f = &s_base[0][0];                              // [NTH] ints, free by now
-      double* s_r4 = reinterpret_cast<double*>(&s_tex[0][0]);   // [4][NTH] doubles, free by now
-      double a0 = 0, a1 = 0, a2 = 0, a3 = 0; int f = 0;
-      // 8 blocks' partials in flight per thread (every load misses this XCD's L2), summed in block order
-      for (int b0 = threadIdx.x; b0 < (int)gridDim.x; b0 += 8 * NTH) {
-        double v0[8], v1[8], v2[8], v3[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const int b = b0 + k * NTH;
-          const bool ok = b < (int)gridDim.x;
-          v0[k] = ok ? load_agent(p.block_bs + 3 * b) : 0.0;
-          v1[k] = ok ? load_agent(p.block_bs + 3 * b + 1) : 0.0;
-          v2[k] = ok ? load_agent(p.block_bs + 3 * b + 2) : 0.0;
-          v3[k] = ok ? load_agent(p.block_cost + b) : 0.0;
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { a0 += v0[k]; a1 += v1[k]; a2 += v2[k]; a3 += v3[k]; f |= (v3[k] != v3[k]) ? 1 : 0; }
-      }
-      const unsigned long long t_fin1 = p.dbg ? __builtin_amdgcn_s_memrealtime() : 0;
-      a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3);
-      f = __any(f) ? 1 : 0;
-      if (lane == 0) { s_r4[wave] = a0; s_r4[WAVES + wave] = a1; s_r4[2 * WAVES + wave] = a2; s_r4[3 * WAVES + wave] = a3; s_f[wave] = f; }
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        for (int w = 1; w < WAVES; ++w) {
-          s_r4[0] += s_r4[w]; s_r4[WAVES] += s_r4[WAVES + w]; s_r4[2 * WAVES] += s_r4[2 * WAVES + w]; s_r4[3 * WAVES] += s_r4[3 * WAVES + w];
-          s_f[0] |= s_f[w];
-        }
-      }
-      __syncthreads();
-      unsigned long long t_fin2 = 0, t_fin3 = 0;
-      if (threadIdx.x == 0) {
-        t_fin2 = p.dbg ? __builtin_amdgcn_s_memrealtime() : 0;
-        p.scal[kMccPts] = s_r4[0]; p.scal[kStep2Pts] = s_r4[WAVES]; p.scal[kX2Pts] = s_r4[2 * WAVES];
-        p.scal[kCandCost] = s_r4[3 * WAVES]; p.scal[kEvalFailCand] = (double)s_f[0];
-        *p.ticket = 0;
-        if (p.lm && p.decide) lm_decide(p.lm, p.scal, p.log, p.max_log, 0);
-        if (p.lm && p.decide && p.lm->done && p.lm->done_seq == 0) p.lm->done_seq = p.seq;
-        t_fin3 = p.dbg ? __builtin_amdgcn_s_memrealtime() : 0;
-      }
-      if (p.xchg) {
-        __syncthreads();
-        xchg_pack(p.scal, p.xchg, p.xchg_rank, p.xchg_world, threadIdx.x, NTH);
-      }
-      if (p.host_scal) {
-        __syncthreads();
-        lm_publish(p.lm, (p.lm && p.decide) ? p.host_state : nullptr, p.scal, p.host_scal, p.host_seq, p.seq, threadIdx.x, NTH);
-      }
-      if (p.dbg && threadIdx.x == 0) {
-        p.dbg[(size_t)gridDim.x * 8] = __builtin_amdgcn_s_memrealtime() - t_fin0;
-        p.dbg[(size_t)gridDim.x * 8 + 1] = t_fin0 - t_begin;
-        p.dbg[(size_t)gridDim.x * 8 + 2] = t_fin1 - t_fin0;      // partial loads
-        p.dbg[(size_t)gridDim.x * 8 + 3] = t_fin2 - t_fin1;      // block reduction
-        p.dbg[(size_t)gridDim.x * 8 + 4] = t_fin3 - t_fin2;      // decision
-      }
-    }
-  }
+  if (FUSED) fused_finalize<WAVES>(p, lane, wave, &s_base[0][0], reinterpret_cast<double*>(&s_tex[0][0]), t_begin);
 }
 
 // =====================================================================================================
@@ -1438,12 +1558,17 @@ __device__ __forceinline__ void sample_generic_mc(const float4* __restrict__ fra
 // The sampling pass over C channels: one lane per observation like k_sample; the channel loop is the outer (run time)
 // loop, inside it the footprint rows of that channel stream through LDS in batches and the lane accumulates the SAME six
 // sums across all channels in the reference's residual order (channel-major, photobundle.cc:708-722), because every
-// pixel of every channel shares the projection Jacobian A: M = sum_k sum_pix w^2 g g^T etc.  Unfused (host-driven LM
-// steps): this is the wide-descriptor path, not the headline one.
+// pixel of every channel shares the projection Jacobian A: M = sum_k sum_pix w^2 g g^T etc.
 constexpr int sample_mc_rows_per_batch(int R) { return (12 / (2 * R + 2)) > 0 ? 12 / (2 * R + 2) : 1; }
 
-template <int R, bool JAC, int WAVES>
-__global__ __launch_bounds__(WAVES * 64, 2) void k_sample_mc(SampleParams p, const float4* __restrict__ frames_mc, int n_channels) {
+//   FUSED: like k_sample's fused form -- back-substitution of the step for the workgroup's whole points first, sampling at
+//   the candidate it just formed, step finalisation (and, single rank, the trust-region decision) by the last workgroup.
+template <int R, bool JAC, int WAVES, bool FUSED>
+__global__ __launch_bounds__(WAVES * 64, 2) void k_sample_mc(SampleParams p_in, const float4* __restrict__ frames_mc, int n_channels) {
+  static_assert(!FUSED || (WAVES * 64) % 128 == 0, "fused tiles are 128 observations");
+  SampleParams p = p_in;
+  p.dbg = nullptr;
+  if (FUSED && !fused_resolve_parity(p)) return;
   constexpr int W = 2 * R + 1, F = 2 * R + 2;
   constexpr int RB = sample_mc_rows_per_batch(R);
   constexpr int NB = (F + RB - 1) / RB;
@@ -1451,21 +1576,37 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_sample_mc(SampleParams p, con
   constexpr int LSTRIDE = 65;
   constexpr int NPL = JAC ? 3 : 1;
   constexpr size_t kTexBytes = sizeof(uint32_t) * WAVES * NPL * FF * LSTRIDE;
-  constexpr size_t kPreBytes = kMaxFrames * sizeof(CamGeom);
+  constexpr size_t kBsBytes = FUSED ? sizeof(double) * 3 * WAVES * 64 : 0;      // back-substitution scratch ahead of the tables
+  constexpr size_t kPreBytes = kBsBytes + (FUSED ? 2 : 1) * kMaxFrames * sizeof(CamGeom);
+  static_assert(!FUSED || kTexBytes >= sizeof(double) * 4 * WAVES * 64, "the finalisation reuses the texel region");
   __shared__ __attribute__((aligned(16))) char s_raw[kTexBytes > kPreBytes ? kTexBytes : kPreBytes];
   float (*s_tex)[NPL * FF * LSTRIDE] = reinterpret_cast<float (*)[NPL * FF * LSTRIDE]>(s_raw);
   __shared__ int32_t s_base[WAVES][64];
-  __shared__ double s_red[WAVES];
+  __shared__ double s_red[4 * WAVES];
   __shared__ int32_t s_fail;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int obs = blockIdx.x * (WAVES * 64) + threadIdx.x;
-  const bool active = obs < p.n_obs;
+  const int bid = blockIdx.x;
+  int obs = blockIdx.x * (WAVES * 64) + threadIdx.x;
+  bool active = obs < p.n_obs;
   if (threadIdx.x == 0) s_fail = 0;
-  CamGeom* s_geom = reinterpret_cast<CamGeom*>(s_raw);
+  CamGeom* s_geom = reinterpret_cast<CamGeom*>(s_raw + kBsBytes);
+  double* s_bk = reinterpret_cast<double*>(s_geom + kMaxFrames);
+  FusedIdx fi{make_int4(0, 0, 0, 0), 0, 0, 0, 0};
+  if (FUSED) fi = fused_prefetch_indices<WAVES * 64>(p, bid);
   stage_geom<WAVES * 64>(p.geom, s_geom, p.n_frames, threadIdx.x);
+  if (FUSED) fused_stage_step_table<WAVES * 64>(p, s_bk);
   lds_barrier();
 
   int pt = 0, slot = 0;
+  double prm[3] = {0.0, 0.0, 0.0};
+  double bs_mcc = 0.0, bs_st2 = 0.0, bs_x2 = 0.0;
+  if (FUSED) {
+    fused_backsub<WAVES * 64>(p, p.rays, fi, s_bk, reinterpret_cast<double*>(s_raw), pt, slot, obs, active, prm, bs_mcc, bs_st2, bs_x2);
+  } else if (active) {
+    pt = p.obs_point[obs];
+    slot = p.obs_slot[obs];
+    prm[0] = p.xyz[3 * (size_t)pt]; prm[1] = p.xyz[3 * (size_t)pt + 1]; prm[2] = p.xyz[3 * (size_t)pt + 2];
+  }
   double u = 0.0, v = 0.0;
   int bx = 0, by = 0;
   bool regular = false;
@@ -1475,9 +1616,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_sample_mc(SampleParams p, con
   for (int j = 0; j < W; ++j) { dxs[j] = 1.f; dys[j] = 1.f; omdx[j] = 0.0; }
   const size_t npix = (size_t)p.rows * p.cols;
   if (active) {
-    pt = p.obs_point[obs];
-    slot = p.obs_slot[obs];
-    const double prm[3] = {p.xyz[3 * (size_t)pt], p.xyz[3 * (size_t)pt + 1], p.xyz[3 * (size_t)pt + 2]};
+    if (p.rays && !(prm[0] > 0.0)) atomicOr(&s_fail, 1);     // inverse-depth variant: rho <= 0 is an evaluation failure (k_sample)
     double X[3], qd[3];
     point_world(p.rays, pt, prm, X, qd);
     double xw[3];
@@ -1618,15 +1757,21 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_sample_mc(SampleParams p, con
       p.rec[5 * p.rec_stride + obs] = cost_obs;
     }
   }
-  const double ws = wave_sum(cost_obs);
-  if (lane == 0) s_red[wave] = ws;
-  lds_barrier();
-  if (threadIdx.x == 0) {
-    double a = 0.0;
+  if (FUSED) {
+    lds_barrier();        // every wave is done with the texel region / s_base before the finalisation reuses them
+    fused_block_partials<WAVES>(p, bid, lane, wave, cost_obs, bs_mcc, bs_st2, bs_x2, s_red, s_fail);
+    fused_finalize<WAVES>(p, lane, wave, &s_base[0][0], reinterpret_cast<double*>(s_raw), 0ull);
+  } else {
+    const double ws = wave_sum(cost_obs);
+    if (lane == 0) s_red[wave] = ws;
+    lds_barrier();
+    if (threadIdx.x == 0) {
+      double a = 0.0;
 #pragma unroll
-    for (int w = 0; w < WAVES; ++w) a += s_red[w];
-    p.block_cost[blockIdx.x] = a;
-    p.block_fail[blockIdx.x] = s_fail;
+      for (int w = 0; w < WAVES; ++w) a += s_red[w];
+      p.block_cost[blockIdx.x] = a;
+      p.block_fail[blockIdx.x] = s_fail;
+    }
   }
 }
 
@@ -2107,7 +2252,8 @@ __global__ __launch_bounds__(1024) void k_reduce_final(const double* __restrict_
                                                         const int32_t* __restrict__ block_fail, int n_cost_blocks,
                                                         double* __restrict__ packed, double* __restrict__ scal,
                                                         const LmState* lm, int enq_cur, const double* block_cost_alt,
-                                                        const int32_t* block_fail_alt, int final_pass) {
+                                                        const int32_t* block_fail_alt, int final_pass, int sys_stores) {
+  // sys_stores: `packed` is this rank's peer-exchange mailbox (read by other devices): write-through, cache-bypassing stores
   if (lm) {
     if (lm->done && !final_pass) return;
     if (final_pass && !lm_final_pass_needed(lm)) return;
@@ -2150,9 +2296,9 @@ __global__ __launch_bounds__(1024) void k_reduce_final(const double* __restrict_
       double v = s_red[0][ex];
 #pragma unroll
       for (int w = 1; w < 1024 / 64; ++w) v = is_max ? fmax(v, s_red[w][ex]) : v + s_red[w][ex];
-      if (e < stride - 3) packed[e] = v;
+      if (e < stride - 3) { if (sys_stores) store_system_f64(packed + e, v); else packed[e] = v; }
       else if (e == stride - 3) scal[kGmaxPts] = v;
-      else if (e == stride - 2) packed[stride - 2] = v;
+      else if (e == stride - 2) { if (sys_stores) store_system_f64(packed + stride - 2, v); else packed[stride - 2] = v; }
       else scal[kSchurFail] = v;
     }
   } else {
@@ -2164,7 +2310,7 @@ __global__ __launch_bounds__(1024) void k_reduce_final(const double* __restrict_
     flat[tid] = acc; s_f[tid] = f;
     __syncthreads();
     for (int s = 512; s > 0; s >>= 1) { if (tid < s) { flat[tid] += flat[tid + s]; s_f[tid] |= s_f[tid + s]; } __syncthreads(); }
-    if (tid == 0) { packed[stride - 3] = flat[0]; scal[kEvalFailLin] = (double)s_f[0]; }
+    if (tid == 0) { if (sys_stores) store_system_f64(packed + stride - 3, flat[0]); else packed[stride - 3] = flat[0]; scal[kEvalFailLin] = (double)s_f[0]; }
   }
 }
 
@@ -2625,6 +2771,495 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve_generic(SolveParams p_i
     __syncthreads();
   }
   solve_epilogue<kSolveThreads>(p, n, y, sc, D2, gcs, gc, s_ok != 0, tid);
+}
+
+// =====================================================================================================
+// Blocked dense factorisation of the reduced camera system on one 256-thread workgroup (any n = 6 nf <= 96).
+//
+// The one-wave kernels above walk 6 nf dependent columns (42 at BASELINE configs[1], 90 at configs[3]) through ~50 KB of
+// straight-line code; this one walks nf dependent PANELS of six columns with a small loop body, square-root free
+// (S = L D L^T, unit lower L: the pivot chain is reciprocal + multiply instead of reciprocal square root + two products):
+//   phase A (one thread per row at / below the panel, the right-hand side riding along as row n of the augmented matrix
+//            [S y; y^T .] -- its factor row is D^-1 L^-1 y, so the forward substitution and the diagonal scaling cost
+//            nothing extra): every thread factorises the 6x6 diagonal block itself (21 broadcast LDS reads, a chain of
+//            six reciprocals) and solves its own row of the panel against it; it keeps the row both unscaled (w = l d,
+//            for its own trailing updates) and scaled (l, what the other rows read);
+//   phase B (one thread per (row, 6-column block) of the trailing matrix): A_rc -= sum_m w_rm l_cm over the panel, 36 FMAs;
+// two workgroup barriers per panel.  Backward substitution L^T x = z runs panel by panel from the bottom (one barrier each):
+// every thread solves the 6x6 unit-triangular system of the panel itself and removes its contribution from its own unknown.
+// Replaces Ceres' dense Cholesky of the reduced system (SchurComplementSolver, reference src/photobundle.cc:743, :829).
+// =====================================================================================================
+constexpr int kSolveBlockedThreads = 256;
+constexpr int kSolveNarrowFree = 8;          // free cameras up to which four waves hold every phase-B item in one round
+__host__ __device__ inline size_t solve_blocked_smem_bytes(int n) {
+  // augmented matrix (n + 1) x (n + 1) | unscaled panel rows (n + 1) x 6 | xs, sc, D2, gcs, gc, dd (n each) | item table
+  const size_t items = (size_t)(n / 6) * (size_t)(n + 1);      // upper bound of the phase-B work items
+  return sizeof(double) * ((size_t)(n + 1) * (n + 1) + 6 * (size_t)(n + 1) + 6 * (size_t)n + 8) + sizeof(uint32_t) * items;
+}
+
+// LOADER: plain loads (the packed sums were produced by an earlier kernel / the all-reduce) or agent-scope loads (they
+// were produced by other workgroups of THIS launch, k_reduce_solve).
+template <bool AGENT>
+__device__ __forceinline__ double packed_load(const double* p) { return AGENT ? load_agent(p) : *p; }
+
+// Candidate camera geometry with the work of one camera spread over 32 lanes (cam_geom_one is ~400 dependent-ish fp64
+// operations in one lane; here every lane repeats the short scalar part -- angle, sine, cosine -- and then produces
+// its own entries of R, B and dR).  Same formulas and operand order as cam_geom_one entry by entry.
+__device__ inline void cam_geom_spread(const double cam6[6], CamGeom* __restrict__ out, int c, int fixed_slot, int sub) {
+  const double wx = cam6[0], wy = cam6[1], wz = cam6[2];
+  const double theta2 = wx * wx + wy * wy + wz * wz;
+  const bool rod = theta2 > DBL_EPSILON;
+  CamGeom& g = out[c];
+  if (sub < 3) { g.aa[sub] = cam6[sub]; g.t[sub] = cam6[3 + sub]; }
+  if (sub == 3) {
+    g.rodrigues = rod; g.is_free = (c != fixed_slot);
+    g.free_index = (c == fixed_slot) ? -1 : (fixed_slot >= 0 && c > fixed_slot ? c - 1 : c);
+    g.pad = 0;
+  }
+  if (rod) {
+    const double theta = sqrt(theta2);
+    double ct, st;
+    sincos_angle(theta, st, ct);
+    const double ti = 1.0 / theta;
+    const double ax = wx * ti, ay = wy * ti, az = wz * ti;
+    const double oc = 1.0 - ct;
+    const double R[9] = {ct + ax * ax * oc,      ax * ay * oc - az * st, ay * st + ax * az * oc,
+                         az * st + ax * ay * oc, ct + ay * ay * oc,      -ax * st + ay * az * oc,
+                         -ay * st + ax * az * oc, ax * st + ay * az * oc, ct + az * az * oc};
+    if (sub < 3) g.w[sub] = (sub == 0) ? ax : (sub == 1 ? ay : az);
+    if (sub == 4) { g.ct = ct; g.st = st; }
+    if (sub < 9) { double r = R[0]; for (int k = 1; k < 9; ++k) r = (sub == k) ? R[k] : r; g.R[sub] = r; }
+    if (sub < 27) {
+      // dR[9 k + 3 i + j] = sum_m R[3 i + m] * Bx_k[3 m + j],  Bx_k = [column k of B]x
+      const int k = sub / 9, ij = sub - 9 * k, i = ij / 3, j = ij - 3 * i;
+      const double W[3] = {wx, wy, wz};
+      const double Wx[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
+      double bcol[3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        // B[3 r + k] for the lane's k
+        double acc = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk) {
+          if (kk != k) continue;
+          acc = W[r] * W[kk];
+#pragma unroll
+          for (int q = 0; q < 3; ++q) acc += (R[3 * q + r] - (r == q ? 1.0 : 0.0)) * Wx[3 * q + kk];
+        }
+        bcol[r] = acc / theta2;
+      }
+      const double b0 = bcol[0], b1 = bcol[1], b2 = bcol[2];
+      const double Bx[9] = {0, -b2, b1, b2, 0, -b0, -b1, b0, 0};
+      double acc = 0.0;
+#pragma unroll
+      for (int ii = 0; ii < 3; ++ii) {
+        if (ii != i) continue;
+#pragma unroll
+        for (int jj = 0; jj < 3; ++jj) {
+          if (jj != j) continue;
+          acc = 0.0;
+#pragma unroll
+          for (int m = 0; m < 3; ++m) acc += R[3 * ii + m] * Bx[3 * m + jj];
+        }
+      }
+      g.dR[sub] = acc;
+    }
+  } else {
+    if (sub < 3) g.w[sub] = 0.0;
+    if (sub == 4) { g.ct = 1.0; g.st = 0.0; }
+    const double R[9] = {1, -wz, wy, wz, 1, -wx, -wy, wx, 1};
+    if (sub < 9) { double r = R[0]; for (int k = 1; k < 9; ++k) r = (sub == k) ? R[k] : r; g.R[sub] = r; }
+    if (sub < 27) {
+      const int k = sub / 9, m = sub - 9 * k;
+      const double e0 = (k == 0), e1 = (k == 1), e2 = (k == 2);
+      const double Ex[9] = {0, -e2, e1, e2, 0, -e0, -e1, e0, 0};
+      double r = Ex[0];
+      for (int q = 1; q < 9; ++q) r = (m == q) ? Ex[q] : r;
+      g.dR[sub] = r;
+    }
+  }
+}
+
+// T threads: 256 (four waves) up to eight free cameras, 1024 beyond (phase B of a 90 x 90 system has up to 644 work items)
+template <bool AGENT, int T>
+__device__ inline void solve_blocked(SolveParams& p, double* smem, int tid) {
+  const int nf = p.n_free;
+  const int n = 6 * nf;
+  const int ld = n + 1;                       // odd: consecutive rows start in different banks
+  double* A = smem;                           // [(n + 1)][ld] lower triangle + rhs row n
+  double* Wp = A + (size_t)(n + 1) * ld;      // [(n + 1)][6] the current panel's rows, unscaled (l d)
+  double* xs = Wp + (size_t)(n + 1) * 6;      // solution of the scaled system
+  double* sc = xs + n;
+  double* D2 = sc + n;
+  double* gcs = D2 + n;
+  double* gc = gcs + n;
+  double* dd = gc + n;                        // (unused slot kept for alignment of the item table)
+  uint32_t* items = reinterpret_cast<uint32_t*>(dd + n + 2);   // phase-B work items: row | block column << 16
+  __shared__ int s_ok;
+  __shared__ int s_item_start[kMaxFrames + 1];
+  __shared__ double s_cams[6 * kMaxFrames];     // current cameras and their free indices: requested with the first round trip,
+  __shared__ int s_free[kMaxFrames];            // consumed by the epilogue (which then has no global load on its path)
+  const int nT = 36 * p.n_pairs;
+  const double* src = p.packed;
+  unsigned long long ts[6] = {0, 0, 0, 0, 0, 0}, tsa = 0, tsb = 0, tsp[3] = {0, 0, 0}, tsl = 0;
+#define PBA_TS(k) do { if (PBA_PHASE_TIMING) ts[k] = __builtin_amdgcn_s_memtime(); } while (0)
+  PBA_TS(0);
+  // ---- prologue: scale / damp / scatter the packed pair blocks (one global round trip) --------------------------
+  double val0[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) { const int e = tid + u * T; val0[u] = (e < nT) ? packed_load<AGENT>(src + e) : 0.0; }
+  // every global load of the prologue is issued before the first one is consumed: ONE round trip
+  const double cam_v = (tid < 6 * p.n_frames) ? p.cams[tid] : 0.0;
+  const int free_v = (tid < p.n_frames) ? p.geom[tid].free_index : -1;
+  static_assert(T >= 6 * kMaxFrames, "one thread per reduced-system row");
+  double du = 0.0, g = 0.0, y0 = 0.0, s_old = 1.0;
+  if (tid < n) {
+    du = packed_load<AGENT>(src + nT + 2 * n + tid);
+    g = packed_load<AGENT>(src + nT + n + tid);
+    y0 = packed_load<AGENT>(src + nT + tid);
+    if (!p.init_scale) s_old = p.sc[tid];
+  }
+  if (tid < 6 * p.n_frames) s_cams[tid] = cam_v;
+  if (tid < p.n_frames) s_free[tid] = free_v;
+  if (tid < n) {
+    const int i = tid;
+    double s;
+    if (p.init_scale) { s = p.jacobi ? 1.0 / (1.0 + sqrt(du)) : 1.0; p.sc[i] = s; p.sc[n + i] = du > 0.0 ? 1.0 : 0.0; }
+    else s = s_old;
+    sc[i] = s;
+    D2[i] = fmin(fmax(s * s * du, p.min_diag), p.max_diag) / p.radius;
+    gc[i] = g;
+    gcs[i] = s * g;
+    A[(size_t)n * ld + i] = s * y0;
+  }
+  if (PBA_PHASE_TIMING) tsp[0] = __builtin_amdgcn_s_memtime();
+  __shared__ unsigned char s_pa[kMaxFrames * (kMaxFrames + 1) / 2], s_pb[kMaxFrames * (kMaxFrames + 1) / 2];
+  for (int pr = tid; pr < p.n_pairs; pr += T) {
+    int a = 0, rem = pr;
+    while (rem >= nf - a) { rem -= nf - a; ++a; }
+    s_pa[pr] = (unsigned char)a; s_pb[pr] = (unsigned char)(a + rem);
+  }
+  // phase-B item table, ordered by block column j = 1 .. nf - 1 (the items of panel k are the suffix j > k): rows 6 j .. n
+  if (tid <= nf) {
+    int start = 0;
+    for (int j = 1; j < tid; ++j) start += n - 6 * j + 1;      // items of block columns 1 .. tid - 1
+    s_item_start[tid] = start;                                    // [j] = first item of block column j (j >= 1)
+  }
+  if (tid == 0) s_ok = 1;
+  __syncthreads();
+  if (PBA_PHASE_TIMING) tsp[1] = __builtin_amdgcn_s_memtime();
+  for (int j = 1; j < nf; ++j) {
+    const int base = s_item_start[j];
+    for (int r = 6 * j + tid; r <= n; r += T) items[base + (r - 6 * j)] = (uint32_t)r | ((uint32_t)j << 16);
+  }
+  for (int e0 = tid; e0 < nT; e0 += 4 * T) {
+    double val[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int e = e0 + u * T; val[u] = (e0 == tid) ? val0[u] : ((e < nT) ? packed_load<AGENT>(src + e) : 0.0); }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = e0 + u * T;
+      if (e >= nT) continue;
+      const int pair = e / 36, k = e - pair * 36;
+      const int i = k / 6, j = k - i * 6;
+      const int a = s_pa[pair], b = s_pb[pair];
+      const int r = 6 * a + i, c = 6 * b + j;       // block (a, b), a <= b: entry (r, c) of the upper triangle / diagonal block
+      double v = sc[r] * val[u] * sc[c];
+      if (r == c) v += D2[r];
+      if (a != b) A[(size_t)c * ld + r] = v;        // mirrored into the lower triangle
+      else if (c >= r) A[(size_t)c * ld + r] = v;   // diagonal blocks: the upper triangle is the one that is kept (as in solve_prologue)
+    }
+  }
+  __syncthreads();
+  if (p.S_dbg) {
+    for (int k = tid; k < n * n; k += T) { const int r = k / n, c = k - r * n; p.S_dbg[k] = (r >= c) ? A[(size_t)r * ld + c] : A[(size_t)c * ld + r]; }
+    for (int i = tid; i < n; i += T) p.rhs_dbg[i] = A[(size_t)n * ld + i];
+    __syncthreads();
+  }
+  const int n_items = (nf > 1) ? s_item_start[nf - 1] + (n - 6 * (nf - 1) + 1) : 0;
+  PBA_TS(1);
+  if (!(p.final_pass && !p.init_scale)) {
+    // ---- factorisation S = L D L^T (unit lower L in A, the rhs row ends up as D^-1 L^-1 y) ---------------------------
+    for (int k = 0; k < nf; ++k) {
+      const int c0 = 6 * k;
+      if (PBA_PHASE_TIMING) tsl = __builtin_amdgcn_s_memtime();
+      for (int r = c0 + tid; r <= n; r += T) {
+        double Wd[21], Lt[21];      // diagonal block: unscaled (w = l d) and scaled entries, lower triangle packed i (i + 1) / 2 + m
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+          for (int m = 0; m <= i; ++m) Wd[i * (i + 1) / 2 + m] = A[(size_t)(c0 + i) * ld + c0 + m];
+        double a[6];
+#pragma unroll
+        for (int m = 0; m < 6; ++m) a[m] = A[(size_t)r * ld + c0 + m];
+        double rd[6];
+        bool pd = true;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          // column j of the block: w_ij = a_ij - sum_{m<j} w_im l_jm (i >= j), d_j = w_jj, l_ij = w_ij / d_j
+#pragma unroll
+          for (int i = j; i < 6; ++i) {
+            double v = Wd[i * (i + 1) / 2 + j];
+#pragma unroll
+            for (int m = 0; m < j; ++m) v = fma(-Wd[i * (i + 1) / 2 + m], Lt[j * (j + 1) / 2 + m], v);
+            Wd[i * (i + 1) / 2 + j] = v;
+          }
+          const double d = Wd[j * (j + 1) / 2 + j];
+          const bool ok = (d > 0.0) && isfinite(d);
+          pd = pd && ok;
+          rd[j] = fast_rcp(ok ? d : 1.0);
+#pragma unroll
+          for (int i = j + 1; i < 6; ++i) Lt[i * (i + 1) / 2 + j] = Wd[i * (i + 1) / 2 + j] * rd[j];
+        }
+        // this row of the panel: w_j = a_j - sum_{m<j} w_m l_jm, l_j = w_j / d_j  (for the six rows of the diagonal block
+        // this repeats the recurrence above: l = 1 on the diagonal; entries right of it are never read)
+        double w[6], l[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          double v = a[j];
+#pragma unroll
+          for (int m = 0; m < j; ++m) v = fma(-w[m], Lt[j * (j + 1) / 2 + m], v);
+          w[j] = v;
+          l[j] = v * rd[j];
+        }
+#pragma unroll
+        for (int m = 0; m < 6; ++m) { A[(size_t)r * ld + c0 + m] = l[m]; Wp[(size_t)r * 6 + m] = w[m]; }
+        if (r == c0 && !pd) s_ok = 0;
+      }
+      __syncthreads();
+      if (PBA_PHASE_TIMING) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); tsa += tn - tsl; tsl = tn; }
+      if (k + 1 < nf) {
+        for (int it = s_item_start[k + 1] + tid; it < n_items; it += T) {
+          const uint32_t wd = items[it];
+          const int r = (int)(wd & 0xffffu), j = (int)(wd >> 16);
+          double wr[6], lc[36], acc[6];
+#pragma unroll
+          for (int m = 0; m < 6; ++m) wr[m] = Wp[(size_t)r * 6 + m];
+#pragma unroll
+          for (int e = 0; e < 6; ++e)
+#pragma unroll
+            for (int m = 0; m < 6; ++m) lc[6 * e + m] = A[(size_t)(6 * j + e) * ld + c0 + m];
+#pragma unroll
+          for (int e = 0; e < 6; ++e) acc[e] = A[(size_t)r * ld + 6 * j + e];
+#pragma unroll
+          for (int e = 0; e < 6; ++e)
+#pragma unroll
+            for (int m = 0; m < 6; ++m) acc[e] = fma(-wr[m], lc[6 * e + m], acc[e]);
+#pragma unroll
+          for (int e = 0; e < 6; ++e) A[(size_t)r * ld + 6 * j + e] = acc[e];
+        }
+        __syncthreads();
+        if (PBA_PHASE_TIMING) tsb += __builtin_amdgcn_s_memtime() - tsl;
+      }
+    }
+    PBA_TS(2);
+    // ---- backward substitution L^T x = z, z = row n (already D^-1 L^-1 y), L unit lower --------------------------------
+    {
+      for (int k = nf - 1; k >= 0; --k) {
+        const int c0 = 6 * k;
+        if (tid < c0 + 6) {
+          double L[21], z[6], x[6];
+#pragma unroll
+          for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int m = 0; m < i; ++m) L[i * (i + 1) / 2 + m] = A[(size_t)(c0 + i) * ld + c0 + m];
+#pragma unroll
+          for (int m = 0; m < 6; ++m) z[m] = A[(size_t)n * ld + c0 + m];
+#pragma unroll
+          for (int j = 5; j >= 0; --j) {
+            double v = z[j];
+#pragma unroll
+            for (int m = 5; m > j; --m) v = fma(-L[m * (m + 1) / 2 + j], x[m], v);
+            x[j] = v;
+          }
+          if (tid < c0) {
+            double zc = A[(size_t)n * ld + tid];
+#pragma unroll
+            for (int m = 0; m < 6; ++m) zc = fma(-A[(size_t)(c0 + m) * ld + tid], x[m], zc);
+            A[(size_t)n * ld + tid] = zc;
+          } else {
+            double xv = x[0];
+#pragma unroll
+            for (int m = 1; m < 6; ++m) xv = (tid - c0 == m) ? x[m] : xv;
+            xs[tid] = xv;
+          }
+        }
+        __syncthreads();
+      }
+    }
+  } else {
+    for (int i = tid; i < n; i += T) xs[i] = 0.0;
+    __syncthreads();
+  }
+  PBA_TS(3);
+  // ---- epilogue (camera step, candidate cameras + geometry, replicated scalars) -----------------------------------
+  const bool chol_ok = s_ok != 0;
+  if (tid < 6 * p.n_frames && !(p.final_pass && !p.init_scale)) {
+    const int slot = tid / 6, k = tid % 6;
+    const int fa = s_free[slot];
+    double d = 0.0;
+    if (fa >= 0) d = -sc[6 * fa + k] * xs[6 * fa + k];
+    p.delta_c[tid] = d;
+    p.cams_cand[tid] = s_cams[tid] + d;
+  }
+  if (p.geom_cand) {
+    // candidate camera geometry: 32 lanes per camera, eight cameras per pass
+    for (int c = tid / 32; c < p.n_frames; c += T / 32) {
+      double cam6[6];
+      const int fa = s_free[c];
+      for (int k = 0; k < 6; ++k) cam6[k] = s_cams[6 * c + k] + (fa >= 0 ? -sc[6 * fa + k] * xs[6 * fa + k] : 0.0);
+      cam_geom_spread(cam6, p.geom_cand, c, p.fixed_slot, tid & 31);
+    }
+  }
+  if (tid < 64) {
+    double mcc = 0.0, st2 = 0.0, x2 = 0.0, gmax = 0.0, gn2 = 0.0, bad = 0.0;
+    for (int i = tid; i < n; i += 64) {
+      mcc += 0.5 * xs[i] * gcs[i] + 0.5 * D2[i] * xs[i] * xs[i];
+      const double d = sc[i] * xs[i];
+      st2 += d * d;
+      gmax = fmax(gmax, fabs(gc[i]));
+      gn2 += gc[i] * gc[i];
+      if (!isfinite(xs[i])) bad = 1.0;
+    }
+    for (int i = tid; i < 6 * p.n_frames; i += 64) {
+      const int fa = s_free[i / 6];
+      if (fa < 0) continue;
+      const double* live = p.sc + n + 6 * fa;
+      if (live[0] + live[1] + live[2] + live[3] + live[4] + live[5] > 0.0) x2 += s_cams[i] * s_cams[i];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      mcc += __shfl_xor(mcc, off); st2 += __shfl_xor(st2, off); x2 += __shfl_xor(x2, off);
+      gn2 += __shfl_xor(gn2, off); gmax = fmax(gmax, __shfl_xor(gmax, off)); bad = fmax(bad, __shfl_xor(bad, off));
+    }
+    if (tid == 0) {
+      p.scal[kMccCams] = mcc; p.scal[kStep2Cams] = st2; p.scal[kX2Cams] = x2;
+      p.scal[kGmaxCams] = gmax; p.scal[kGnorm2Cams] = gn2;
+      p.scal[kSolveOk] = (chol_ok && bad == 0.0) ? 1.0 : 0.0;
+      p.scal[kCostLin] = packed_load<AGENT>(p.packed + p.stride - 3);
+      p.scal[kGnorm2Pts] = packed_load<AGENT>(p.packed + p.stride - 2);
+    }
+  }
+  PBA_TS(4);
+  if (PBA_PHASE_TIMING && p.dbg && tid == T - 1)
+    printf("solve_blocked n %d cycles: prologue %llu (first round trip %llu, tables %llu, scatter %llu) factorisation %llu (phase A %llu, phase B %llu) substitution %llu epilogue (geometry lane) %llu\n",
+           n, ts[1] - ts[0], tsp[0] - ts[0], tsp[1] - tsp[0], ts[1] - tsp[1], ts[2] - ts[1], tsa, tsb, ts[3] - ts[2], ts[4] - ts[3]);
+#undef PBA_TS
+}
+
+// The reduced solve as its own launch: multi-rank steps (the all-reduce of the packed sums sits between the reduction
+// and the solve) and the PBA_FUSE_SOLVE=0 diagnostics path.
+template <int T>
+__global__ __launch_bounds__(T) void k_solve_blocked(SolveParams p_in) {
+  SolveParams p = p_in;
+  if (!solve_resolve(p)) return;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  solve_blocked<false, T>(p, reinterpret_cast<double*>(smem), threadIdx.x);
+}
+
+// Reduction of the per-workgroup Schur partials AND the reduced solve in ONE launch (single-rank steps): the workgroups
+// reduce kReduceEntries packed entries each exactly like k_reduce_final (same sums, same order, same bits), publish
+// them with agent-scope (write-through) stores and take a ticket; the LAST workgroup to arrive keeps its first four
+// waves and runs the blocked solve on the packed sums it reads back with agent-scope loads.  Saves a launch (its drain
+// + ramp-up and a cold instruction cache) per LM iteration.
+struct ReduceSolveParams {
+  const double* partial; int32_t n_blocks, stride;
+  const double* block_cost; const int32_t* block_fail; int32_t n_cost_blocks;
+  const double* block_cost_alt; const int32_t* block_fail_alt;
+  double* packed; double* scal;
+  unsigned int* ticket;          // zero between launches
+  SolveParams so;                // lm / enq_cur / final_pass of the step live here
+};
+
+__global__ __launch_bounds__(1024) void k_reduce_solve(ReduceSolveParams rp) {
+  const LmState* lm = rp.so.lm;
+  const double* block_cost = rp.block_cost;
+  const int32_t* block_fail = rp.block_fail;
+  if (lm) {
+    if (lm->done && !rp.so.final_pass) return;
+    if (rp.so.final_pass && !lm_final_pass_needed(lm)) return;
+    if (lm->cur != rp.so.enq_cur) { block_cost = rp.block_cost_alt; block_fail = rp.block_fail_alt; }
+  }
+  extern __shared__ __attribute__((aligned(16))) char dyn_smem[];      // the solve's matrix (last workgroup only)
+  const unsigned long long t_k0 = PBA_PHASE_TIMING ? __builtin_amdgcn_s_memrealtime() : 0ull;
+  constexpr int EX = kReduceEntries, SUB = 1024 / EX;
+  __shared__ double s_red[SUB][EX + 1];
+  __shared__ int s_f[1024];
+  __shared__ int s_last;
+  const int tid = threadIdx.x;
+  const int ex = tid % EX, sub = tid / EX;
+  const int stride = rp.stride, n_blocks = rp.n_blocks;
+  if ((int)blockIdx.x < (int)gridDim.x - 1) {
+    const int e = blockIdx.x * EX + ex;
+    const bool valid = e < stride;
+    const bool is_max = (e == stride - 3) || (e == stride - 1);
+    double acc = 0.0;
+    if (valid) {
+      for (int b = sub; b < n_blocks; b += 16 * SUB) {
+        double v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          const int bb = b + SUB * k;
+          v[k] = (bb < n_blocks) ? rp.partial[(size_t)bb * stride + e] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc = is_max ? fmax(acc, v[k]) : acc + v[k];
+      }
+    }
+    static_assert(EX == 16, "lane = 16 (sub % 4) + ex");
+#pragma unroll
+    for (int off = 16; off <= 32; off <<= 1) {
+      const double o = __shfl_xor(acc, off);
+      acc = is_max ? fmax(acc, o) : acc + o;
+    }
+    if ((tid & 63) < EX) s_red[tid >> 6][ex] = acc;
+    __syncthreads();
+    if (sub == 0 && valid) {
+      double v = s_red[0][ex];
+#pragma unroll
+      for (int w = 1; w < 1024 / 64; ++w) v = is_max ? fmax(v, s_red[w][ex]) : v + s_red[w][ex];
+      if (e < stride - 3) store_agent(rp.packed + e, v);
+      else if (e == stride - 3) rp.scal[kGmaxPts] = v;
+      else if (e == stride - 2) store_agent(rp.packed + stride - 2, v);
+      else rp.scal[kSchurFail] = v;
+    }
+  } else {
+    static_assert(SUB * (EX + 1) >= 1024, "flat view");
+    double* flat = &s_red[0][0];
+    double acc = 0.0; int f = 0;
+    for (int b = tid; b < rp.n_cost_blocks; b += 1024) { acc += block_cost[b]; f |= block_fail[b]; }
+    flat[tid] = acc; s_f[tid] = f;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) { if (tid < s) { flat[tid] += flat[tid + s]; s_f[tid] |= s_f[tid + s]; } __syncthreads(); }
+    if (tid == 0) { store_agent(rp.packed + stride - 3, flat[0]); rp.scal[kEvalFailLin] = (double)s_f[0]; }
+  }
+  // ---- ticket: the last workgroup to arrive solves ----------------------------------------------------------------
+  // every storing thread waits until its write-through stores have left the CU, then the workgroup takes its ticket
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned t = __hip_atomic_fetch_add(rp.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = (t == gridDim.x - 1) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  const bool wide = rp.so.n_free > kSolveNarrowFree;
+  if (!wide && tid >= kSolveBlockedThreads) return;   // twelve of the sixteen waves leave; barriers below count the remaining four
+  if (tid == 0) *rp.ticket = 0;
+  const unsigned long long t_k1 = PBA_PHASE_TIMING ? __builtin_amdgcn_s_memrealtime() : 0ull;
+  SolveParams so = rp.so;
+  if (so.lm) {
+    if (so.lm->cur != so.enq_cur) {
+      so.cams = so.cams_alt; so.cams_cand = so.cams_cand_alt; so.geom = so.geom_alt;
+      if (so.geom_cand) so.geom_cand = so.geom_cand_alt;
+    }
+    so.radius = so.lm->radius;
+  }
+  if (wide) solve_blocked<true, 1024>(so, reinterpret_cast<double*>(dyn_smem), tid);
+  else solve_blocked<true, kSolveBlockedThreads>(so, reinterpret_cast<double*>(dyn_smem), tid);
+  if (PBA_PHASE_TIMING && rp.so.dbg && tid == 0)
+    printf("k_reduce_solve: last workgroup %d of %d reached the solve %.2f us after its own start, finished it %.2f us later\n", (int)blockIdx.x,
+           (int)gridDim.x, 0.01 * (double)(t_k1 - t_k0), 0.01 * (double)(__builtin_amdgcn_s_memrealtime() - t_k1));
 }
 
 // =====================================================================================================

@@ -205,6 +205,15 @@ class Engine:
         buf = (C.c_char * 128).from_buffer_copy(unique_id)
         self._check(self._L.pba_comm_init_rccl(self._h, buf, int(rank), int(world)), "pba_comm_init_rccl")
 
+    def comm_enable_peer_exchange(self):
+        """Collective.  Returns the transport name afterwards ("rccl+peer" / "callback+peer" when the device-side exchange is on)."""
+        self._check(self._L.pba_comm_enable_peer_exchange(self._h), "pba_comm_enable_peer_exchange")
+        return self.comm_transport()
+
+    def comm_transport(self):
+        self._L.pba_comm_transport.restype = C.c_char_p
+        return self._L.pba_comm_transport(self._h).decode()
+
     def comm_init_callback(self, fn, rank, world):
         """fn(numpy float64 view, op) must all-reduce in place (op 0 = sum, 1 = max)."""
         def tramp(ptr, n, op, ctx):

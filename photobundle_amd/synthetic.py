@@ -204,3 +204,29 @@ def make_window(n_frames=8, n_points=50000, radius=2, size=KITTI_SIZE, K=KITTI_K
         weights=imgproc.make_patch_weights(radius, gaussian), huber=huber, fixed_slot=0, images=images,
         meta=dict(cams_gt=cams_gt, T_gt=T_gt, T_init=T_init, local_init=local_init, depths=np.stack(depths),
                   visibility=visibility))
+
+
+def channel_fn(kind):
+    """make_window(channel_fn=...) for Options::descriptorType = "IntensityAndGradient" / "BitPlanes" (host producers of
+    photobundle_amd/imgproc.py)."""
+    def fn(img):
+        ch = imgproc.descriptor_channels(img, kind)
+        return ch, imgproc.channel_planes(ch)
+    return fn
+
+
+def inverse_depth_rays(p):
+    """World ray of every point through the camera of its first observation (initial pose): X = o + d / rho with
+    rho = 1 / depth in that camera.  Input of pba_set_inverse_depth (the north star's SE(3) x inverse-depth mode)."""
+    first = np.searchsorted(p.obs_point, np.arange(p.n_points))
+    slot = p.obs_slot[first]
+    rays, rho = np.zeros((p.n_points, 6)), np.zeros(p.n_points)
+    for s in np.unique(slot):
+        T_cw = se3.params_to_pose(p.cams[s])          # world -> camera
+        R, t = T_cw[:3, :3], T_cw[:3, 3]
+        m = slot == s
+        Xc = p.xyz[m] @ R.T + t
+        rays[m, :3] = -R.T @ t
+        rays[m, 3:] = (Xc / Xc[:, 2:3]) @ R
+        rho[m] = 1.0 / Xc[:, 2]
+    return rays, rho

@@ -6,6 +6,8 @@ size-independent properties: run-to-run bit determinism and monotone cost over a
 import numpy as np
 import pytest
 
+from gpu_util import pose_rmse, referee_parity
+
 pytestmark = pytest.mark.gpu
 
 
@@ -142,101 +144,79 @@ def _trace_parity(ref, res, pose_tol=1e-5):
     return rmse_rot, rmse_t
 
 
-def _pose_rmse(a, b):
-    d = a[1:] - b[1:]
-    return float(np.sqrt(np.mean(d[:, :3] ** 2))), float(np.sqrt(np.mean(d[:, 3:] ** 2)))
+
+def _oracle_runs(p, ulp_twins=False, **kw):
+    """The referee + double-precision runs of the oracle: dual numbers, analytic Jacobian and (ulp_twins) the analytic one
+    with every point coordinate moved one ulp up / down -- four samples of where a double-precision solve of this window
+    may end up."""
+    from oracle import oracle
+    q = oracle.solve(p, oracle.default_options(num_threads=8, use_autodiff=0, extended_precision=1, **kw))
+    o0 = oracle.default_options(num_threads=8, use_autodiff=0, **kw)
+    twins = [oracle.solve(p, oracle.default_options(num_threads=8, use_autodiff=1, **kw)), oracle.solve(p, o0)]
+    if ulp_twins:
+        twins += [oracle.solve(p, o0, xyz=np.nextafter(p.xyz, np.inf)), oracle.solve(p, o0, xyz=np.nextafter(p.xyz, -np.inf))]
+    return q, twins
 
 
-def _noise_floor_parity(ref, alts, res, tag):
-    """Long solves of this problem are CHAOTIC in the rounding: the objective is piecewise bilinear in u8 images and the
-    window has a free scale gauge (only camera 0 is constant, photobundle.cc:809-813), so double-precision CPU
-    evaluations of the SAME algorithm that differ only in rounding (`ref` = dual-number oracle, `alts` = further oracle
-    runs: analytic Jacobian, inputs moved by one ulp either way) drift apart after a handful of iterations.  At
-    configs[1] five such twins stop after 63 .. 98 iterations, by function OR parameter tolerance, with final costs up to
-    2.4e-3 apart and translations up to a few mm apart.  That spread is the noise floor of the reference itself; the
-    engine (one more rounding of the same algorithm) is held to it:
-      * while all twins still agree with ref to 1e-9 in cost (the deterministic prefix) the engine matches ref to 1e-9
-        with identical accept / reject decisions and trust-region radii,
-      * afterwards its distance to ref stays within 20x the largest twin-ref distance seen so far,
-      * at the end it has converged (termination_type 0) to a cost that is within 2x the twins' spread of its nearest
-        twin -- or below every twin's --, with poses within 2x the twins' pose spread (+ the north_star 1e-5) of its
-        nearest twin."""
-    if isinstance(alts, dict):
-        alts = [alts]
-    ri, gi = ref["iterations"], res["iterations"]
-    floor, prefix = 0.0, 0
-    rows = []
-    for i in range(min([len(ri), len(gi)] + [len(a["iterations"]) for a in alts])):
-        a, g = ri[i], gi[i]
-        floor = max([floor] + [abs(a["cost"] - b["iterations"][i]["cost"]) / a["cost"] for b in alts])
-        dg = abs(a["cost"] - g["cost"]) / a["cost"]
-        rows.append((i, floor, dg))
-        if floor <= 1e-9:
-            prefix = i + 1
-            assert dg <= 1e-9, (tag, i, a["cost"], g["cost"])
-            assert a["step_is_successful"] == g["step_is_successful"] and a["step_is_valid"] == g["step_is_valid"], (tag, i)
-            assert np.isclose(a["trust_region_radius"], g["trust_region_radius"], rtol=1e-6), (tag, i)
-        else:
-            assert dg <= 20.0 * floor, (tag, i, floor, dg)
-    assert prefix >= 4, (tag, prefix, rows[:8])
-    twins = [ref] + list(alts)
-    fcs = np.array([t["final_cost"] for t in twins])
-    fc_spread = float((fcs.max() - fcs.min()) / fcs.min())
-    fc_near = float(np.min(np.abs(fcs - res["final_cost"]) / fcs))
-    pose_spread = [0.0, 0.0]
-    for i in range(len(twins)):
-        for j in range(i + 1, len(twins)):
-            r, t = _pose_rmse(twins[i]["cams"], twins[j]["cams"])
-            pose_spread = [max(pose_spread[0], r), max(pose_spread[1], t)]
-    pose_near = min((_pose_rmse(t["cams"], res["cams"]) for t in twins), key=lambda rt: rt[0] / max(pose_spread[0], 1e-30) + rt[1] / max(pose_spread[1], 1e-30))
-    print("%s: iterations of the %d CPU twins %s / engine %d; deterministic prefix %d iterations; final cost: engine %.8e, twins %s "
-          "(spread %.3e, engine to nearest twin %.3e); pose RMSE engine to nearest twin rot %.3e rad trans %.3e m (twins' spread %.3e / %.3e)"
-          % (tag, len(twins), [len(t["iterations"]) - 1 for t in twins], len(gi) - 1, prefix, res["final_cost"],
-             ["%.8e" % f for f in fcs], fc_spread, fc_near, pose_near[0], pose_near[1], pose_spread[0], pose_spread[1]))
-    assert res["termination_type"] == ref["termination_type"], (res["message"], ref["message"])
-    assert fc_near <= 2.0 * fc_spread + 1e-9 or res["final_cost"] <= fcs.min()
-    assert pose_near[0] <= 2.0 * pose_spread[0] + 1e-5 and pose_near[1] <= 2.0 * pose_spread[1] + 1e-5
-    return prefix
-
-
-@pytest.mark.timeout(1800)
+@pytest.mark.timeout(2400)
 def test_configs1_parity_to_convergence(full_window):
     """configs[1] at full size with the reference's solver options (tolerances on, photobundle.cc:738-761), run until a
-    tolerance terminates the solve (~80-100 iterations), against the dual-number oracle; see _noise_floor_parity."""
+    tolerance terminates the solve (~70-100 iterations), against the extended-precision referee with two double-precision
+    oracle runs fixing the noise floor (see _referee_parity).  Then the north_star pose bar on this (poor-init, headline)
+    window: solves truncated after k iterations are compared pose by pose -- measured: the engine holds 1e-5 (rotation
+    in rad AND translation in m, RMSE over the free cameras) for the first 8 iterations (8e-9 rad / 3e-7 m after 8), the
+    double-precision oracle itself only for the first 6 (5e-5 m after 8); from iteration ~10 on the rounding noise of
+    any double-precision evaluation is amplified past the bar."""
     from oracle import oracle
     from photobundle_amd.engine import default_solver_options
     from gpu_util import make_engine
     p = full_window
-    ref = oracle.solve(p, oracle.default_options(num_threads=8, use_autodiff=1))
-    o0 = oracle.default_options(num_threads=8, use_autodiff=0)
-    alts = [oracle.solve(p, o0), oracle.solve(p, o0, xyz=np.nextafter(p.xyz, np.inf)), oracle.solve(p, o0, xyz=np.nextafter(p.xyz, -np.inf))]
-    assert ref["termination_type"] == 0 and len(ref["iterations"]) >= 10, ref["message"]
+    q, twins = _oracle_runs(p, ulp_twins=True)
+    assert q["termination_type"] == 0 and len(q["iterations"]) >= 10, q["message"]
     with make_engine(p, keep_reduced_system=False) as e:
         res = e.solve(default_solver_options())
-    _noise_floor_parity(ref, alts, res, "configs[1] to convergence")
+        tight = referee_parity(q, twins, res, "configs[1] to convergence")
+        assert tight >= 5
+        from gpu_util import trajectory_consistency
+        worst_c = trajectory_consistency(p, e, (10, 40), lambda k_: default_solver_options(max_num_iterations=k_))
+        print("configs[1]: oracle cost at the engine's own states after 10 / 40 iterations: largest relative difference %.1e" % worst_c)
+        hold_engine = hold_twin = 0
+        for k in (2, 4, 6, 8):
+            qk = oracle.solve(p, oracle.default_options(num_threads=8, use_autodiff=0, extended_precision=1, max_num_iterations=k))
+            tk = oracle.solve(p, oracle.default_options(num_threads=8, use_autodiff=1, max_num_iterations=k))
+            e.load(p)
+            rk = e.solve(default_solver_options(max_num_iterations=k))
+            pe, pt = pose_rmse(rk["cams"], qk["cams"]), pose_rmse(tk["cams"], qk["cams"])
+            print("configs[1], %d iterations: pose RMSE to the referee: engine rot %.2e rad trans %.2e m; double oracle %.2e / %.2e"
+                  % (k, pe[0], pe[1], pt[0], pt[1]))
+            if max(pe) <= 1e-5 and hold_engine == k - 2:
+                hold_engine = k
+            if max(pt) <= 1e-5 and hold_twin == k - 2:
+                hold_twin = k
+            assert pe[0] <= 2.0 * pt[0] + 1e-12 and pe[1] <= 2.0 * pt[1] + 1e-12
+        print("configs[1]: the 1e-5 pose bar holds for the first %d iterations (engine) / %d (double-precision oracle)" % (hold_engine, hold_twin))
+        assert hold_engine >= 6 and hold_engine >= hold_twin
 
 
-@pytest.mark.timeout(1800)
+@pytest.mark.timeout(2400)
 def test_configs1_well_initialised_window_to_convergence():
-    """Same shape, the "good VO" regime (small pose / depth perturbation): the three solves stay together for ~40
-    iterations, so 30 iterations are compared at the tight tolerances, then the run to convergence as above."""
+    """Same shape, the "good VO" regime (small pose / depth perturbation): everything stays together for ~20 iterations,
+    so 20 iterations are compared at the tight tolerances against the plain oracle, then the run to convergence as above."""
     from oracle import oracle
     from photobundle_amd import synthetic
     from photobundle_amd.engine import default_solver_options
     from gpu_util import make_engine
     p = synthetic.make_window(n_frames=8, n_points=50000, radius=2, rot_deg=0.02, trans=0.003, depth_noise=0.002)
-    ref = oracle.solve(p, oracle.default_options(num_threads=8, use_autodiff=1))
-    o0 = oracle.default_options(num_threads=8, use_autodiff=0)
-    alts = [oracle.solve(p, o0), oracle.solve(p, o0, xyz=np.nextafter(p.xyz, np.inf)), oracle.solve(p, o0, xyz=np.nextafter(p.xyz, -np.inf))]
+    q, twins = _oracle_runs(p, max_num_iterations=150)
     with make_engine(p, keep_reduced_system=False) as e:
-        res = e.solve(default_solver_options())
-        prefix = _noise_floor_parity(ref, alts, res, "configs[1], well initialised, to convergence")
-        n_it = min(30, prefix - 1)
-        assert n_it >= 10
+        res = e.solve(default_solver_options(max_num_iterations=150))
+        tight = referee_parity(q, twins, res, "configs[1], well initialised, to convergence")
+        assert tight >= 20
+        n_it = 12
         e.load(p)
-        res30 = e.solve(default_solver_options(max_num_iterations=n_it))
-    ref30 = oracle.solve(p, oracle.default_options(num_threads=8, use_autodiff=1, max_num_iterations=n_it))
-    rr, rt = _trace_parity(ref30, res30)
+        res12 = e.solve(default_solver_options(max_num_iterations=n_it))
+    ref12 = oracle.solve(p, oracle.default_options(num_threads=8, use_autodiff=1, max_num_iterations=n_it))
+    rr, rt = _trace_parity(ref12, res12)
     print("configs[1], well initialised, %d iterations: pose RMSE rot %.3e rad, trans %.3e m" % (n_it, rr, rt))
 
 
@@ -250,15 +230,19 @@ def test_configs4_ten_iterations_against_oracle():
     from gpu_util import make_engine
     p = synthetic.make_window(n_frames=8, n_points=50000, radius=5, huber=0.05)
     n_it = 10
-    o = oracle.default_options(max_num_iterations=n_it, num_threads=8, use_autodiff=0)
-    ref = oracle.solve(p, o)
-    alts = [oracle.solve(p, o, xyz=np.nextafter(p.xyz, np.inf)), oracle.solve(p, o, xyz=np.nextafter(p.xyz, -np.inf))]
+    q = oracle.solve(p, oracle.default_options(max_num_iterations=n_it, num_threads=8, use_autodiff=0, extended_precision=1))
+    ref = oracle.solve(p, oracle.default_options(max_num_iterations=n_it, num_threads=8, use_autodiff=0))
     with make_engine(p, keep_reduced_system=False) as e:
         res = e.solve(default_solver_options(max_num_iterations=n_it))
-    assert len(ref["iterations"]) == n_it + 1 == len(res["iterations"])
-    _noise_floor_parity(ref, alts, res, "configs[4] 10 iterations")
-    for a, b in zip(ref["iterations"], res["iterations"]):
-        assert a["step_is_successful"] == b["step_is_successful"]
+    assert len(ref["iterations"]) == n_it + 1 == len(res["iterations"]) == len(q["iterations"])
+    run = 0.0
+    for i, (a, b, c) in enumerate(zip(q["iterations"], ref["iterations"], res["iterations"])):
+        assert a["step_is_successful"] == b["step_is_successful"] == c["step_is_successful"]
+        run = max(run, abs(b["cost"] - a["cost"]) / a["cost"])
+        assert abs(c["cost"] - a["cost"]) / a["cost"] <= max(1e-12, 2.0 * run), (i, c["cost"], a["cost"], run)
+    pe, pt = pose_rmse(res["cams"], q["cams"]), pose_rmse(ref["cams"], q["cams"])
+    print("configs[4] %d iterations: pose RMSE to the referee: engine rot %.2e rad trans %.2e m, double oracle %.2e / %.2e" % (n_it, pe[0], pe[1], pt[0], pt[1]))
+    assert max(pe) <= 1e-5 and pe[0] <= 2.0 * pt[0] + 1e-12 and pe[1] <= 2.0 * pt[1] + 1e-12
 
 
 @pytest.fixture(scope="module")
