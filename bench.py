@@ -165,6 +165,12 @@ def main():
                 if args.inverse_depth:
                     eng.set_inverse_depth(rays, rho0)
             eng.comm_init_callback(_allreduce, rank, world)
+    if world > 1 and os.environ.get("PBA_PEER", "1") != "0":
+        # per-step exchanges as device-side mailbox reads over peer-mapped memory (no collective launch per LM step); the
+        # call is collective and every rank ends up with the same answer -- the base transport stays when IPC is unavailable
+        eng.comm_enable_peer_exchange()
+    if world > 1:
+        transport = "%s (%s)" % (transport, eng.comm_transport())
     elif os.environ.get("PBA_FORCE_MULTI") == "1":
         # diagnostics: the multi-rank code path (RCCL all-reduces on the engine's stream, k_decide) at world = 1
         eng.comm_init_rccl(Engine.comm_unique_id(), 0, 1)
@@ -258,11 +264,20 @@ def main():
             del src_t, dst_t
         except Exception:
             copy_gbps = None
-    # per-kernel launch durations: a separate short profiled solve (HIP events on the engine's stream, one stream
-    # sync per step) so that the timed region above carries no instrumentation
+    # per-kernel shares of the iteration: one more solve, outside the timed region.  Single rank: device time stamps inside
+    # the same asynchronous pipeline the timed region ran (interval between consecutive kernel ends; nothing is added to
+    # the stream -- an event record after every kernel makes it end with a cache write-back the pipelined run never pays,
+    # which inflated k_schur by ~6 us).  More ranks: HIP events around every kernel of the host-stepped driver, which also
+    # times the two per-step exchanges.
     reset_state()
-    eng.reset_counters()
-    eng.solve(opts(min(args.steps, 10)))
+    if world == 1:
+        eng.set_profiling(2)
+        eng.solve(opts(args.steps))
+        timing_source = "device time stamps in the asynchronous pipeline (interval between consecutive kernel ends)"
+    else:
+        eng.reset_counters()
+        eng.solve(opts(min(args.steps, 10)))
+        timing_source = "HIP events around every kernel of the host-stepped driver (each bracket ends with a cache write-back)"
     ctr = eng.counters()
 
     iters_done = tot["iters"]
@@ -287,10 +302,12 @@ def main():
         "k_sample<JAC> (Jacobian pass)": (ctr["linearize_ms"], ctr["linearize_launches"], ab["sample_jac"]),
         "k_sample<cost> (cost pass)": (ctr["cost_ms"], ctr["cost_launches"], ab["b_cost"]),
         "k_schur (point elimination)": (ctr["schur_ms"], ctr["schur_launches"], ab["schur"]),
+        # serial stretch of the iteration: reduction of the Schur partials + reduced camera solve (O(frames^2): no per-observation bytes)
+        "k_reduce_solve (partials + reduced solve)": (ctr["solve_ms"], ctr["solve_launches"], 0.0),
     }
     # the kernel with the largest average launch duration (no tie-break; `per_kernel` carries the others)
     avg_ms = {k: v[0] / max(1, v[1]) for k, v in kern.items()}
-    dom = max(kern, key=lambda k: avg_ms[k])
+    dom = max((k for k in kern if kern[k][2] > 0), key=lambda k: avg_ms[k])      # (the serial solve stage moves no per-observation bytes)
     ms, launches, bytes_per_obs = kern[dom]
     avg_s = (ms / max(1, launches)) * 1e-3
     achieved = n_obs_local * bytes_per_obs / avg_s if avg_s > 0 else 0.0
@@ -313,7 +330,7 @@ def main():
                            if traffic else None),
         "traffic_frac": (traffic / avg_s / HBM_PEAK) if (traffic and avg_s > 0) else None,
         "valu_floor_us": (valu_insts * 4.0 / (1024 * 2.4e9) * 1e6) if valu_insts else None,
-        "avg_launch_us": avg_s * 1e6, "algorithmic_bytes_per_obs": bytes_per_obs,
+        "avg_launch_us": avg_s * 1e6, "timing_source": timing_source, "algorithmic_bytes_per_obs": bytes_per_obs,
         "whole_iteration_frac": (run_bytes / elapsed) / (HBM_PEAK * world),
         "whole_iteration_frac_nominal": (run_bytes_nominal / elapsed) / (HBM_PEAK * world),
         "kernels_ms_per_launch": {k: (v[0] / max(1, v[1])) for k, v in kern.items()},
@@ -344,6 +361,10 @@ def main():
                "cost_passes": n_cost, "resolve_passes": n_res, "initial_cost": res["initial_cost"],
                "final_cost": res["final_cost"], "message": res["message"]},
         "roofline": roofline,
+        "exchange": {"transport": eng.comm_transport(), "ranks_seen_by_transport": eng.comm_rank_count(),
+                     "us_per_step": (1e3 * ctr["exchange_ms"] / ctr["exchange_launches"]) if ctr["exchange_launches"] else 0.0,
+                     "note": "both per-step exchanges (packed reduced camera system + step scalars), HIP events on the engine's stream in the "
+                             "profiled (host-stepped) solve; 0 at one rank"},
         "pcie_inclusive": {"upload_ms": 1e3 * upload_s, "iters_per_sec": iters_done / (elapsed + upload_s),
                            "note": "host->device upload of the whole window (frames, points, descriptors, observations, cameras) + the same solve"},
         "device_copy_GBps": copy_gbps,

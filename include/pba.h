@@ -149,6 +149,11 @@ typedef struct pba_counters {
   double schur_ms;           /* ... of the Schur elimination kernel */
   int64_t linearize_launches, cost_launches, schur_launches;
   int64_t n_obs, n_points;   /* local shard */
+  double solve_ms;           /* ... of the reduction of the Schur partials + reduced camera solve (k_reduce_solve, or k_reduce_final
+                                + k_solve_blocked at more than one rank, without the exchange between them) */
+  double exchange_ms;        /* ... of the two per-step exchanges (all-reduce of the packed reduced system + of the step scalars):
+                                RCCL collectives or the peer-exchange kernels; 0 at a single rank */
+  int64_t solve_launches, exchange_launches;
 } pba_counters;
 
 const char* pba_status_string(int status);
@@ -228,7 +233,15 @@ int pba_comm_init_callback(pba_engine* e, pba_allreduce_fn fn, void* ctx, int32_
  * "callback", "callback+peer", "none").  Waits are bounded by PBA_WAIT_TIMEOUT_S -> PBA_ERR_COMM. */
 int pba_comm_enable_peer_exchange(pba_engine* e);
 const char* pba_comm_transport(const pba_engine* e);
+/* Ranks the transport itself reports (ncclCommCount for RCCL, the callback's world otherwise; 1 without a transport). */
+int pba_comm_rank_count(const pba_engine* e);
 
+/* Per-kernel accounting.  pba_set_profiling mode 0: off.  1 (what pba_reset_counters switches on): HIP events around
+ * every kernel of the host-stepped driver -- each bracket ends with an event record (a cache write-back the pipelined run
+ * does not pay) and the exchanges are timed too.  2: device time stamps inside the ASYNCHRONOUS pipeline (single rank):
+ * the three kernels of an LM iteration run back to back, the interval between two consecutive kernel ends is a kernel's
+ * share of the iteration; nothing is added to the stream.  pba_get_counters reports whichever mode is on. */
+int pba_set_profiling(pba_engine* e, int32_t mode);
 int pba_get_counters(pba_engine* e, pba_counters* c);
 int pba_reset_counters(pba_engine* e);
 

@@ -60,7 +60,8 @@ class StepInfo(C.Structure):
 class Counters(C.Structure):
     _fields_ = [("linearize_ms", C.c_double), ("cost_ms", C.c_double), ("schur_ms", C.c_double),
                 ("linearize_launches", C.c_int64), ("cost_launches", C.c_int64), ("schur_launches", C.c_int64),
-                ("n_obs", C.c_int64), ("n_points", C.c_int64)]
+                ("n_obs", C.c_int64), ("n_points", C.c_int64), ("solve_ms", C.c_double), ("exchange_ms", C.c_double),
+                ("solve_launches", C.c_int64), ("exchange_launches", C.c_int64)]
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int64, C.c_int32, C.c_void_p)
@@ -70,8 +71,8 @@ SYMBOLS = [
     "pba_status_string", "pba_last_error", "pba_default_solver_options", "pba_create", "pba_destroy",
     "pba_set_frame_u8", "pba_set_frame_channels_f32", "pba_get_frame_planes", "pba_set_problem", "pba_set_cameras", "pba_set_inverse_depth", "pba_get_points_world", "pba_get_state",
     "pba_linearize", "pba_step", "pba_accept", "pba_get_reduced_system", "pba_get_obs_records", "pba_solve",
-    "pba_comm_unique_id", "pba_comm_init_rccl", "pba_comm_init_callback", "pba_comm_enable_peer_exchange", "pba_comm_transport",
-    "pba_get_counters", "pba_reset_counters",
+    "pba_comm_unique_id", "pba_comm_init_rccl", "pba_comm_init_callback", "pba_comm_enable_peer_exchange", "pba_comm_transport", "pba_comm_rank_count",
+    "pba_set_profiling", "pba_get_counters", "pba_reset_counters",
 ]
 
 
@@ -116,7 +117,9 @@ def lib():
     L.pba_comm_enable_peer_exchange.argtypes = [C.c_void_p]
     L.pba_comm_transport.argtypes = [C.c_void_p]
     L.pba_comm_transport.restype = C.c_char_p
+    L.pba_comm_rank_count.argtypes = [C.c_void_p]
     L.pba_get_counters.argtypes = [C.c_void_p, C.POINTER(Counters)]
     L.pba_reset_counters.argtypes = [C.c_void_p]
+    L.pba_set_profiling.argtypes = [C.c_void_p, C.c_int32]
     _LIB = L
     return L

@@ -17,6 +17,7 @@ struct Rccl {
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   std::string err;
@@ -29,6 +30,7 @@ struct Rccl {
     CommInitRank = reinterpret_cast<decltype(CommInitRank)>(dlsym(lib, "ncclCommInitRank"));
     CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
     CommAbort = reinterpret_cast<decltype(CommAbort)>(dlsym(lib, "ncclCommAbort"));   // optional
+    CommCount = reinterpret_cast<decltype(CommCount)>(dlsym(lib, "ncclCommCount"));   // optional
     AllReduce = reinterpret_cast<decltype(AllReduce)>(dlsym(lib, "ncclAllReduce"));
     GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
     if (!GetUniqueId || !CommInitRank || !CommDestroy || !AllReduce || !GetErrorString) { err = "librccl misses a required symbol"; return false; }
@@ -109,6 +111,14 @@ int Comm::allreduce_host(double* h, int n, int op) {
   }
   err = "no transport initialised";
   return 1;
+}
+
+int Comm::rank_count() const {
+  if (kind == 1 && nccl_comm && rccl().CommCount) {
+    int n = 0;
+    if (rccl().CommCount(static_cast<ncclComm_t>(nccl_comm), &n) == ncclSuccess) return n;
+  }
+  return world;
 }
 
 int Comm::enable_peer() {

@@ -46,6 +46,7 @@ struct Comm {
   unsigned long long seq_a = 0, seq_b = 0;      // exchanges enqueued so far (identical on every rank)
   // all-gathers the IPC handles through allreduce_host, maps the peers; every rank ends with the same answer
   int enable_peer();
+  int rank_count() const;     // what the transport itself reports (ncclCommCount), else `world`
   void close_peer();
   static size_t flag_index(int kind, unsigned long long seq) { return (size_t)(2 * kind + (int)(seq & 1)); }
   static size_t data_offset(int kind, unsigned long long seq) { return kFlagDoubles + (kind == 0 ? (seq & 1) * kCapA : 2 * kCapA + (seq & 1) * kCapB); }

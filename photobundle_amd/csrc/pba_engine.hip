@@ -59,8 +59,7 @@ struct pba_engine {
   uint8_t* d_obs_slot = nullptr;
   int32_t* d_pt_begin = nullptr;
   int4* d_tile_info = nullptr;
-  uint8_t* d_obs_l0 = nullptr;
-  uint8_t* d_obs_cnt = nullptr;
+  int2* d_lane_rec = nullptr;       // [n_tiles][kTile] per tile lane: point, slot | first lane << 8 | observations of the point << 16
   int n_tiles = 0;
   // linearisation + solve scratch
   int64_t rec_stride = 0;
@@ -89,6 +88,9 @@ struct pba_engine {
   bool fuse = true;                 // back-substitution + finalisation fused into the candidate pass (radius <= 3)
   unsigned int* d_ticket = nullptr;
   unsigned int* d_ticket_solve = nullptr;   // arrival counter of k_reduce_solve
+  unsigned long long* d_stamp = nullptr;    // [kStampMaxIters + 1][kStampRecord] device time stamps of the pipelined iterations (pba_set_profiling(e, 2))
+  bool stamps = false;
+  int stamp_iter = 0;                       // record of the iteration being enqueued (0: the first linearisation)
   int solve_kind = 0;               // PBA_SOLVE: 0 blocked workgroup Cholesky (fused with the reduction at one rank), 1 one/two-wave kernels, 2 generic
   // asynchronous driver (device-side trust-region decisions)
   LmState* d_lm = nullptr;          // device state
@@ -114,8 +116,9 @@ struct pba_engine {
 
   // counters
   bool profile = false;
-  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  bool ev_used[3] = {false, false, false};
+  static constexpr int kEvPairs = 7;     // Jacobian pass, cost pass, Schur, reduction, solve, exchange A, exchange B
+  hipEvent_t ev[2 * kEvPairs] = {};
+  bool ev_used[kEvPairs] = {};
   pba_counters ctr{};
   std::unordered_map<void*, size_t> dev_cap;   // capacity in bytes of every dev_alloc'ed buffer, keyed by its owner field
 };
@@ -221,6 +224,34 @@ void launch_sample(pba_engine* e, const SampleParams& sp) {
 bool fused_capable(const pba_engine* e) { return e->fuse && ((e->cfg.flags >> 1) & 3) == 0; }
 int sample_waves_for_radius(int) { return kSampleWaves; }
 
+__global__ void k_noop() {}
+// device -> host-mapped pinned memory (8-byte words, grid-stride); visible to the host once the stream has drained
+__global__ void k_to_host(const double* __restrict__ src, double* __restrict__ dst, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+// A timing bracket that starts on an idle stream would charge the kernel with the host's launch latency (the begin
+// event is stamped at once, the kernel arrives microseconds later): a no-op kernel in front absorbs it.
+void ev_begin(pba_engine* e, int k) {
+  if (e->profile) {
+    hipLaunchKernelGGL(k_noop, dim3(1), dim3(1), 0, e->stream);
+    (void)hipEventRecord(e->ev[2 * k], e->stream);
+  }
+}
+void ev_end(pba_engine* e, int k) { if (e->profile) { (void)hipEventRecord(e->ev[2 * k + 1], e->stream); e->ev_used[k] = true; } }
+void ev_collect(pba_engine* e) {
+  if (!e->profile) return;
+  double* acc[pba_engine::kEvPairs] = {&e->ctr.linearize_ms, &e->ctr.cost_ms, &e->ctr.schur_ms, &e->ctr.solve_ms, &e->ctr.solve_ms,
+                                       &e->ctr.exchange_ms, &e->ctr.exchange_ms};
+  int64_t* cnt[pba_engine::kEvPairs] = {&e->ctr.linearize_launches, &e->ctr.cost_launches, &e->ctr.schur_launches, &e->ctr.solve_launches,
+                                        nullptr, &e->ctr.exchange_launches, nullptr};
+  for (int k = 0; k < pba_engine::kEvPairs; ++k) {
+    if (!e->ev_used[k]) continue;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, e->ev[2 * k], e->ev[2 * k + 1]) == hipSuccess) { *acc[k] += ms; if (cnt[k]) *cnt[k] += 1; }
+    e->ev_used[k] = false;
+  }
+}
+
 template <int NF>
 void launch_solve_wave(pba_engine* e, const SolveParams& so) {
   hipLaunchKernelGGL((k_solve_wave<NF>), dim3(1), dim3(256), 0, e->stream, so);
@@ -253,6 +284,12 @@ void launch_solve(pba_engine* e, const SolveParams& so, int n) {
   }
   const size_t solve_smem = sizeof(double) * ((size_t)n * (n + 1) + 5 * n);
   hipLaunchKernelGGL(k_solve_generic, dim3(1), dim3(kSolveThreads), solve_smem, e->stream, so);
+}
+
+// record of the iteration being enqueued in the device time-stamp log (null: stamps off / beyond the log)
+unsigned long long* stamp_record(pba_engine* e) {
+  if (!e->stamps || !e->d_stamp || e->stamp_iter > kStampMaxIters) return nullptr;
+  return e->d_stamp + (size_t)e->stamp_iter * kStampRecord;
 }
 
 // ---- peer exchange (pba_comm.h): kind 0 = packed reduced system, 1 = step scalars -------------------------------------
@@ -289,16 +326,22 @@ int launch_reduce_and_solve(pba_engine* e, const SolveParams& so, int n, int cur
     rp.block_cost = e->d_block_cost[cur]; rp.block_fail = e->d_block_fail[cur]; rp.n_cost_blocks = n_cost_blocks;
     rp.block_cost_alt = e->d_block_cost[cand]; rp.block_fail_alt = e->d_block_fail[cand];
     rp.packed = e->d_packed; rp.scal = e->d_scal; rp.ticket = e->d_ticket_solve; rp.so = so;
+    rp.stamp = (lm && !final_pass) ? stamp_record(e) : nullptr;
+    ev_begin(e, 3);
     hipLaunchKernelGGL(k_reduce_solve, dim3(grid), dim3(1024), solve_blocked_smem_bytes(n), e->stream, rp);
+    ev_end(e, 3);
     HIP_TRY(e, hipGetLastError());
     return PBA_OK;
   }
   const bool peer = multi && e->comm.peer;
   if (peer && (size_t)e->part_stride > Comm::kCapA) return fail(e, PBA_ERR_COMM, "reduced system of %d doubles exceeds the peer mailbox", e->part_stride);
+  ev_begin(e, 3);
   hipLaunchKernelGGL(k_reduce_final, dim3(grid), dim3(1024), 0, e->stream, e->d_partial, e->schur_grid, e->part_stride,
                      e->d_block_cost[cur], e->d_block_fail[cur], n_cost_blocks, peer ? peer_slot(e, 0) : e->d_packed, e->d_scal, lm, cur,
                      (const double*)e->d_block_cost[cand], (const int32_t*)e->d_block_fail[cand], final_pass, peer ? 1 : 0);
+  ev_end(e, 3);
   HIP_TRY(e, hipGetLastError());
+  if (multi) ev_begin(e, 5);
   if (peer) {
     const int rcp = peer_allreduce(e, 0, e->part_stride - 1, e->d_packed);
     if (rcp) return rcp;
@@ -306,7 +349,10 @@ int launch_reduce_and_solve(pba_engine* e, const SolveParams& so, int n, int cur
     if (e->comm.allreduce_device(e->d_packed, (size_t)e->part_stride - 1, 0, e->stream))
       return fail(e, PBA_ERR_COMM, "allreduce(reduced system) failed: %s", e->comm.err.c_str());
   }
+  if (multi) ev_end(e, 5);
+  ev_begin(e, 4);
   launch_solve(e, so, n);
+  ev_end(e, 4);
   HIP_TRY(e, hipGetLastError());
   return PBA_OK;
 }
@@ -357,36 +403,15 @@ int exchange_step_scalars(pba_engine* e, bool packed) {
                        e->comm.peer ? 1 : 0);
     HIP_TRY(e, hipGetLastError());
   }
-  if (e->comm.peer) return peer_allreduce(e, 1, (int)n, e->d_xchg);
-  if (e->comm.allreduce_device(e->d_xchg, n, 0, e->stream))
+  ev_begin(e, 6);
+  if (e->comm.peer) {
+    const int rcp = peer_allreduce(e, 1, (int)n, e->d_xchg);
+    if (rcp) return rcp;
+  } else if (e->comm.allreduce_device(e->d_xchg, n, 0, e->stream)) {
     return fail(e, PBA_ERR_COMM, "allreduce(step scalars) failed: %s", e->comm.err.c_str());
+  }
+  ev_end(e, 6);
   return PBA_OK;
-}
-
-__global__ void k_noop() {}
-// device -> host-mapped pinned memory (8-byte words, grid-stride); visible to the host once the stream has drained
-__global__ void k_to_host(const double* __restrict__ src, double* __restrict__ dst, size_t n) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
-}
-// A timing bracket that starts on an idle stream would charge the kernel with the host's launch latency (the begin
-// event is stamped at once, the kernel arrives microseconds later): a no-op kernel in front absorbs it.
-void ev_begin(pba_engine* e, int k) {
-  if (e->profile) {
-    hipLaunchKernelGGL(k_noop, dim3(1), dim3(1), 0, e->stream);
-    (void)hipEventRecord(e->ev[2 * k], e->stream);
-  }
-}
-void ev_end(pba_engine* e, int k) { if (e->profile) { (void)hipEventRecord(e->ev[2 * k + 1], e->stream); e->ev_used[k] = true; } }
-void ev_collect(pba_engine* e) {
-  if (!e->profile) return;
-  double* acc[3] = {&e->ctr.linearize_ms, &e->ctr.cost_ms, &e->ctr.schur_ms};
-  int64_t* cnt[3] = {&e->ctr.linearize_launches, &e->ctr.cost_launches, &e->ctr.schur_launches};
-  for (int k = 0; k < 3; ++k) {
-    if (!e->ev_used[k]) continue;
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, e->ev[2 * k], e->ev[2 * k + 1]) == hipSuccess) { *acc[k] += ms; *cnt[k] += 1; }
-    e->ev_used[k] = false;
-  }
 }
 
 }  // namespace
@@ -504,7 +529,7 @@ int pba_create(const pba_config* cfg, pba_engine** out) {
   if ((rc = dev_alloc(e, &e->d_ticket_solve, (size_t)1))) return bail(rc);
   if (hipMemsetAsync(e->d_ticket_solve, 0, sizeof(unsigned int), e->stream) != hipSuccess) return bail(PBA_ERR_HIP);
   if (const char* sv = getenv("PBA_SOLVE")) e->solve_kind = atoi(sv);
-  for (int k = 0; k < 6; ++k)
+  for (int k = 0; k < 2 * pba_engine::kEvPairs; ++k)
     if (hipEventCreate(&e->ev[k]) != hipSuccess) return bail(PBA_ERR_HIP);
   e->sample_waves = sample_waves_for_radius(cfg->radius);
   if ((rc = ensure_state_stage(e, (size_t)6 * kMaxFrames + 3 * 65536))) return bail(rc);   // grown on demand beyond 64k points
@@ -535,9 +560,9 @@ void pba_destroy(pba_engine* e) {
   for (int k = 0; k < 2; ++k) { dev_free(&e->d_xyz[k]); dev_free(&e->d_cams[k]); dev_free(&e->d_geom[k]); dev_free(&e->d_block_cost[k]); dev_free(&e->d_block_fail[k]); }
   dev_free(&e->d_rays);
   dev_free(&e->d_desc); dev_free(&e->d_w2); dev_free(&e->d_obs_point); dev_free(&e->d_obs_slot); dev_free(&e->d_pt_begin);
-  dev_free(&e->d_tile_info); dev_free(&e->d_obs_l0); dev_free(&e->d_obs_cnt); dev_free(&e->d_rec[0]); dev_free(&e->d_rec[1]); dev_free(&e->d_sp); dev_free(&e->d_ptrec); dev_free(&e->d_sc);
+  dev_free(&e->d_tile_info); dev_free(&e->d_lane_rec); dev_free(&e->d_rec[0]); dev_free(&e->d_rec[1]); dev_free(&e->d_sp); dev_free(&e->d_ptrec); dev_free(&e->d_sc);
   dev_free(&e->d_delta_c); dev_free(&e->d_partial); dev_free(&e->d_red); dev_free(&e->d_packed); dev_free(&e->d_S);
-  dev_free(&e->d_rhs); dev_free(&e->d_bs_out); dev_free(&e->d_scal); dev_free(&e->d_xchg); dev_free(&e->d_ticket); dev_free(&e->d_ticket_solve);
+  dev_free(&e->d_rhs); dev_free(&e->d_bs_out); dev_free(&e->d_scal); dev_free(&e->d_xchg); dev_free(&e->d_ticket); dev_free(&e->d_ticket_solve); dev_free(&e->d_stamp);
   if (e->h_scal) (void)hipHostFree(e->h_scal);
   if (e->h_lm) (void)hipHostFree(e->h_lm);
   if (e->h_comm_err) (void)hipHostFree(e->h_comm_err);
@@ -547,7 +572,7 @@ void pba_destroy(pba_engine* e) {
   if (e->h_log) (void)hipHostFree(e->h_log);
   dev_free(&e->d_lm);
   dev_free(&e->d_log);
-  for (int k = 0; k < 6; ++k) if (e->ev[k]) (void)hipEventDestroy(e->ev[k]);
+  for (int k = 0; k < 2 * pba_engine::kEvPairs; ++k) if (e->ev[k]) (void)hipEventDestroy(e->ev[k]);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
 }
@@ -645,14 +670,13 @@ int pba_set_problem(pba_engine* e, int32_t n_points, const double* xyz, const do
   }
   e->n_tiles = (int)tiles.size() - 1;
   std::vector<int4> tinfo(e->n_tiles);
-  std::vector<uint8_t> obs_l0(n_obs), obs_cnt(n_obs);
+  std::vector<int2> lane_rec((size_t)e->n_tiles * kTile, make_int2(0, 0));
   for (int t = 0; t < e->n_tiles; ++t) {
     const int o0 = tiles[t], o1 = tiles[t + 1];
     tinfo[t] = make_int4(o0, o1 - o0, obs_point[o0], obs_point[o1 - 1] - obs_point[o0] + 1);
     for (int o = o0; o < o1; ++o) {
       const int p = obs_point[o];
-      obs_l0[o] = (uint8_t)(pt_begin[p] - o0);
-      obs_cnt[o] = (uint8_t)(pt_begin[p + 1] - pt_begin[p]);
+      lane_rec[(size_t)t * kTile + (o - o0)] = make_int2(p, (int)slot8[o] | ((pt_begin[p] - o0) << 8) | ((pt_begin[p + 1] - pt_begin[p]) << 16));
     }
   }
   e->n_points = n_points;
@@ -673,8 +697,7 @@ int pba_set_problem(pba_engine* e, int32_t n_points, const double* xyz, const do
   if ((rc = dev_alloc(e, &e->d_obs_slot, (size_t)n_obs))) return rc;
   if ((rc = dev_alloc(e, &e->d_pt_begin, (size_t)n_points + 1))) return rc;
   if ((rc = dev_alloc(e, &e->d_tile_info, tinfo.size()))) return rc;
-  if ((rc = dev_alloc(e, &e->d_obs_l0, (size_t)n_obs))) return rc;
-  if ((rc = dev_alloc(e, &e->d_obs_cnt, (size_t)n_obs))) return rc;
+  if ((rc = dev_alloc(e, &e->d_lane_rec, lane_rec.size()))) return rc;
   e->rec_stride = ((int64_t)n_obs + 255) / 256 * 256;
   for (int k = 0; k < 2; ++k) if ((rc = dev_alloc(e, &e->d_rec[k], (size_t)6 * e->rec_stride))) return rc;
   if ((rc = dev_alloc(e, &e->d_sp, (size_t)3 * n_points))) return rc;
@@ -703,8 +726,7 @@ int pba_set_problem(pba_engine* e, int32_t n_points, const double* xyz, const do
   HIP_TRY(e, hipMemcpyAsync(e->d_obs_slot, slot8.data(), n_obs, hipMemcpyHostToDevice, e->stream));
   HIP_TRY(e, hipMemcpyAsync(e->d_pt_begin, pt_begin.data(), sizeof(int32_t) * (n_points + 1), hipMemcpyHostToDevice, e->stream));
   HIP_TRY(e, hipMemcpyAsync(e->d_tile_info, tinfo.data(), sizeof(int4) * tinfo.size(), hipMemcpyHostToDevice, e->stream));
-  HIP_TRY(e, hipMemcpyAsync(e->d_obs_l0, obs_l0.data(), n_obs, hipMemcpyHostToDevice, e->stream));
-  HIP_TRY(e, hipMemcpyAsync(e->d_obs_cnt, obs_cnt.data(), n_obs, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(e, hipMemcpyAsync(e->d_lane_rec, lane_rec.data(), sizeof(int2) * lane_rec.size(), hipMemcpyHostToDevice, e->stream));
   HIP_TRY(e, hipStreamSynchronize(e->stream));
   e->slot_mask = 0;
   for (int o = 0; o < n_obs; ++o) e->slot_mask |= 1u << slot8[o];
@@ -850,7 +872,7 @@ int pba_internal_step(pba_engine* e, double radius, int32_t init_scale, const pb
 
   SchurParams sc{};
   sc.xyz = e->d_xyz[cur]; sc.rays = e->inverse_depth ? e->d_rays : nullptr; sc.geom = e->d_geom[cur]; sc.rec = e->d_rec[cur]; sc.obs_point = e->d_obs_point;
-  sc.obs_slot = e->d_obs_slot; sc.tile_info = e->d_tile_info; sc.obs_l0 = e->d_obs_l0; sc.obs_cnt = e->d_obs_cnt; sc.sp = e->d_sp;
+  sc.obs_slot = e->d_obs_slot; sc.tile_info = e->d_tile_info; sc.lane_rec = e->d_lane_rec; sc.sp = e->d_sp;
   sc.ptrec = e->d_ptrec; sc.partial = e->d_partial; sc.rec_stride = e->rec_stride; sc.n_tiles = e->n_tiles; sc.n_frames = e->n_frames;
   sc.n_free = e->n_free; sc.n_pairs = e->n_pairs; sc.part_stride = e->part_stride; sc.init_scale = init_scale;
   sc.jacobi = o->jacobi_scaling; sc.fx = e->cfg.fx; sc.fy = e->cfg.fy; sc.radius = radius; sc.inv_radius = 1.0 / radius;
@@ -902,7 +924,7 @@ int pba_internal_step(pba_engine* e, double radius, int32_t init_scale, const pb
   if (!grad_only && fused_capable(e)) {
     // one kernel: back-substitution -> candidate pass (Jacobian pass when speculating) -> step finalisation
     SampleParams sp = make_sample_params(e, cand);
-    sp.tile_info = e->d_tile_info; sp.obs_l0 = e->d_obs_l0; sp.obs_cnt = e->d_obs_cnt; sp.geom_prev = e->d_geom[cur];
+    sp.tile_info = e->d_tile_info; sp.lane_rec = e->d_lane_rec; sp.geom_prev = e->d_geom[cur];
     sp.xyz_prev = e->d_xyz[cur]; sp.rec_prev = e->d_rec[cur]; sp.sp = e->d_sp; sp.ptrec = e->d_ptrec;
     sp.delta_c = e->d_delta_c; sp.block_bs = e->d_bs_out; sp.ticket = e->d_ticket; sp.scal = e->d_scal;
     sp.host_scal = multi ? nullptr : e->h_scal_dev; sp.host_seq = h_seq_dev; sp.seq = seq; sp.n_tiles = e->n_tiles;
@@ -1107,6 +1129,8 @@ int pba_comm_enable_peer_exchange(pba_engine* e) {
   return PBA_OK;
 }
 
+int pba_comm_rank_count(const pba_engine* e) { return e ? e->comm.rank_count() : 0; }
+
 const char* pba_comm_transport(const pba_engine* e) {
   if (!e || e->comm.kind == 0) return "none";
   if (e->comm.kind == 1) return e->comm.peer ? "rccl+peer" : "rccl";
@@ -1115,6 +1139,29 @@ const char* pba_comm_transport(const pba_engine* e) {
 
 int pba_get_counters(pba_engine* e, pba_counters* c) {
   if (!e || !c) return PBA_ERR_INVALID;
+  if (e->stamps && e->d_stamp) {
+    // device time stamps of the LAST asynchronous solve (100 MHz ticks): intervals between consecutive kernel ends
+    PBA_NOT_POISONED(e);
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    const int n_rec = std::min(e->stamp_iter, (int)kStampMaxIters) + 1;
+    std::vector<unsigned long long> st((size_t)n_rec * kStampRecord);
+    HIP_TRY(e, hipMemcpyAsync(st.data(), e->d_stamp, sizeof(unsigned long long) * st.size(), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    double d_sample = 0.0, d_schur = 0.0, d_solve = 0.0;
+    int64_t n = 0;
+    for (int it = 1; it < n_rec; ++it) {
+      const unsigned long long* r = &st[(size_t)it * kStampRecord];
+      const unsigned long long prev = st[(size_t)(it - 1) * kStampRecord + kStampEndSample];
+      unsigned long long e_schur = 0;
+      for (int b = 0; b < kStampSchurBlocks; ++b) e_schur = std::max(e_schur, r[kStampSchur0 + b]);
+      if (!prev || e_schur <= prev || r[kStampEndSolve] <= e_schur || r[kStampEndSample] <= r[kStampEndSolve]) continue;   // a step that did not run
+      d_schur += (double)(e_schur - prev); d_solve += (double)(r[kStampEndSolve] - e_schur); d_sample += (double)(r[kStampEndSample] - r[kStampEndSolve]);
+      ++n;
+    }
+    e->ctr.linearize_ms = 1e-5 * d_sample; e->ctr.linearize_launches = n;
+    e->ctr.schur_ms = 1e-5 * d_schur; e->ctr.schur_launches = n;
+    e->ctr.solve_ms = 1e-5 * d_solve; e->ctr.solve_launches = n;
+  }
   *c = e->ctr;
   return PBA_OK;
 }
@@ -1125,6 +1172,26 @@ int pba_reset_counters(pba_engine* e) {
   e->ctr = pba_counters{};
   e->ctr.n_obs = no; e->ctr.n_points = np;
   e->profile = true;   // counters are only collected once asked for
+  e->stamps = false;
+  return PBA_OK;
+}
+
+int pba_set_profiling(pba_engine* e, int32_t mode) {
+  if (!e || mode < 0 || mode > 2) return PBA_ERR_INVALID;
+  PBA_NOT_POISONED(e);
+  HIP_TRY(e, hipSetDevice(e->cfg.device));
+  const int64_t no = e->ctr.n_obs, np = e->ctr.n_points;
+  e->ctr = pba_counters{};
+  e->ctr.n_obs = no; e->ctr.n_points = np;
+  e->profile = (mode == 1);
+  e->stamps = (mode == 2);
+  e->stamp_iter = 0;
+  if (e->stamps) {
+    const int rc = dev_alloc(e, &e->d_stamp, (size_t)(kStampMaxIters + 1) * kStampRecord);
+    if (rc) return rc;
+    HIP_TRY(e, hipMemsetAsync(e->d_stamp, 0, sizeof(unsigned long long) * (kStampMaxIters + 1) * kStampRecord, e->stream));
+  }
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
   return PBA_OK;
 }
 
@@ -1174,7 +1241,7 @@ int pba_internal_async_enqueue(pba_engine* e, int kind, int init_scale, const pb
   *seq_out = 0;
   auto sample_params = [&](bool skip) {
     SampleParams sp = make_sample_params(e, skip ? cur : cand);
-    sp.tile_info = e->d_tile_info; sp.obs_l0 = e->d_obs_l0; sp.obs_cnt = e->d_obs_cnt;
+    sp.tile_info = e->d_tile_info; sp.lane_rec = e->d_lane_rec;
     sp.geom_prev = e->d_geom[skip ? cand : cur]; sp.xyz_prev = e->d_xyz[skip ? cand : cur]; sp.rec_prev = e->d_rec[skip ? cand : cur];
     sp.sp = e->d_sp; sp.ptrec = e->d_ptrec; sp.delta_c = e->d_delta_c; sp.block_bs = e->d_bs_out; sp.ticket = e->d_ticket;
     sp.scal = e->d_scal; sp.n_tiles = e->n_tiles; sp.skip_backsub = skip ? 1 : 0;
@@ -1186,6 +1253,8 @@ int pba_internal_async_enqueue(pba_engine* e, int kind, int init_scale, const pb
     // plain Jacobian pass at the current point, on the fused (tile) grid so that both parities share one block count
     SampleParams sp = sample_params(true);
     sp.lm = nullptr; sp.host_scal = nullptr; sp.host_seq = h_seq_dev; sp.seq = 0; sp.decide = 0; sp.enq_cur = cur;
+    e->stamp_iter = 0;
+    sp.stamp = stamp_record(e);
     launch_sample<true, true>(e, sp);
     e->jac_passes++;
     e->cost_blocks[0] = e->cost_blocks[1] = e->fused_grid;
@@ -1203,7 +1272,7 @@ int pba_internal_async_enqueue(pba_engine* e, int kind, int init_scale, const pb
   }
   SchurParams sc{};
   sc.xyz = e->d_xyz[cur]; sc.rays = e->inverse_depth ? e->d_rays : nullptr; sc.geom = e->d_geom[cur]; sc.rec = e->d_rec[cur]; sc.obs_point = e->d_obs_point;
-  sc.obs_slot = e->d_obs_slot; sc.tile_info = e->d_tile_info; sc.obs_l0 = e->d_obs_l0; sc.obs_cnt = e->d_obs_cnt; sc.sp = e->d_sp;
+  sc.obs_slot = e->d_obs_slot; sc.tile_info = e->d_tile_info; sc.lane_rec = e->d_lane_rec; sc.sp = e->d_sp;
   sc.ptrec = e->d_ptrec; sc.partial = e->d_partial; sc.rec_stride = e->rec_stride; sc.n_tiles = e->n_tiles; sc.n_frames = e->n_frames;
   sc.n_free = e->n_free; sc.n_pairs = e->n_pairs; sc.part_stride = e->part_stride; sc.init_scale = init_scale;
   // the previous enqueue decided on the device (last workgroup of the fused sampling kernel, or k_decide after the
@@ -1211,6 +1280,8 @@ int pba_internal_async_enqueue(pba_engine* e, int kind, int init_scale, const pb
   sc.pub_state = e->h_lm_dev; sc.pub_scal = e->d_scal; sc.pub_host_scal = e->h_scal_dev; sc.pub_host_seq = h_seq_dev; sc.pub_seq = e->seq;
   sc.jacobi = o->jacobi_scaling; sc.fx = e->cfg.fx; sc.fy = e->cfg.fy; sc.radius = 1.0; sc.inv_radius = 1.0;
   sc.min_diag = o->min_lm_diagonal; sc.max_diag = o->max_lm_diagonal; sc.dbg = nullptr;
+  if (kind == 1 && e->stamps) e->stamp_iter++;
+  sc.stamp = (kind == 1) ? stamp_record(e) : nullptr;
   sc.lm = e->d_lm; sc.enq_cur = cur; sc.final_pass = (kind == 2) ? 1 : 0; sc.xyz_alt = e->d_xyz[cand]; sc.geom_alt = e->d_geom[cand]; sc.rec_alt = e->d_rec[cand];
   launch_schur(e, sc);
   SolveParams so{};
@@ -1226,6 +1297,7 @@ int pba_internal_async_enqueue(pba_engine* e, int kind, int init_scale, const pb
   if (kind == 1) {
     SampleParams sp = sample_params(false);
     sp.lm = e->d_lm; sp.enq_cur = cur; sp.decide = multi ? 0 : 1;
+    sp.stamp = stamp_record(e);
     sp.host_scal = nullptr;     // published by the next k_schur (or k_flush): see SchurParams::pub_*
     sp.host_seq = h_seq_dev; sp.seq = seq;
     if (multi) {

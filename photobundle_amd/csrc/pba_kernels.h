@@ -103,6 +103,15 @@ __device__ __forceinline__ int xcd_logical_block(int b, int grid) {
   return x * q + (x < r ? x : r) + i;
 }
 
+// Device time stamps of the PIPELINED iteration (pba_set_profiling(e, 2)): the three kernels of an LM iteration run back
+// to back, so the interval between the END of one and the END of the next is that kernel's share of the iteration
+// (launch latency included) -- without the event records that make a kernel end with a cache write-back.  Every kernel
+// only STORES the 100 MHz counter into the iteration's record (fire and forget: nothing is loaded or awaited on the
+// critical path); the host forms the intervals afterwards.  Record of one iteration (u64):
+//   [0] end of the sampling kernel (its last workgroup, after the step finalisation)   [1] unused
+//   [2] end of the reduced solve (the solving workgroup)   [3 + b] end of k_schur's workgroup b (the host takes the maximum)
+enum StampSlot { kStampEndSample = 0, kStampEndSolve = 2, kStampSchur0 = 3, kStampSchurBlocks = 1024, kStampRecord = 3 + 1024, kStampMaxIters = 256 };
+
 // Workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, i.e. it waits for every
 // outstanding global STORE of the wave (~1 us round trip) although nothing after the barrier depends on it.
 // Global LOADS stay correct: the compiler still waits for a load's result before its first use.
@@ -650,8 +659,8 @@ struct SampleParams {
   double huber;
   // ---- FUSED only: back-substitution of the step that leads to the point being sampled, and step finalisation ----
   const int4* tile_info;      // [n_tiles] whole-point tiles of <= 128 observations (shared with k_schur)
-  const uint8_t* obs_l0;      // [n_obs]
-  const uint8_t* obs_cnt;     // [n_obs]
+  const int2* lane_rec;       // [n_tiles][128] per tile lane: {point, slot | first lane of the point << 8 | observations of the point << 16}
+                              // (indexed by tile and lane only: no dependency on the tile descriptor, one round trip less)
   const CamGeom* geom_prev;   // geometry at the CURRENT point (the linearisation the step was computed from)
   const double* xyz_prev;     // current points; `xyz` is then the OUTPUT (candidate points)
   const double* rec_prev;     // Jacobian-pass records of the current point
@@ -660,6 +669,7 @@ struct SampleParams {
   const double* delta_c;      // [n_frames][6]
   double* block_bs;           // [gridDim.x][3] mcc, step^2, x^2 partials
   unsigned int* ticket;       // arrival counter (zero between launches)
+  unsigned long long* stamp;  // null, or the device time-stamp block of pba_set_profiling(e, 2) (kStamp* below)
   double* scal;               // device scalar block
   double* host_scal;          // host-mapped copy (null: multi-rank, published later)
   unsigned long long* host_seq;
@@ -710,13 +720,12 @@ template <int NT>
 __device__ __forceinline__ FusedIdx fused_prefetch_indices(const SampleParams& p, int bid) {
   FusedIdx f{make_int4(0, 0, 0, 0), 0, 0, 0, 0};
   const int tile = bid * (NT / 128) + (int)(threadIdx.x >> 7);
-  if (tile < p.n_tiles) f.ti = p.tile_info[tile];
   const int lt = threadIdx.x & 127;
-  if (lt < f.ti.y) {
-    const int o = f.ti.x + lt;
-    f.pt = p.obs_point[o];
-    f.slot = p.obs_slot[o];
-    f.l0 = p.obs_l0[o]; f.cnt = p.obs_cnt[o];
+  if (tile < p.n_tiles) {
+    f.ti = p.tile_info[tile];
+    const int2 r = p.lane_rec[(size_t)tile * 128 + lt];      // (lanes beyond the tile's observations hold zeros)
+    f.pt = r.x;
+    f.slot = r.y & 0xff; f.l0 = (r.y >> 8) & 0xff; f.cnt = (r.y >> 16) & 0xff;
   }
   return f;
 }
@@ -926,6 +935,7 @@ __device__ __forceinline__ void fused_finalize(const SampleParams& p, int lane, 
       __syncthreads();
       lm_publish(p.lm, (p.lm && p.decide) ? p.host_state : nullptr, p.scal, p.host_scal, p.host_seq, p.seq, threadIdx.x, NTH);
     }
+    if (p.stamp && threadIdx.x == 0) p.stamp[kStampEndSample] = __builtin_amdgcn_s_memrealtime();
     if (p.dbg && threadIdx.x == 0) {
       p.dbg[(size_t)gridDim.x * 8] = __builtin_amdgcn_s_memrealtime() - t_fin0;
       p.dbg[(size_t)gridDim.x * 8 + 1] = t_fin0 - t_begin;
@@ -1795,8 +1805,8 @@ struct SchurParams {
   const int32_t* obs_point;
   const uint8_t* obs_slot;
   const int4* tile_info;        // [n_tiles] {first observation, observations, first point, points} (whole points)
-  const uint8_t* obs_l0;        // [n_obs] lane (within its tile) of the first observation of the observation's point
-  const uint8_t* obs_cnt;       // [n_obs] number of observations of that point
+  const int2* lane_rec;         // [n_tiles][kTile] per tile lane: {point, slot | first lane of the observation's point << 8 | number of
+                                // observations of that point << 16}; independent of the tile descriptor (requested with it)
   double* sp;                   // [n_points][3] Jacobi scale of the point columns (written when init_scale)
   double* ptrec;                // [n_points][12]: P (6, sym packed 00 01 02 11 12 22), g_p (3), D_p^2 (3)
   double* partial;              // [gridDim.x][part_stride]
@@ -1820,6 +1830,7 @@ struct SchurParams {
   // rather than at the end of the sampling kernel that produced the outcome (measured: 6 us per iteration)
   LmState* pub_state; const double* pub_scal; double* pub_host_scal;
   unsigned long long* pub_host_seq; unsigned long long pub_seq;
+  unsigned long long* stamp;   // null, or the device time-stamp block (kStamp*)
 };
 
 __device__ __forceinline__ int sym6(int i, int j) {  // packed upper triangle of a symmetric 6x6 (21 entries)
@@ -1902,9 +1913,11 @@ __global__ __launch_bounds__(kTile, 2) void k_schur(SchurParams p_in) {
   // per-observation phase starts with its second round trip (point, Jacobi scale, record) instead of its first
   int nx_pt = 0, nx_slot = 0, nx_l0 = 0, nx_cnt = 0;
   double nx_x[3] = {0.0, 0.0, 0.0};
+  {
+    const int2 r = p.lane_rec[(size_t)min((int)blockIdx.x, p.n_tiles - 1) * kTile + tid];     // with the descriptor, not after it
+    nx_pt = r.x; nx_slot = r.y & 0xff; nx_l0 = (r.y >> 8) & 0xff; nx_cnt = (r.y >> 16) & 0xff;
+  }
   if (tid < ti_next.y) {
-    const int o = ti_next.x + tid;
-    nx_pt = p.obs_point[o]; nx_slot = p.obs_slot[o]; nx_l0 = p.obs_l0[o]; nx_cnt = p.obs_cnt[o];
     nx_x[0] = p.xyz[3 * (size_t)nx_pt]; nx_x[1] = p.xyz[3 * (size_t)nx_pt + 1]; nx_x[2] = p.xyz[3 * (size_t)nx_pt + 2];
   }
   for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
@@ -2095,9 +2108,9 @@ __global__ __launch_bounds__(kTile, 2) void k_schur(SchurParams p_in) {
     }
     lds_barrier();
     PBA_TICK(3);
-    if (tile + (int)gridDim.x < p.n_tiles && tid < ti_next.y) {      // next tile's indices: two phases ahead of its coordinates
-      const int o = ti_next.x + tid;
-      nx_pt = p.obs_point[o]; nx_slot = p.obs_slot[o]; nx_l0 = p.obs_l0[o]; nx_cnt = p.obs_cnt[o];
+    if (tile + (int)gridDim.x < p.n_tiles) {      // next tile's indices: two phases ahead of its coordinates
+      const int2 r = p.lane_rec[(size_t)(tile + (int)gridDim.x) * kTile + tid];
+      nx_pt = r.x; nx_slot = r.y & 0xff; nx_l0 = (r.y >> 8) & 0xff; nx_cnt = (r.y >> 16) & 0xff;
     }
 
     // ---- P3b: camera-side sums of [U_l | r_l | g_c,l] by camera -------------------------------------------------
@@ -2237,6 +2250,7 @@ __global__ __launch_bounds__(kTile, 2) void k_schur(SchurParams p_in) {
       out[36 * p.n_pairs + 3 * n + 0] = m;
       out[36 * p.n_pairs + 3 * n + 1] = a;
       out[36 * p.n_pairs + 3 * n + 2] = f;
+      if (p.stamp && blockIdx.x < kStampSchurBlocks) p.stamp[kStampSchur0 + blockIdx.x] = __builtin_amdgcn_s_memrealtime();
     }
   }
 }
@@ -3168,6 +3182,7 @@ struct ReduceSolveParams {
   const double* block_cost_alt; const int32_t* block_fail_alt;
   double* packed; double* scal;
   unsigned int* ticket;          // zero between launches
+  unsigned long long* stamp;     // null, or the device time-stamp block (kStamp*)
   SolveParams so;                // lm / enq_cur / final_pass of the step live here
 };
 
@@ -3257,6 +3272,7 @@ __global__ __launch_bounds__(1024) void k_reduce_solve(ReduceSolveParams rp) {
   }
   if (wide) solve_blocked<true, 1024>(so, reinterpret_cast<double*>(dyn_smem), tid);
   else solve_blocked<true, kSolveBlockedThreads>(so, reinterpret_cast<double*>(dyn_smem), tid);
+  if (rp.stamp && tid == 0) rp.stamp[kStampEndSolve] = __builtin_amdgcn_s_memrealtime();
   if (PBA_PHASE_TIMING && rp.so.dbg && tid == 0)
     printf("k_reduce_solve: last workgroup %d of %d reached the solve %.2f us after its own start, finished it %.2f us later\n", (int)blockIdx.x,
            (int)gridDim.x, 0.01 * (double)(t_k1 - t_k0), 0.01 * (double)(__builtin_amdgcn_s_memrealtime() - t_k1));

@@ -210,6 +210,9 @@ class Engine:
         self._check(self._L.pba_comm_enable_peer_exchange(self._h), "pba_comm_enable_peer_exchange")
         return self.comm_transport()
 
+    def comm_rank_count(self):
+        return int(self._L.pba_comm_rank_count(self._h))
+
     def comm_transport(self):
         self._L.pba_comm_transport.restype = C.c_char_p
         return self._L.pba_comm_transport(self._h).decode()
@@ -231,6 +234,10 @@ class Engine:
     # ---- counters ----------------------------------------------------------------------------------------------
     def reset_counters(self):
         self._check(self._L.pba_reset_counters(self._h), "pba_reset_counters")
+
+    def set_profiling(self, mode):
+        """0 off, 1 HIP events around every kernel (host-stepped driver), 2 device time stamps in the asynchronous pipeline."""
+        self._check(self._L.pba_set_profiling(self._h, int(mode)), "pba_set_profiling")
 
     def counters(self):
         c = _lib.Counters()

@@ -6,7 +6,7 @@ TAG=${1:-final}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $OLDPWD/bench.py --no-cpu-baseline"
+BENCH="python $OLDPWD/bench.py --no-cpu-baseline --repeats 3"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o s -- $BENCH > "$OUT/bench_under_rocprof.json" 2> /dev/null
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o f -- $BENCH > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o w -- $BENCH > /dev/null 2>&1
