@@ -124,52 +124,86 @@ def main():
     n_obs_local = prob.n_obs
     n_bar = n_obs_local / prob.n_points
 
-    eng = Engine(rows, cols, prob.K, prob.radius, prob.n_frames, huber=prob.huber, device=local_rank, precision=args.precision,
-                 channels=args.channels)
-    eng.load(prob)
     rays = rho0 = None
     if args.inverse_depth:
         rays, rho0 = synthetic.inverse_depth_rays(prob)
-        eng.set_inverse_depth(rays, rho0)
+
+    def opts(k):
+        # fixed iteration count: tolerances disabled (SURVEY.md 8d "Fixed 10 LM iterations for throughput")
+        return default_solver_options(max_num_iterations=k, function_tolerance=0.0, gradient_tolerance=0.0,
+                                      parameter_tolerance=0.0)
+
+    def new_engine():
+        e_ = Engine(rows, cols, prob.K, prob.radius, prob.n_frames, huber=prob.huber, device=local_rank, precision=args.precision,
+                    channels=args.channels)
+        e_.load(prob)
+        if args.inverse_depth:
+            e_.set_inverse_depth(rays, rho0)
+        return e_
+
+    def all_ranks_ok(ok):
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=ctl)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return int(flag.item()) == 1
+
+    def _allreduce(a, op):          # host-staged transport through torch.distributed (callback of pba_comm_init_callback)
+        t = torch.from_numpy(a.copy()).to(ctl)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX if op == 1 else dist.ReduceOp.SUM)
+        a[:] = t.cpu().numpy()
+
+    def join_transport(e_, want_rccl):
+        """Collective.  RCCL (device-direct all-reduces on the engine's stream) when every rank can, else host-staged."""
+        if want_rccl:
+            uid = torch.zeros(129, dtype=torch.uint8, device=ctl)     # 128-byte ncclUniqueId + "valid" byte
+            if rank == 0:
+                try:
+                    raw = bytearray(Engine.comm_unique_id()) + bytearray([1])
+                    uid.copy_(torch.frombuffer(raw, dtype=torch.uint8))
+                except Exception as exc:
+                    print("rank 0: no RCCL unique id (%s)" % exc, file=sys.stderr)
+            dist.broadcast(uid, 0)
+            uid_host = uid.cpu().numpy()
+            ok = bool(uid_host[128])
+            if ok:
+                try:
+                    e_.comm_init_rccl(bytes(uid_host[:128].tobytes()), rank, world)
+                except Exception as exc:
+                    print("rank %d: RCCL transport unavailable (%s)" % (rank, exc), file=sys.stderr)
+                    ok = False
+            if all_ranks_ok(ok):
+                return e_, "RCCL all-reduce of the reduced camera system"
+            if ok:               # mixed outcome: a fresh engine, so that every rank uses the same transport
+                e_.close()
+                e_ = new_engine()
+        e_.comm_init_callback(_allreduce, rank, world)
+        return e_, "host-staged all-reduce via torch.distributed" + (" (RCCL init failed)" if want_rccl else "")
+
+    if world > 1:
+        os.environ.setdefault("PBA_WAIT_TIMEOUT_S", "60")      # read at pba_create: a stuck exchange is an error after 60 s, not a hang
+    eng = new_engine()
     transport = "RCCL all-reduce of the reduced camera system"
     if world > 1:
-        uid = torch.zeros(129, dtype=torch.uint8, device=ctl)     # 128-byte ncclUniqueId + "valid" byte
-        if rank == 0:
-            try:
-                raw = bytearray(Engine.comm_unique_id()) + bytearray([1])
-                uid.copy_(torch.frombuffer(raw, dtype=torch.uint8))
-            except Exception as exc:
-                print("rank 0: no RCCL unique id (%s)" % exc, file=sys.stderr)
-        dist.broadcast(uid, 0)
-        uid_host = uid.cpu().numpy()
-        rccl_ok = int(uid_host[128])
-        if rccl_ok:
-            try:
-                eng.comm_init_rccl(bytes(uid_host[:128].tobytes()), rank, world)
-            except Exception as exc:     # keep the multi-GPU line alive: host-staged all-reduce through torch.distributed
-                print("rank %d: RCCL transport unavailable (%s), falling back to the host-staged transport" % (rank, exc), file=sys.stderr)
-                rccl_ok = 0
-        flag = torch.tensor([rccl_ok], dtype=torch.int32, device=ctl)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0:
-            transport = "host-staged all-reduce via torch.distributed (RCCL init failed)"
-            def _allreduce(a, op):
-                t = torch.from_numpy(a.copy()).to(ctl)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX if op == 1 else dist.ReduceOp.SUM)
-                a[:] = t.cpu().numpy()
-            if rccl_ok:          # mixed outcome: rebuild the engine so that every rank uses the same transport
-                eng.close()
-                eng = Engine(rows, cols, prob.K, prob.radius, prob.n_frames, huber=prob.huber, device=local_rank,
-                             precision=args.precision, channels=args.channels)
-                eng.load(prob)
-                if args.inverse_depth:
-                    eng.set_inverse_depth(rays, rho0)
-            eng.comm_init_callback(_allreduce, rank, world)
-    if world > 1 and os.environ.get("PBA_PEER", "1") != "0":
-        # per-step exchanges as device-side mailbox reads over peer-mapped memory (no collective launch per LM step); the
-        # call is collective and every rank ends up with the same answer -- the base transport stays when IPC is unavailable
-        eng.comm_enable_peer_exchange()
-    if world > 1:
+        eng, transport = join_transport(eng, backend == "nccl")
+        if os.environ.get("PBA_PEER", "1") != "0":
+            # per-step exchanges as device-side mailbox reads over peer-mapped memory (no collective launch per LM step); the
+            # call is collective and every rank ends up with the same answer -- the base transport stays when IPC is unavailable.
+            # The path is then exercised once before anything is timed: should it fail on ANY rank (it has only ever run
+            # between two processes on one device), every rank rebuilds its engine on the base transport alone.
+            eng.comm_enable_peer_exchange()
+            if eng.comm_transport().endswith("+peer"):
+                try:
+                    eng.solve(opts(2))
+                    ok = True
+                except Exception as exc:
+                    print("rank %d: peer exchange failed its self-test (%s)" % (rank, exc), file=sys.stderr)
+                    ok = False
+                if not all_ranks_ok(ok):
+                    try:
+                        eng.close()
+                    except Exception:
+                        pass
+                    eng = new_engine()
+                    eng, transport = join_transport(eng, backend == "nccl")
         transport = "%s (%s)" % (transport, eng.comm_transport())
     elif os.environ.get("PBA_FORCE_MULTI") == "1":
         # diagnostics: the multi-rank code path (RCCL all-reduces on the engine's stream, k_decide) at world = 1
@@ -186,11 +220,6 @@ def main():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
-
-    def opts(k):
-        # fixed iteration count: tolerances disabled (SURVEY.md 8d "Fixed 10 LM iterations for throughput")
-        return default_solver_options(max_num_iterations=k, function_tolerance=0.0, gradient_tolerance=0.0,
-                                      parameter_tolerance=0.0)
 
     if args.warmup > 0:
         eng.solve(opts(args.warmup))

@@ -2816,9 +2816,10 @@ __host__ __device__ inline size_t solve_blocked_smem_bytes(int n) {
 template <bool AGENT>
 __device__ __forceinline__ double packed_load(const double* p) { return AGENT ? load_agent(p) : *p; }
 
-// Candidate camera geometry with the work of one camera spread over 32 lanes (cam_geom_one is ~400 dependent-ish fp64
-// operations in one lane; here every lane repeats the short scalar part -- angle, sine, cosine -- and then produces
-// its own entries of R, B and dR).  Same formulas and operand order as cam_geom_one entry by entry.
+// Candidate camera geometry with the work of one camera spread over 32 consecutive lanes (cam_geom_one is ~400 fp64
+// operations, nine of them divisions, in ONE lane on the serial stretch of every LM iteration).  Every lane repeats the
+// short scalar part (angle, sine / cosine, R); lanes 0..8 then hold one entry of B each, and lanes 0..26 form one entry
+// of dR = R [B_k]x each from three cross-lane reads of B's column k.  Same formulas and operand order as cam_geom_one.
 __device__ inline void cam_geom_spread(const double cam6[6], CamGeom* __restrict__ out, int c, int fixed_slot, int sub) {
   const double wx = cam6[0], wy = cam6[1], wz = cam6[2];
   const double theta2 = wx * wx + wy * wy + wz * wz;
@@ -2830,7 +2831,10 @@ __device__ inline void cam_geom_spread(const double cam6[6], CamGeom* __restrict
     g.free_index = (c == fixed_slot) ? -1 : (fixed_slot >= 0 && c > fixed_slot ? c - 1 : c);
     g.pad = 0;
   }
-  if (rod) {
+  const int e9 = sub < 9 ? sub : 8;                 // entry of a 3x3 this lane is responsible for (lanes 0..8)
+  const int ei = e9 / 3, ej = e9 - 3 * ei;
+  double Rv, dRv;
+  if (rod) {                                         // (uniform over the 32 lanes of a camera)
     const double theta = sqrt(theta2);
     double ct, st;
     sincos_angle(theta, st, ct);
@@ -2842,56 +2846,55 @@ __device__ inline void cam_geom_spread(const double cam6[6], CamGeom* __restrict
                          -ay * st + ax * az * oc, ax * st + ay * az * oc, ct + az * az * oc};
     if (sub < 3) g.w[sub] = (sub == 0) ? ax : (sub == 1 ? ay : az);
     if (sub == 4) { g.ct = ct; g.st = st; }
-    if (sub < 9) { double r = R[0]; for (int k = 1; k < 9; ++k) r = (sub == k) ? R[k] : r; g.R[sub] = r; }
-    if (sub < 27) {
-      // dR[9 k + 3 i + j] = sum_m R[3 i + m] * Bx_k[3 m + j],  Bx_k = [column k of B]x
-      const int k = sub / 9, ij = sub - 9 * k, i = ij / 3, j = ij - 3 * i;
-      const double W[3] = {wx, wy, wz};
-      const double Wx[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
-      double bcol[3];
+    Rv = R[0];
 #pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        // B[3 r + k] for the lane's k
-        double acc = 0.0;
+    for (int k = 1; k < 9; ++k) Rv = (e9 == k) ? R[k] : Rv;
+    // lanes 0..8: B[3 i + j] = (w_i w_j + sum_q (R[3 q + i] - delta_iq) Wx[3 q + j]) / theta^2   (i = ei, j = ej)
+    const double W3[3] = {wx, wy, wz};
+    const double Wx[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
+    double wi = W3[0], wj = W3[0];
 #pragma unroll
-        for (int kk = 0; kk < 3; ++kk) {
-          if (kk != k) continue;
-          acc = W[r] * W[kk];
+    for (int k = 1; k < 3; ++k) { wi = (ei == k) ? W3[k] : wi; wj = (ej == k) ? W3[k] : wj; }
+    double acc = wi * wj;
 #pragma unroll
-          for (int q = 0; q < 3; ++q) acc += (R[3 * q + r] - (r == q ? 1.0 : 0.0)) * Wx[3 * q + kk];
-        }
-        bcol[r] = acc / theta2;
-      }
-      const double b0 = bcol[0], b1 = bcol[1], b2 = bcol[2];
-      const double Bx[9] = {0, -b2, b1, b2, 0, -b0, -b1, b0, 0};
-      double acc = 0.0;
+    for (int q = 0; q < 3; ++q) {
+      double rqi = R[3 * q], wxqj = Wx[3 * q];
 #pragma unroll
-      for (int ii = 0; ii < 3; ++ii) {
-        if (ii != i) continue;
-#pragma unroll
-        for (int jj = 0; jj < 3; ++jj) {
-          if (jj != j) continue;
-          acc = 0.0;
-#pragma unroll
-          for (int m = 0; m < 3; ++m) acc += R[3 * ii + m] * Bx[3 * m + jj];
-        }
-      }
-      g.dR[sub] = acc;
+      for (int k = 1; k < 3; ++k) { rqi = (ei == k) ? R[3 * q + k] : rqi; wxqj = (ej == k) ? Wx[3 * q + k] : wxqj; }
+      acc += (rqi - (ei == q ? 1.0 : 0.0)) * wxqj;
     }
+    const double Bv = acc / theta2;
+    // lanes 0..26: dR[9 k + 3 i + j] = sum_m R[3 i + m] Bx_k[3 m + j],  Bx_k = [column k of B]x
+    const int s27 = sub < 27 ? sub : 26;
+    const int k = s27 / 9, ij = s27 - 9 * k, i = ij / 3, j = ij - 3 * i;
+    const int base = threadIdx.x & ~31;              // first lane of this camera's group within the wave (32-lane groups)
+    const int lane0 = (base & 63);
+    const double b0 = __shfl(Bv, lane0 + k), b1 = __shfl(Bv, lane0 + 3 + k), b2 = __shfl(Bv, lane0 + 6 + k);
+    const double r0 = __shfl(Rv, lane0 + 3 * i), r1 = __shfl(Rv, lane0 + 3 * i + 1), r2 = __shfl(Rv, lane0 + 3 * i + 2);
+    // column j of Bx = [0 -b2 b1; b2 0 -b0; -b1 b0 0]
+    const double x0 = (j == 0) ? 0.0 : (j == 1 ? -b2 : b1);
+    const double x1 = (j == 0) ? b2 : (j == 1 ? 0.0 : -b0);
+    const double x2 = (j == 0) ? -b1 : (j == 1 ? b0 : 0.0);
+    double a3 = 0.0;
+    a3 += r0 * x0; a3 += r1 * x1; a3 += r2 * x2;
+    dRv = a3;
   } else {
     if (sub < 3) g.w[sub] = 0.0;
     if (sub == 4) { g.ct = 1.0; g.st = 0.0; }
     const double R[9] = {1, -wz, wy, wz, 1, -wx, -wy, wx, 1};
-    if (sub < 9) { double r = R[0]; for (int k = 1; k < 9; ++k) r = (sub == k) ? R[k] : r; g.R[sub] = r; }
-    if (sub < 27) {
-      const int k = sub / 9, m = sub - 9 * k;
-      const double e0 = (k == 0), e1 = (k == 1), e2 = (k == 2);
-      const double Ex[9] = {0, -e2, e1, e2, 0, -e0, -e1, e0, 0};
-      double r = Ex[0];
-      for (int q = 1; q < 9; ++q) r = (m == q) ? Ex[q] : r;
-      g.dR[sub] = r;
-    }
+    Rv = R[0];
+#pragma unroll
+    for (int k = 1; k < 9; ++k) Rv = (e9 == k) ? R[k] : Rv;
+    const int s27 = sub < 27 ? sub : 26;
+    const int k = s27 / 9, m = s27 - 9 * k;
+    const double e0 = (k == 0), e1 = (k == 1), e2 = (k == 2);
+    const double Ex[9] = {0, -e2, e1, e2, 0, -e0, -e1, e0, 0};
+    dRv = Ex[0];
+#pragma unroll
+    for (int q = 1; q < 9; ++q) dRv = (m == q) ? Ex[q] : dRv;
   }
+  if (sub < 9) g.R[sub] = Rv;
+  if (sub < 27) g.dR[sub] = dRv;
 }
 
 // T threads: 256 (four waves) up to eight free cameras, 1024 beyond (phase B of a 90 x 90 system has up to 644 work items)
@@ -3125,6 +3128,7 @@ __device__ inline void solve_blocked(SolveParams& p, double* smem, int tid) {
       cam_geom_spread(cam6, p.geom_cand, c, p.fixed_slot, tid & 31);
     }
   }
+  PBA_TS(5);
   if (tid < 64) {
     double mcc = 0.0, st2 = 0.0, x2 = 0.0, gmax = 0.0, gn2 = 0.0, bad = 0.0;
     for (int i = tid; i < n; i += 64) {
@@ -3156,8 +3160,8 @@ __device__ inline void solve_blocked(SolveParams& p, double* smem, int tid) {
   }
   PBA_TS(4);
   if (PBA_PHASE_TIMING && p.dbg && tid == T - 1)
-    printf("solve_blocked n %d cycles: prologue %llu (first round trip %llu, tables %llu, scatter %llu) factorisation %llu (phase A %llu, phase B %llu) substitution %llu epilogue (geometry lane) %llu\n",
-           n, ts[1] - ts[0], tsp[0] - ts[0], tsp[1] - tsp[0], ts[1] - tsp[1], ts[2] - ts[1], tsa, tsb, ts[3] - ts[2], ts[4] - ts[3]);
+    printf("solve_blocked n %d cycles: prologue %llu (first round trip %llu, tables %llu, scatter %llu) factorisation %llu (phase A %llu, phase B %llu) substitution %llu epilogue (geometry lane) %llu (to the end of the geometry %llu)\n",
+           n, ts[1] - ts[0], tsp[0] - ts[0], tsp[1] - tsp[0], ts[1] - tsp[1], ts[2] - ts[1], tsa, tsb, ts[3] - ts[2], ts[4] - ts[3], ts[5] - ts[3]);
 #undef PBA_TS
 }
 
