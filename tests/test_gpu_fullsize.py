@@ -295,3 +295,36 @@ def test_configs3_determinism_and_monotone_cost(window_configs3):
             assert it["cost"] < cost
             cost = it["cost"]
     assert a["final_cost"] == cost < a["initial_cost"]
+
+
+@pytest.mark.timeout(2400)
+def test_configs1_shape_multichannel_descriptors():
+    """BASELINE configs[1] shape (8 frames x 50k points, 5x5) with IntensityAndGradient descriptors (3 channels, 75
+    residuals per block; reference photobundle.cc:229-245, :708-723) on the fused + asynchronous pipeline: cost and all
+    400k Jacobian-pass records against the oracle, 4 LM iterations of trace parity, bit determinism."""
+    from oracle import oracle
+    from photobundle_amd import synthetic
+    from photobundle_amd.engine import default_solver_options
+    from gpu_util import check_obs_records, make_engine
+    p = synthetic.make_window(n_frames=8, n_points=50000, radius=2, channel_fn=synthetic.channel_fn("IntensityAndGradient"))
+    assert p.n_obs == 400000 and p.channels == 3 and p.desc.shape[1] == 75
+    c_ref, sq = oracle.cost(p, threads=8)
+    with make_engine(p, keep_reduced_system=False) as e:
+        c = e.linearize()
+        assert np.isclose(c, c_ref, rtol=1e-12)
+        rec = e.obs_records()
+        assert np.allclose(rec[:, 5], 0.5 * sq, rtol=1e-12)
+        worst = check_obs_records(p, rec, threads=8)
+        print("configs[1] shape, 3 channels: record check, worst relative block errors:", worst)
+    del rec, sq
+    n_it = 4
+    ref = oracle.solve(p, oracle.default_options(max_num_iterations=n_it, num_threads=8, use_autodiff=0))
+    runs = []
+    for _ in range(2):
+        with make_engine(p, keep_reduced_system=False) as e:
+            runs.append(e.solve(default_solver_options(max_num_iterations=n_it)))
+    res = runs[0]
+    assert np.array_equal(res["cams"], runs[1]["cams"]) and res["final_cost"] == runs[1]["final_cost"]
+    rr, rt = _trace_parity(ref, res)
+    assert res["num_residuals"] == 400000 * 75
+    print("configs[1] shape, 3 channels, %d iterations: pose RMSE rot %.3e rad, trans %.3e m" % (n_it, rr, rt))

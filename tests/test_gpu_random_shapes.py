@@ -23,6 +23,7 @@ pytestmark = pytest.mark.gpu
 
 def _draw_cases(n, seed=20260928):
     rng = np.random.default_rng(seed)
+    rng_ch = np.random.default_rng(seed + 1)      # separate stream: the shapes of the round-2 sweep stay what they were
     cases = []
     for k in range(n):
         rows = int(rng.integers(72, 160))
@@ -35,6 +36,9 @@ def _draw_cases(n, seed=20260928):
             huber=float(rng.choice([0.0, 0.0, 0.05, 0.5, 5.0])), gaussian=bool(rng.random() < 0.3),
             rot_deg=float(rng.choice([0.05, 0.1, 0.5, 2.0])), trans=float(rng.choice([0.01, 0.02, 0.1, 0.4])),
             seed_offset=100 + k))
+        # descriptor channels of the residual blocks (reference Options::descriptorType): mostly Intensity, some
+        # IntensityAndGradient (3) / BitPlanes (8) -- the fused multi-channel kernel with the asynchronous driver
+        cases[-1]["channels"] = int(rng_ch.choice([1, 1, 1, 1, 3, 8]))
     return cases
 
 
@@ -42,9 +46,10 @@ CASES = _draw_cases(int(os.environ.get("PBA_RANDOM_CASES", "24")))      # the fi
 
 
 def _make(c):
+    ch_fn = synthetic.channel_fn({3: "IntensityAndGradient", 8: "BitPlanes"}[c["channels"]]) if c.get("channels", 1) > 1 else None
     p = synthetic.make_window(n_frames=c["n_frames"], n_points=c["n_points"], radius=c["radius"], size=c["size"], K=c["K"],
                               visibility=c["visibility"], huber=c["huber"], gaussian=c["gaussian"], rot_deg=c["rot_deg"],
-                              trans=c["trans"], seed_offset=c["seed_offset"])
+                              trans=c["trans"], seed_offset=c["seed_offset"], channel_fn=ch_fn)
     if c["ragged"]:
         rng = np.random.default_rng(c["seed_offset"])
         begin = np.searchsorted(p.obs_point, np.arange(p.n_points + 1))
@@ -59,7 +64,7 @@ def _make(c):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("case", CASES, ids=["%02d-f%d-r%d-%s%s" % (i, c["n_frames"], c["radius"], c["visibility"], "-ragged" if c["ragged"] else "")
+@pytest.mark.parametrize("case", CASES, ids=["%02d-f%d-r%d-c%d-%s%s" % (i, c["n_frames"], c["radius"], c["channels"], c["visibility"], "-ragged" if c["ragged"] else "")
                                              for i, c in enumerate(CASES)])
 def test_random_shape(case):
     print("case:", case)
