@@ -98,7 +98,9 @@ def test_rccl_collectives_on_the_device_stream(tmp_path):
         "from gpu_util import make_engine\n"
         "import test_gpu_multirank as t\n"
         "p = t._make()\n"
+        "import os\n"
         "e = make_engine(p); e.comm_init_rccl(Engine.comm_unique_id(), 0, 1)\n"
+        "if os.environ.get('PBA_TEST_PEER') == '1': assert e.comm_enable_peer_exchange() == 'rccl+peer'\n"
         "res = e.solve(default_solver_options(max_num_iterations=8))\n"
         "e.load(p); conv = e.solve(default_solver_options(max_num_iterations=200, function_tolerance=1e-4)); e.close()\n"
         "np.savez(%r + '/out_' + sys.argv[1] + '.npz', cams=res['cams'], xyz=res['xyz'], costs=np.array([i['cost'] for i in res['iterations']]),"
@@ -106,13 +108,18 @@ def test_rccl_collectives_on_the_device_stream(tmp_path):
         " conv_type=conv['termination_type'])\n"
     ) % (ROOT, os.path.join(ROOT, "tests"), str(tmp_path))
     outs = {}
-    for tag, env in [("plain", {}), ("multi_async", {"PBA_FORCE_MULTI": "1"}), ("multi_sync", {"PBA_FORCE_MULTI": "1", "PBA_ASYNC": "0"})]:
+    for tag, env in [("plain", {}), ("multi_async", {"PBA_FORCE_MULTI": "1"}), ("multi_sync", {"PBA_FORCE_MULTI": "1", "PBA_ASYNC": "0"}),
+                     ("peer_async", {"PBA_FORCE_MULTI": "1", "PBA_TEST_PEER": "1"}), ("peer_sync", {"PBA_FORCE_MULTI": "1", "PBA_TEST_PEER": "1", "PBA_ASYNC": "0"})]:
         r = subprocess.run([sys.executable, "-c", code, tag], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-3000:]
         outs[tag] = np.load(tmp_path / ("out_%s.npz" % tag))
     # same driver, same kernels, collectives are identities at world = 1: bit-identical
     assert np.array_equal(outs["multi_async"]["costs"], outs["plain"]["costs"])
     assert np.array_equal(outs["multi_async"]["cams"], outs["plain"]["cams"]) and np.array_equal(outs["multi_async"]["xyz"], outs["plain"]["xyz"])
+    # the peer exchange at world = 1 (this rank's mailbox is its only peer): k_peer_allreduce instead of ncclAllReduce, same bits
+    assert np.array_equal(outs["peer_async"]["costs"], outs["plain"]["costs"]) and np.array_equal(outs["peer_async"]["cams"], outs["plain"]["cams"])
+    assert np.array_equal(outs["peer_async"]["conv_costs"], outs["plain"]["conv_costs"]) and int(outs["peer_async"]["conv_type"]) == 0
+    assert np.array_equal(outs["peer_sync"]["costs"], outs["multi_sync"]["costs"]) and np.array_equal(outs["peer_sync"]["cams"], outs["multi_sync"]["cams"])
     # the synchronous driver linearises the first point on a different workgroup grid (different summation order)
     assert np.allclose(outs["multi_sync"]["costs"], outs["plain"]["costs"], rtol=1e-11)
     assert np.abs(outs["multi_sync"]["cams"] - outs["plain"]["cams"]).max() <= 1e-9
