@@ -91,7 +91,7 @@ struct pba_engine {
   unsigned long long* d_stamp = nullptr;    // [kStampMaxIters + 1][kStampRecord] device time stamps of the pipelined iterations (pba_set_profiling(e, 2))
   bool stamps = false;
   int stamp_iter = 0;                       // record of the iteration being enqueued (0: the first linearisation)
-  int solve_kind = 0;               // PBA_SOLVE: 0 blocked workgroup Cholesky (fused with the reduction at one rank), 1 one/two-wave kernels, 2 generic
+  int solve_kind = 0;               // PBA_SOLVE: 0 blocked workgroup L D L^T (fused with the reduction at one rank), 1 k_solve_generic (diagnostics)
   // asynchronous driver (device-side trust-region decisions)
   LmState* d_lm = nullptr;          // device state
   LmState* h_lm = nullptr;          // host-mapped mirror, written at every publish
@@ -252,35 +252,11 @@ void ev_collect(pba_engine* e) {
   }
 }
 
-template <int NF>
-void launch_solve_wave(pba_engine* e, const SolveParams& so) {
-  hipLaunchKernelGGL((k_solve_wave<NF>), dim3(1), dim3(256), 0, e->stream, so);
-}
 void launch_solve(pba_engine* e, const SolveParams& so, int n) {
   if (e->solve_kind == 0) {
     if (e->n_free > kSolveNarrowFree) hipLaunchKernelGGL((k_solve_blocked<1024>), dim3(1), dim3(1024), solve_blocked_smem_bytes(n), e->stream, so);
     else hipLaunchKernelGGL((k_solve_blocked<kSolveBlockedThreads>), dim3(1), dim3(kSolveBlockedThreads), solve_blocked_smem_bytes(n), e->stream, so);
     return;
-  }
-  if (e->solve_kind == 1) {
-  switch (e->n_free) {
-    case 1: launch_solve_wave<1>(e, so); return;
-    case 2: launch_solve_wave<2>(e, so); return;
-    case 3: launch_solve_wave<3>(e, so); return;
-    case 4: launch_solve_wave<4>(e, so); return;
-    case 5: launch_solve_wave<5>(e, so); return;
-    case 6: launch_solve_wave<6>(e, so); return;
-    case 7: launch_solve_wave<7>(e, so); return;
-    case 8: launch_solve_wave<8>(e, so); return;
-    case 9: launch_solve_wave<9>(e, so); return;
-    case 10: launch_solve_wave<10>(e, so); return;
-    case 11: hipLaunchKernelGGL((k_solve_wave2<11>), dim3(1), dim3(128), 0, e->stream, so); return;
-    case 12: hipLaunchKernelGGL((k_solve_wave2<12>), dim3(1), dim3(128), 0, e->stream, so); return;
-    case 13: hipLaunchKernelGGL((k_solve_wave2<13>), dim3(1), dim3(128), 0, e->stream, so); return;
-    case 14: hipLaunchKernelGGL((k_solve_wave2<14>), dim3(1), dim3(128), 0, e->stream, so); return;
-    case 15: hipLaunchKernelGGL((k_solve_wave2<15>), dim3(1), dim3(128), 0, e->stream, so); return;
-    default: break;
-  }
   }
   const size_t solve_smem = sizeof(double) * ((size_t)n * (n + 1) + 5 * n);
   hipLaunchKernelGGL(k_solve_generic, dim3(1), dim3(kSolveThreads), solve_smem, e->stream, so);

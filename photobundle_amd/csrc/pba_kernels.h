@@ -2482,262 +2482,11 @@ __device__ __forceinline__ void solve_epilogue(const SolveParams& p, int n, cons
   }
 }
 
-// Fast path, n = 6 NF <= 60: lane r of wave 0 keeps row r of L in registers (compile-time indexed) and runs a
-// left-looking factorisation whose DEPENDENT chain never touches LDS: per column the newest entry L_j,j-1, the running
-// diagonal of the next pivot row and the right-hand side entry cross the wave with v_readlane (the values land in
-// SGPRs and feed the next FMA directly), and every lane derives the pivot's reciprocal square root itself.  LDS only
-// carries the OLDER entries of row j + 1 (written at least one column earlier, read as wave-uniform 16-byte broadcasts)
-// for the prefix sums, which are throughput work that fills the latency slots of the chain.  Arithmetic (operand order
-// of every sum) is that of k_solve_wave2.  The other three waves only help with the prologue / epilogue.
-template <int NF>
-__global__ __launch_bounds__(256) void k_solve_wave(SolveParams p_in) {
-  SolveParams p = p_in;
-  if (!PBA_PHASE_TIMING) p.dbg = 0;
-  if (!solve_resolve(p)) return;
-  constexpr int N = 6 * NF;
-  constexpr int LD = N + 1;
-  constexpr int LE = N + (N & 1) + 2;       // even stride: 16-byte aligned pairs for the broadcast reads
-  __shared__ double S[N * LD];
-  __shared__ __attribute__((aligned(16))) double LT[N * LE];
-  __shared__ double y_s[N], sc[N], D2[N], gcs[N], gc[N];
-  __shared__ int s_ok;
-  const int tid = threadIdx.x;
-  unsigned long long t0 = (PBA_PHASE_TIMING ? __builtin_amdgcn_s_memtime() : 0ull), t1 = 0, t2 = 0, t3 = 0, t4 = 0;
-  solve_prologue<256>(p, N, LD, S, y_s, sc, D2, gcs, gc, tid);
-  t1 = (PBA_PHASE_TIMING ? __builtin_amdgcn_s_memtime() : 0ull);
-  if (p.final_pass && !p.init_scale) {
-    if (tid == 0) s_ok = 1;      // gradient-only pass: the epilogue only reports the norms of g_c
-  } else if (tid < 64) {
-    const int lane = tid;
-    const int r = lane < N ? lane : N - 1;
-    const bool live = lane < N;
-    double L[N];
-#pragma unroll
-    for (int c = 0; c < N; ++c) L[c] = 0.0;
-    double y = live ? y_s[r] : 0.0;
-    double d_own = 1.0;              // 1 / L_rr of this lane's row
-    double diag = S[r * LD + r];     // running A_rr - sum_k L_rk^2
-    bool ok = true;
-    double inv;                      // 1 / L_jj of the column being finished (wave-uniform)
-    {
-      const double d0 = readlane_f64(diag, 0);
-      ok = (d0 > 0.0) && isfinite(d0);
-      inv = fast_rsqrt(ok ? d0 : 1.0);
-    }
-    double pre0 = S[r * LD + 0], pre1 = 0.0;
-    double lr_prev = 0.0;            // this lane's entry of the previous column
-    // lane - j, carried through the (fully unrolled) loop behind an optimisation barrier: written as `lane > j` the 2 N
-    // comparisons are loop invariant, get hoisted, and their 2 N mask pairs spill from the scalar registers
-    int rem = lane;
-#pragma unroll
-    for (int j = 0; j < N; ++j) {
-      asm volatile("" : "+v"(rem));
-      const bool below = rem > 0, here = rem == 0;       // row r is below / on the diagonal of column j
-      // operands of the NEXT column's prefix (row j + 1 of L, entries k < j: all in LDS since the end of the previous
-      // step) are requested first, so that their LDS latency runs under the dependent chain of this column
-      typedef double v2d __attribute__((ext_vector_type(2)));      // one register quad per operand pair (see the pin below)
-      v2d rw[(N + 1) / 2];
-      const double a_next = (j + 1 < N) ? S[r * LD + j + 1] : 0.0;
-      if (j + 1 < N) {
-#pragma unroll
-        for (int k = 0; k + 1 < j; k += 2) rw[k / 2] = *reinterpret_cast<const v2d*>(&LT[(j + 1) * LE + k]);
-        if (j & 1) rw[j / 2].x = LT[(j + 1) * LE + j - 1];
-      }
-      asm volatile("" ::: "memory");     // the requests stay here, ahead of the chain (the compiler would sink them next to their uses)
-      // finish column j: only the term with L_j,j-1 (lane j's entry of the previous column) was still missing
-      double v = pre0 + pre1;
-      if (j > 0) v = fma(-lr_prev, readlane_f64(lr_prev, j), v);
-      // rows <= j are complete: what they compute from here on is never read (their y is frozen by the select below and
-      // the LT entries they write lie on or above the diagonal, which nobody reads), so nothing is masked to zero
-      const double lrj = v * inv;
-      L[j] = lrj;
-      lr_prev = lrj;
-      // right-hand side, column-oriented forward substitution: z_j = y_j / L_jj, then y_r -= L_rj z_j below
-      const double zj = readlane_f64(y, j) * inv;
-      d_own = here ? inv : d_own;
-      y = below ? fma(-lrj, zj, y) : (here ? zj : y);
-      LT[r * LE + j] = lrj;
-      diag = fma(-lrj, lrj, diag);
-      if (j + 1 < N) {
-        // next pivot: every lane takes row j + 1's running diagonal and inverts it itself
-        const double dn = readlane_f64(diag, j + 1);
-        const bool pd = (dn > 0.0) && isfinite(dn);
-        ok = ok && pd;
-        inv = fast_rsqrt(pd ? dn : 1.0);
-        // prefix of column j + 1: four independent partial sums over k < j (same association as before); ONE wait for all
-        // of the row instead of one per operand pair
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int k = 0; k < (j + 1) / 2; ++k) asm volatile("" : "+v"(rw[k]));   // the sums start here, not earlier (the PAIR is pinned: pinning the halves separately cost a register move per operand)
-        pre0 = a_next; pre1 = 0.0;
-        double pre2 = 0.0, pre3 = 0.0;
-#pragma unroll
-        for (int k = 0; k + 3 < j; k += 4) {
-          pre0 = fma(-L[k], rw[k / 2].x, pre0);
-          pre1 = fma(-L[k + 1], rw[k / 2].y, pre1);
-          pre2 = fma(-L[k + 2], rw[k / 2 + 1].x, pre2);
-          pre3 = fma(-L[k + 3], rw[k / 2 + 1].y, pre3);
-        }
-#pragma unroll
-        for (int k = j & ~3; k < j; ++k) pre0 = fma(-L[k], (k & 1) ? rw[k / 2].y : rw[k / 2].x, pre0);
-        pre0 += pre2; pre1 += pre3;
-      }
-      wave_lds_sync();
-      rem -= 1;
-    }
-    t2 = (PBA_PHASE_TIMING ? __builtin_amdgcn_s_memtime() : 0ull);
-    // backward substitution L^T x = z: lane r needs column r of L = L[j][r] for j > r; fetched up front (independent
-    // LDS reads, contiguous across lanes) so that the sweep itself is mul -> readlane -> fma per row.  Entries on or
-    // above the diagonal (j <= r) hold leftovers of the factorisation: the select in the sweep never lets them in.
-    double lc[N];
-#pragma unroll
-    for (int j = 0; j < N; ++j) lc[j] = LT[j * LE + r];
-    rem = lane - (N - 1);
-#pragma unroll
-    for (int j = N - 1; j >= 0; --j) {
-      asm volatile("" : "+v"(rem));
-      // x_j = y_j / L_jj on every lane (inv_j is not kept: d_own of lane j crosses with the value)
-      const double xj = readlane_f64(y * d_own, j);
-      y = (rem < 0) ? fma(-lc[j], xj, y) : ((rem == 0) ? xj : y);      // rem = lane - j
-      rem += 1;
-    }
-    if (lane < N) y_s[lane] = y;
-    if (lane == 0) s_ok = ok ? 1 : 0;
-    t3 = (PBA_PHASE_TIMING ? __builtin_amdgcn_s_memtime() : 0ull);
-  }
-  __syncthreads();
-  solve_epilogue<256>(p, N, y_s, sc, D2, gcs, gc, s_ok != 0, tid);
-  t4 = (PBA_PHASE_TIMING ? __builtin_amdgcn_s_memtime() : 0ull);
-  if (PBA_PHASE_TIMING && p.dbg && tid == 0) printf("k_solve_wave cycles: prologue %llu cholesky %llu substitution %llu epilogue %llu\n", t1 - t0, t2 - t1, t3 - t2, t4 - t3);
-}
+// (Rounds 1-2 had one- and two-wave kernels here, k_solve_wave<NF> / k_solve_wave2<NF>: a row of L per lane in registers,
+// v_readlane chains, ~50 KB of straight-line code per size, 16.4 us at n = 42 and 81.7 us at n = 90.  The blocked workgroup
+// solve below replaced them; profiles/r03/before_old_solve_*.csv keeps their timings.)
 
-// 60 < n = 6 NF <= 96 (11..16 free cameras, BASELINE configs[3]): two waves, thread r owns row r of L in registers,
-// LEFT-looking and software-pipelined: L_rj = (A_rj - sum_k L_rk L_jk) / L_jj with row j of L read from LDS by
-// wave-uniform broadcasts.  All terms k < j - 1 of column j are accumulated during step j - 1 (their operands were
-// published a step earlier), so after the barrier only the newest term L_j,j-1 and the scaling remain on the dependent
-// chain; the owner of row j + 1 then derives the next pivot from its running diagonal and publishes 1 / L_j+1,j+1 while
-// everybody accumulates the next prefix.
-// One workgroup barrier per column (two waves).  The right-hand side is folded in one step behind (z_j is published
-// with column j and consumed at step j + 1).  The backward sweep runs inside each wave with v_readlane: wave 1
-// (rows >= 64) first, its solution crosses to wave 0 through LDS once.
-template <int NF>
-__global__ __launch_bounds__(128) void k_solve_wave2(SolveParams p_in) {
-  SolveParams p = p_in;
-  if (!PBA_PHASE_TIMING) p.dbg = 0;
-  unsigned long long t0 = (PBA_PHASE_TIMING ? __builtin_amdgcn_s_memtime() : 0ull), t1 = 0, t2 = 0, t3 = 0;
-  if (!solve_resolve(p)) return;
-  constexpr int N = 6 * NF;
-  constexpr int LD = N + 1;
-  static_assert(N > 64 && N <= 96, "two-wave solve");
-  __shared__ __attribute__((aligned(16))) double S[N * LD + 1];
-  __shared__ double y_s[N], sc[N], D2[N], gcs[N], gc[N];
-  __shared__ double z_s[N];          // z_j = (L^-1 y)_j, published with column j
-  __shared__ int s_ok;
-  const int tid = threadIdx.x;
-  solve_prologue<128>(p, N, LD, S, y_s, sc, D2, gcs, gc, tid);
-  t1 = (PBA_PHASE_TIMING ? __builtin_amdgcn_s_memtime() : 0ull);
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r = tid < N ? tid : N - 1;
-  const bool live = tid < N;
-  // L rows for the broadcast reads and the backward sweep: even stride => 16-byte aligned pairs (ds_read_b128)
-  constexpr int LE = N + (N & 1) + 2;
-  __shared__ __attribute__((aligned(16))) double LT[N * LE];
-  __shared__ double inv_s[N];        // 1 / L_jj, published by row j one step ahead
-  double L[N];
-#pragma unroll
-  for (int c = 0; c < N; ++c) L[c] = 0.0;
-  double y = live ? y_s[r] : 0.0;
-  double d_own = 1.0;
-  double diag = S[r * LD + r];       // running A_rr - sum_k L_rk^2
-  bool ok = true;
-  if (tid == 0) {
-    ok = (diag > 0.0) && isfinite(diag);
-    d_own = fast_rsqrt((diag > 0.0) ? diag : 1.0);
-    inv_s[0] = ok ? d_own : -1.0;    // a negative entry flags a non-positive pivot
-  }
-  // pre = A_r,j - sum_{k < j-1} L_rk L_jk for the column about to be finished: everything except the newest term
-  double pre0 = S[r * LD + 0], pre1 = 0.0;
-  lds_barrier();
-#pragma unroll
-  for (int j = 0; j < N; ++j) {
-    const double inv = inv_s[j];
-    ok = ok && (inv > 0.0);
-    // finish column j: only the term with L_j,j-1 (written during the previous step) was still missing
-    double v = pre0 + pre1;
-    if (j > 0) v = fma(-L[j - 1], LT[j * LE + j - 1], v);
-    if (j > 0 && tid >= j) y = fma(-L[j - 1], z_s[j - 1], y);   // rhs: one step behind, rows below j - 1 only
-    const double lrj = (tid > j) ? v * inv : 0.0;
-    L[j] = lrj;
-    if (tid == j) { y *= inv; z_s[j] = y; }
-    if (live && tid > j) LT[r * LE + j] = lrj;
-    diag = fma(-lrj, lrj, diag);
-    if (j + 1 < N && tid == j + 1) {
-      // next pivot, one step ahead: derived from this row's running diagonal
-      const bool pd = (diag > 0.0) && isfinite(diag);
-      d_own = fast_rsqrt(pd ? diag : 1.0);
-      inv_s[j + 1] = pd ? d_own : -1.0;
-    }
-    if (j + 1 < N) {
-      // prefix of column j + 1 from row j + 1 of L, entries k < j (all published before the last barrier): four
-      // independent partial sums, wave-uniform 16-byte broadcast reads
-      pre0 = S[r * LD + j + 1]; pre1 = 0.0;
-      double pre2 = 0.0, pre3 = 0.0;
-#pragma unroll
-      for (int k = 0; k + 3 < j; k += 4) {
-        const double2 la = *reinterpret_cast<const double2*>(&LT[(j + 1) * LE + k]);
-        const double2 lb = *reinterpret_cast<const double2*>(&LT[(j + 1) * LE + k + 2]);
-        pre0 = fma(-L[k], la.x, pre0);
-        pre1 = fma(-L[k + 1], la.y, pre1);
-        pre2 = fma(-L[k + 2], lb.x, pre2);
-        pre3 = fma(-L[k + 3], lb.y, pre3);
-      }
-#pragma unroll
-      for (int k = j & ~3; k < j; ++k) pre0 = fma(-L[k], LT[(j + 1) * LE + k], pre0);
-      pre0 += pre2; pre1 += pre3;
-    }
-    lds_barrier();
-  }
-  t2 = (PBA_PHASE_TIMING ? __builtin_amdgcn_s_memtime() : 0ull);
-  // backward substitution L^T x = z (LT holds L row-major): rows N-1 .. 64 inside wave 1
-  if (wave == 1) {
-#pragma unroll
-    for (int j = N - 1; j >= 64; --j) {
-      const double ljr = (tid < j) ? LT[j * LE + r] : 0.0;
-      if (tid == j) y *= d_own;
-      const double xj = readlane_f64(y, j - 64);
-      if (tid < j) y = fma(-ljr, xj, y);
-    }
-    if (live) y_s[tid] = y;
-  }
-  lds_barrier();
-  if (wave == 0) {
-    // contributions of the rows below (independent loads), then this wave's own chain
-#pragma unroll
-    for (int j = N - 1; j >= 64; --j) y = fma(-LT[j * LE + r], y_s[j], y);
-#pragma unroll
-    for (int j = 63; j >= 0; --j) {
-      const double ljr = (tid < j) ? LT[j * LE + r] : 0.0;
-      if (tid == j) y *= d_own;
-      const double xj = readlane_f64(y, j);
-      if (tid < j) y = fma(-ljr, xj, y);
-    }
-    y_s[tid] = y;
-  }
-  {
-    const unsigned long long okm = __ballot(ok);
-    if (tid == 0) s_ok = 1;
-    lds_barrier();
-    if ((tid & 63) == 0 && okm != ~0ull) s_ok = 0;
-  }
-  __syncthreads();
-  t3 = (PBA_PHASE_TIMING ? __builtin_amdgcn_s_memtime() : 0ull);
-  solve_epilogue<128>(p, N, y_s, sc, D2, gcs, gc, s_ok != 0, tid);
-  if (PBA_PHASE_TIMING && p.dbg && tid == 0)
-    printf("k_solve_wave2 cycles: prologue %llu cholesky %llu substitution %llu epilogue %llu\n", t1 - t0, t2 - t1, t3 - t2,
-           (unsigned long long)__builtin_amdgcn_s_memtime() - t3);
-}
-
-// Generic path (any n <= 96): matrix in LDS, 256 threads, 2-D trailing update, one barrier pair per column.
+// Generic path (any n <= 96; diagnostics, PBA_SOLVE=1): matrix in LDS, 256 threads, 2-D trailing update, one barrier pair per column.
 constexpr int kSolveThreads = 256;
 
 __global__ __launch_bounds__(kSolveThreads) void k_solve_generic(SolveParams p_in) {

@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: profile data of the final build + the whole suite + bench matrix (round 3 final evidence)
 set -u
-mkdir -p gpurun_out/g
+mkdir -p gpurun_out/g     # bench matrix + rocprof + whole GPU suite of one round (copy what you keep into profiles/rNN/)
 bash tools/profile_round.sh r03final > gpurun_out/g/profile.log 2>&1
 find gpurun_out/prof_r03final -name "*.rocpd" -delete; find gpurun_out/prof_r03final -name "*.db" -delete
 python bench.py --steps 20 --warmup 5 > gpurun_out/g/bench_driver_args.json 2> /dev/null
