@@ -38,6 +38,9 @@ struct pba_engine {
   size_t h_state_cap = 0;           // doubles
   hipEvent_t ev_img_stage = nullptr;
   bool img_stage_busy = false;
+  hipEvent_t ev_xdep = nullptr;     // orders another engine's stream against this one (pba_set_frame_pyr_down)
+  uint8_t* d_u8_work[2] = {nullptr, nullptr};   // device-side descriptor producers: smoothed frame, census image (on first use)
+  float* d_ch_all = nullptr;        // [channels][rows*cols] channel images produced on the device (on first use)
   std::vector<uint8_t> frame_set;
   uint32_t slot_mask = 0;           // window slots referenced by the observation list
 
@@ -507,6 +510,7 @@ int pba_create(const pba_config* cfg, pba_engine** out) {
   if (const char* sv = getenv("PBA_SOLVE")) e->solve_kind = atoi(sv);
   for (int k = 0; k < 2 * pba_engine::kEvPairs; ++k)
     if (hipEventCreate(&e->ev[k]) != hipSuccess) return bail(PBA_ERR_HIP);
+  if (hipEventCreateWithFlags(&e->ev_xdep, hipEventDisableTiming) != hipSuccess) return bail(PBA_ERR_HIP);
   e->sample_waves = sample_waves_for_radius(cfg->radius);
   if ((rc = ensure_state_stage(e, (size_t)6 * kMaxFrames + 3 * 65536))) return bail(rc);   // grown on demand beyond 64k points
   // The first frame-sized host -> device DMA of a process costs ~8 ms (seen in the drop-in class: first
@@ -545,6 +549,8 @@ void pba_destroy(pba_engine* e) {
   if (e->h_img_stage) (void)hipHostFree(e->h_img_stage);
   if (e->h_state_stage) (void)hipHostFree(e->h_state_stage);
   if (e->ev_img_stage) (void)hipEventDestroy(e->ev_img_stage);
+  if (e->ev_xdep) (void)hipEventDestroy(e->ev_xdep);
+  dev_free(&e->d_u8_work[0]); dev_free(&e->d_u8_work[1]); dev_free(&e->d_ch_all);
   if (e->h_log) (void)hipHostFree(e->h_log);
   dev_free(&e->d_lm);
   dev_free(&e->d_log);
@@ -611,6 +617,146 @@ int pba_get_frame_planes(pba_engine* e, int slot, float* I, float* Gx, float* Gy
   if (r == hipSuccess) r = hipStreamSynchronize(e->stream);
   (void)hipFree(d);
   if (r != hipSuccess) return fail(e, PBA_ERR_HIP, "pba_get_frame_planes: %s", hipGetErrorString(r));
+  return PBA_OK;
+}
+
+int pba_get_frame_channel(pba_engine* e, int slot, int32_t channel, float* I, float* Gx, float* Gy) {
+  if (!e || slot < 0 || slot >= e->cfg.max_frames || !I || !Gx || !Gy) return PBA_ERR_INVALID;
+  if (e->channels <= 1 || channel < 0 || channel >= e->channels)
+    return fail(e, PBA_ERR_INVALID, "pba_get_frame_channel: channel %d of an engine with %d channel(s)", channel, e->channels);
+  PBA_NOT_POISONED(e);
+  HIP_TRY(e, hipSetDevice(e->cfg.device));
+  const size_t npix = (size_t)e->cfg.rows * e->cfg.cols;
+  float* d = nullptr;
+  HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(&d), 3 * npix * sizeof(float)));
+  hipLaunchKernelGGL(k_unpack_channel, dim3((npix + 255) / 256), dim3(256), 0, e->stream,
+                     (const float4*)e->d_frames_mc + ((size_t)slot * e->channels + channel) * npix, d, d + npix, d + 2 * npix, (int)npix);
+  hipError_t r = hipMemcpyAsync(I, d, npix * sizeof(float), hipMemcpyDeviceToHost, e->stream);
+  if (r == hipSuccess) r = hipMemcpyAsync(Gx, d + npix, npix * sizeof(float), hipMemcpyDeviceToHost, e->stream);
+  if (r == hipSuccess) r = hipMemcpyAsync(Gy, d + 2 * npix, npix * sizeof(float), hipMemcpyDeviceToHost, e->stream);
+  if (r == hipSuccess) r = hipStreamSynchronize(e->stream);
+  (void)hipFree(d);
+  if (r != hipSuccess) return fail(e, PBA_ERR_HIP, "pba_get_frame_channel: %s", hipGetErrorString(r));
+  return PBA_OK;
+}
+
+int pba_sample_frame(pba_engine* e, int slot, int32_t channel, int32_t n, const float* y, const float* x, float* out3) {
+  if (!e || slot < 0 || slot >= e->cfg.max_frames || n <= 0 || !y || !x || !out3 || channel < 0 || channel >= e->channels) return PBA_ERR_INVALID;
+  if (!e->frame_set[slot]) return fail(e, PBA_ERR_STATE, "pba_sample_frame: slot %d holds no frame", slot);
+  PBA_NOT_POISONED(e);
+  HIP_TRY(e, hipSetDevice(e->cfg.device));
+  const size_t npix = (size_t)e->cfg.rows * e->cfg.cols;
+  float* d = nullptr;
+  HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(&d), (size_t)5 * n * sizeof(float)));
+  hipError_t r = hipMemcpyAsync(d, y, (size_t)n * sizeof(float), hipMemcpyHostToDevice, e->stream);
+  if (r == hipSuccess) r = hipMemcpyAsync(d + n, x, (size_t)n * sizeof(float), hipMemcpyHostToDevice, e->stream);
+  if (r == hipSuccess) {
+    if (e->channels > 1)
+      hipLaunchKernelGGL(k_sample_probe_mc, dim3((n + 255) / 256), dim3(256), 0, e->stream,
+                         (const float4*)e->d_frames_mc + ((size_t)slot * e->channels + channel) * npix, e->cfg.rows, e->cfg.cols, n,
+                         (const float*)d, (const float*)(d + n), d + 2 * (size_t)n);
+    else
+      hipLaunchKernelGGL(k_sample_probe, dim3((n + 255) / 256), dim3(256), 0, e->stream, (const uint32_t*)(e->d_frames + npix * slot),
+                         e->cfg.rows, e->cfg.cols, n, (const float*)d, (const float*)(d + n), d + 2 * (size_t)n);
+    r = hipGetLastError();
+  }
+  if (r == hipSuccess) r = hipMemcpyAsync(out3, d + 2 * (size_t)n, (size_t)3 * n * sizeof(float), hipMemcpyDeviceToHost, e->stream);
+  if (r == hipSuccess) r = hipStreamSynchronize(e->stream);
+  (void)hipFree(d);
+  if (r != hipSuccess) return fail(e, PBA_ERR_HIP, "pba_sample_frame: %s", hipGetErrorString(r));
+  return PBA_OK;
+}
+
+// cv::getGaussianKernel(n, sigma > 0, CV_32F) as host/imgproc.h gaussianKernel restates it
+static void gaussian_kernel_f32(int n, double sigma, float* k) {
+  const double scale2x = -0.5 / (sigma * sigma);
+  double sum = 0.0;
+  for (int i = 0; i < n; ++i) {
+    const double x = i - (n - 1) * 0.5;
+    k[i] = (float)std::exp(scale2x * x * x);
+    sum += k[i];
+  }
+  sum = 1.0 / sum;
+  for (int i = 0; i < n; ++i) k[i] = (float)(k[i] * sum);
+}
+
+int pba_set_frame_descriptor_u8(pba_engine* e, int slot, const uint8_t* image, int32_t descriptor, float sigma_ct, float sigma_bp) {
+  if (!e || !image || slot < 0 || slot >= e->cfg.max_frames) return PBA_ERR_INVALID;
+  if (descriptor == PBA_DESCRIPTOR_INTENSITY) return pba_set_frame_u8(e, slot, image);
+  const int want = descriptor == PBA_DESCRIPTOR_INTENSITY_AND_GRADIENT ? 3 : descriptor == PBA_DESCRIPTOR_BITPLANES ? 8 : 0;
+  if (!want) return fail(e, PBA_ERR_INVALID, "pba_set_frame_descriptor_u8: unknown descriptor %d", descriptor);
+  if (e->channels != want)
+    return fail(e, PBA_ERR_INVALID, "pba_set_frame_descriptor_u8: descriptor %d has %d channels, the engine was created for %d", descriptor, want, e->channels);
+  PBA_NOT_POISONED(e);
+  HIP_TRY(e, hipSetDevice(e->cfg.device));
+  const int rows = e->cfg.rows, cols = e->cfg.cols;
+  const size_t npix = (size_t)rows * cols;
+  int rc;
+  if (!e->d_ch_all && (rc = dev_alloc(e, &e->d_ch_all, npix * want))) return rc;
+  if (descriptor == PBA_DESCRIPTOR_BITPLANES)
+    for (int k = 0; k < 2; ++k)
+      if (!e->d_u8_work[k] && (rc = dev_alloc(e, &e->d_u8_work[k], npix))) return rc;
+  // same borrowed-buffer protocol as pba_set_frame_u8: pinned copy, everything else asynchronous behind the return
+  if (e->img_stage_busy) { HIP_TRY(e, hipEventSynchronize(e->ev_img_stage)); e->img_stage_busy = false; }
+  std::memcpy(e->h_img_stage, image, npix);
+  HIP_TRY(e, hipMemcpyAsync(e->d_img_stage, e->h_img_stage, npix, hipMemcpyHostToDevice, e->stream));
+  const dim3 grid((cols + 255) / 256, rows), block(256);
+  if (descriptor == PBA_DESCRIPTOR_INTENSITY_AND_GRADIENT) {
+    hipLaunchKernelGGL(k_channels_intensity_gradient, grid, block, 0, e->stream, (const uint8_t*)e->d_img_stage, e->d_ch_all, rows, cols);
+  } else {
+    const uint8_t* src = e->d_img_stage;
+    if (sigma_ct > 0.0f) {
+      float kf[3];
+      gaussian_kernel_f32(3, (double)sigma_ct, kf);
+      int ki[3];
+      for (int i = 0; i < 3; ++i) ki[i] = (int)std::nearbyint((double)kf[i] * 256.0);
+      hipLaunchKernelGGL(k_blur3_u8, grid, block, 0, e->stream, src, e->d_u8_work[0], rows, cols, ki[0], ki[1], ki[2]);
+      src = e->d_u8_work[0];
+    }
+    hipLaunchKernelGGL(k_census, grid, block, 0, e->stream, src, e->d_u8_work[1], rows, cols);
+    float k5[5] = {0.f, 0.f, 1.f, 0.f, 0.f};
+    if (sigma_bp > 0.0f) gaussian_kernel_f32(5, (double)sigma_bp, k5);
+    hipLaunchKernelGGL(k_bitplanes, grid, block, 0, e->stream, (const uint8_t*)e->d_u8_work[1], e->d_ch_all, rows, cols,
+                       sigma_bp > 0.0f ? 1 : 0, k5[0], k5[1], k5[2]);
+  }
+  for (int k = 0; k < want; ++k)
+    hipLaunchKernelGGL(k_pack_channel, grid, block, 0, e->stream, (const float*)(e->d_ch_all + (size_t)k * npix),
+                       e->d_frames_mc + ((size_t)slot * want + k) * npix, rows, cols);
+  HIP_TRY(e, hipGetLastError());
+  HIP_TRY(e, hipEventRecord(e->ev_img_stage, e->stream));
+  e->img_stage_busy = true;
+  e->frame_set[slot] = 1;
+  return PBA_OK;
+}
+
+int pba_set_frame_pyr_down(pba_engine* e, int slot, pba_engine* finer, int finer_slot, uint8_t* image_out) {
+  if (!e || !finer || e == finer || slot < 0 || slot >= e->cfg.max_frames || finer_slot < 0 || finer_slot >= finer->cfg.max_frames)
+    return PBA_ERR_INVALID;
+  if (e->channels > 1 || finer->channels > 1) return fail(e, PBA_ERR_INVALID, "pba_set_frame_pyr_down: single-channel engines only");
+  if (e->cfg.device != finer->cfg.device) return fail(e, PBA_ERR_INVALID, "pba_set_frame_pyr_down: the two engines live on devices %d and %d", e->cfg.device, finer->cfg.device);
+  const int rows = finer->cfg.rows, cols = finer->cfg.cols, drows = (rows + 1) / 2, dcols = (cols + 1) / 2;
+  if (e->cfg.rows != drows || e->cfg.cols != dcols)
+    return fail(e, PBA_ERR_INVALID, "pba_set_frame_pyr_down: %dx%d is not the next level of %dx%d (%dx%d)", e->cfg.rows, e->cfg.cols, rows, cols, drows, dcols);
+  if (!finer->frame_set[finer_slot]) return fail(e, PBA_ERR_STATE, "pba_set_frame_pyr_down: slot %d of the finer level holds no frame", finer_slot);
+  PBA_NOT_POISONED(e);
+  PBA_NOT_POISONED(finer);
+  HIP_TRY(e, hipSetDevice(e->cfg.device));
+  // the finer frame is produced on the other engine's stream
+  HIP_TRY(e, hipEventRecord(finer->ev_xdep, finer->stream));
+  HIP_TRY(e, hipStreamWaitEvent(e->stream, finer->ev_xdep, 0));
+  const dim3 grid((dcols + 255) / 256, drows), block(256);
+  hipLaunchKernelGGL(k_pyr_down<uint32_t>, grid, block, 0, e->stream, (const uint32_t*)(finer->d_frames + (size_t)rows * cols * finer_slot),
+                     e->d_img_stage, rows, cols, drows, dcols);
+  // ... and must not be overwritten there before it has been read here
+  HIP_TRY(e, hipEventRecord(e->ev_xdep, e->stream));
+  HIP_TRY(e, hipStreamWaitEvent(finer->stream, e->ev_xdep, 0));
+  hipLaunchKernelGGL(k_pack_frame, grid, block, 0, e->stream, (const uint8_t*)e->d_img_stage, e->d_frames + (size_t)drows * dcols * slot, drows, dcols);
+  HIP_TRY(e, hipGetLastError());
+  if (image_out) {
+    HIP_TRY(e, hipMemcpyAsync(image_out, e->d_img_stage, (size_t)drows * dcols, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+  }
+  e->frame_set[slot] = 1;
   return PBA_OK;
 }
 

@@ -617,8 +617,29 @@ __device__ __forceinline__ void linear_init_axis(float x, int size, int& x1, int
 __device__ __forceinline__ double hlerp_exact(float dx, double omdx, float a1, float a2) {
   return __fma_rn(omdx, (double)a2, (double)__fmul_rn(dx, a1));
 }
+// The same holds for the FLOAT channel images of the multi-channel descriptors (a2 with 24 significant bits): dx comes out
+// of LinearInitAxis as x2 - x (or 1), a multiple of 2^-24 in (0, 1], so (1.0 - dx) has at most 24 significant bits and
+// the product at most 48 -- exact, one fma again gives the reference's bits.
+//
+// dy * top + (1 - dy) * bot: two double products, ONE double sum, then float (sample_eigen.h:82-83 assigned to the float
+// sample; the reference is built without FMA instructions: CMakeLists.txt:25, -msse4.1).  Contraction must stay off here:
+// fma(dy, top, omdy * bot) skips the rounding of the first product and flips the float result about once in 5e8 samples
+// on float channel images (tests/golden/sampler_double_rounding.json holds such inputs).  The __dmul_rn / __dadd_rn
+// intrinsics are plain operators in inlined bodies to this compiler and do NOT prevent the fusion; the pragma does.
 __device__ __forceinline__ float vlerp_exact(float dy, float omdy, double top, double bot) {
-  return __double2float_rn(__dadd_rn(__dmul_rn((double)dy, top), __dmul_rn((double)omdy, bot)));
+#pragma clang fp contract(off)
+  const double a = (double)dy * top;
+  const double b = (double)omdy * bot;
+  return (float)(a + b);
+}
+// One instruction less, for the regular walk over PACKED u8 frames only: there |texel| <= 255, and for a footprint whose
+// origin has bx >= 4 or by >= 4 both products are EXACT in double, so the fused form returns the same bits.  Proof: for
+// x in [2^k, 2^(k+1)) dx (and 1 - dx) are multiples of 2^(k-23) (k = -1 for x < 1), so top / bot -- sums of multiples
+// of 2^(k-23) below 2^8 -- have at most 31 - k significant bits; dy and 1 - dy are multiples of 2^(j-23) in [0, 1] with
+// at most 23 - j bits (y in [2^j, 2^(j+1))); a product needs at most 54 - k - j <= 53 bits once k + j >= 1, which
+// max(k, j) >= 2 guarantees (k, j >= -1).  k_sample routes the 4 x 4 corner to the per-tap path (vlerp_exact).
+__device__ __forceinline__ float vlerp_u8_interior(float dy, float omdy, double top, double bot) {
+  return (float)fma((double)dy, top, (double)omdy * bot);
 }
 
 // Generic (irregular) tap: any position, straight from the packed frame in global memory.
@@ -638,6 +659,16 @@ __device__ __forceinline__ void sample_generic(const uint32_t* __restrict__ fram
     sgx = 0.5f * vlerp_exact(dy, omdy, hlerp_exact(dx, omdx, tex_gx2(t11), tex_gx2(t12)), hlerp_exact(dx, omdx, tex_gx2(t21), tex_gx2(t22)));
     sgy = 0.5f * vlerp_exact(dy, omdy, hlerp_exact(dx, omdx, tex_gy2(t11), tex_gy2(t12)), hlerp_exact(dx, omdx, tex_gy2(t21), tex_gy2(t22)));
   }
+}
+
+// debug / test: the engine's sampler at arbitrary float positions of one frame (pba_sample_frame)
+__global__ void k_sample_probe(const uint32_t* __restrict__ frame, int rows, int cols, int n, const float* __restrict__ y,
+                               const float* __restrict__ x, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float sI, sgx, sgy;
+  sample_generic<true>(frame, rows, cols, y[i], x[i], sI, sgx, sgy);
+  out[3 * i] = sI; out[3 * i + 1] = sgx; out[3 * i + 2] = sgy;
 }
 
 struct SampleParams {
@@ -1062,7 +1093,7 @@ void k_sample(SampleParams p_in) {
     }
     bx = trunc_x86(xf[0]);
     by = trunc_x86(yf[0]);
-    reg = (bx >= 0) && (by >= 0);
+    reg = (bx >= 0) && (by >= 0) && (FAST || bx >= 4 || by >= 4);   // (the 4 x 4 corner: see vlerp_u8_interior)
 #pragma unroll
     for (int j = 1; j < W; ++j) reg = reg && (trunc_x86(xf[j]) == bx + j) && (trunc_x86(yf[j]) == by + j);
     const bool inside = (bx + W - 1 <= p.cols - 2) && (by + W - 1 <= p.rows - 2);
@@ -1278,14 +1309,14 @@ void k_sample(SampleParams p_in) {
               }
             }
             if (r >= 1) {
-              const float sI = vlerp_exact(dy, omdy, Hp[0][j], h0);
+              const float sI = vlerp_u8_interior(dy, omdy, Hp[0][j], h0);
               const double e = (double)p0[i * W + j] - (double)sI;   // photobundle.cc:720 (i0 - i1)
               if (UNITW) {
                 cc = fma(e, e, cc);
                 if (JAC) {
                   // gradients stay in "2G" units here; the exact power-of-two scales are applied to the sums below
-                  const double gx = (double)vlerp_exact(dy, omdy, Hp[NPL > 1 ? 1 : 0][j], h1);
-                  const double gy = (double)vlerp_exact(dy, omdy, Hp[NPL > 2 ? 2 : 0][j], h2);
+                  const double gx = (double)vlerp_u8_interior(dy, omdy, Hp[NPL > 1 ? 1 : 0][j], h1);
+                  const double gy = (double)vlerp_u8_interior(dy, omdy, Hp[NPL > 2 ? 2 : 0][j], h2);
                   m11 = fma(gx, gx, m11); m12 = fma(gx, gy, m12); m22 = fma(gy, gy, m22);
                   b1 = fma(gx, e, b1); b2 = fma(gy, e, b2);
                 }
@@ -1293,8 +1324,8 @@ void k_sample(SampleParams p_in) {
                 const double w2 = p.w2[i * W + j];
                 cc += w2 * e * e;
                 if (JAC) {
-                  const double gx = (double)vlerp_exact(dy, omdy, Hp[NPL > 1 ? 1 : 0][j], h1);
-                  const double gy = (double)vlerp_exact(dy, omdy, Hp[NPL > 2 ? 2 : 0][j], h2);
+                  const double gx = (double)vlerp_u8_interior(dy, omdy, Hp[NPL > 1 ? 1 : 0][j], h1);
+                  const double gy = (double)vlerp_u8_interior(dy, omdy, Hp[NPL > 2 ? 2 : 0][j], h2);
                   const double wgx = w2 * gx, wgy = w2 * gy;
                   m11 += wgx * gx; m12 += wgx * gy; m22 += wgy * gy;
                   b1 += wgx * e; b2 += wgy * e;
@@ -1547,6 +1578,146 @@ __global__ void k_pack_channel(const float* __restrict__ ch, float4* __restrict_
   tex[i] = make_float4(ch[i], gx, gy, 0.f);
 }
 
+__global__ void k_unpack_channel(const float4* __restrict__ tex, float* I, float* Gx, float* Gy, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 t = tex[i];
+  I[i] = t.x; Gx[i] = t.y; Gy[i] = t.z;
+}
+
+// -----------------------------------------------------------------------------------------------------
+// Device-side producers of the descriptor channels and of the image pyramid (r3).  Same arithmetic, in the same order,
+// as photobundle_amd/host/imgproc.h / photobundle_pyramid.cc (the host restatement of reference src/imgproc.cc:109-245,
+// photobundle.cc:225-248 and of the cv::GaussianBlur / cv::pyrDown calls inside them): integer paths are exact, the float
+// path runs under `#pragma clang fp contract(off)` with plain operators (the __fmul_rn / __fadd_rn intrinsics are plain
+// operators in inlined bodies to this compiler and WOULD be fused) so that it rounds like the FMA-free host build.  One thread per output pixel,
+// taps straight from global memory (once per frame, 466k pixels: the L2 serves the overlap).
+// -----------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int reflect101_dev(int i, int n) {     // BORDER_REFLECT_101, any offset
+  if (n == 1) return 0;
+  while (i < 0 || i >= n) { if (i < 0) i = -i; if (i >= n) i = 2 * n - 2 - i; }
+  return i;
+}
+
+// cv::GaussianBlur(src, dst, Size(3,3), sigma) on 8-bit images in OpenCV's fixed point: kernel cvRound(k * 256), the two
+// passes in integers, (sum + 2^15) >> 16 (imgproc.h gaussianBlur3x3).  k0..k2 are the integer weights.
+__global__ void k_blur3_u8(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int rows, int cols, int k0, int k1, int k2) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y;
+  if (x >= cols) return;
+  const int xm = reflect101_dev(x - 1, cols), xp = reflect101_dev(x + 1, cols);
+  int t[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const uint8_t* s = src + (size_t)reflect101_dev(y + d - 1, rows) * cols;
+    t[d] = k0 * (int)s[xm] + k1 * (int)s[x] + k2 * (int)s[xp];
+  }
+  const int r = (k0 * t[0] + k1 * t[1] + k2 * t[2] + (1 << 15)) >> 16;
+  dst[(size_t)y * cols + x] = (uint8_t)min(255, max(0, r));
+}
+
+// imgproc.cc:126-197: bit b set when the b-th 3x3 neighbour (row-major, centre skipped) >= centre; zero border
+__global__ void k_census(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int rows, int cols) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y;
+  if (x >= cols) return;
+  const size_t i = (size_t)y * cols + x;
+  unsigned v = 0;
+  if (y >= 1 && y < rows - 1 && x >= 1 && x < cols - 1) {
+    const int c = src[i];
+    v = ((unsigned)(src[i - cols - 1] >= c) << 0) | ((unsigned)(src[i - cols] >= c) << 1) | ((unsigned)(src[i - cols + 1] >= c) << 2) |
+        ((unsigned)(src[i - 1] >= c) << 3) | ((unsigned)(src[i + 1] >= c) << 4) | ((unsigned)(src[i + cols - 1] >= c) << 5) |
+        ((unsigned)(src[i + cols] >= c) << 6) | ((unsigned)(src[i + cols + 1] >= c) << 7);
+  }
+  dst[i] = (uint8_t)v;
+}
+
+// imgproc.cc:199-245: the eight bit planes of the census image as float, each smoothed 5x5 (imgproc.h gaussianBlur5x5:
+// k2 c + k1 (l1 + r1) + k0 (l2 + r2) along the rows, then the same down the columns, float, REFLECT_101).  One thread
+// reads the 25 census bytes of its pixel once and produces all eight planes.  blur == 0: the planes themselves.
+__global__ void k_bitplanes(const uint8_t* __restrict__ census, float* __restrict__ out, int rows, int cols, int blur,
+                            float k0, float k1, float k2) {
+#pragma clang fp contract(off)
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y;
+  if (x >= cols) return;
+  const size_t npix = (size_t)rows * cols, i = (size_t)y * cols + x;
+  if (!blur) {
+    const unsigned c = census[i];
+#pragma unroll
+    for (int b = 0; b < 8; ++b) out[(size_t)b * npix + i] = (float)((c >> b) & 1u);
+    return;
+  }
+  int xs[5];
+#pragma unroll
+  for (int d = 0; d < 5; ++d) xs[d] = reflect101_dev(x + d - 2, cols);
+  unsigned c[5][5];
+#pragma unroll
+  for (int r = 0; r < 5; ++r) {
+    const uint8_t* s = census + (size_t)reflect101_dev(y + r - 2, rows) * cols;
+#pragma unroll
+    for (int d = 0; d < 5; ++d) c[r][d] = s[xs[d]];
+  }
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    float t[5];
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+      const float s0 = (float)((c[r][0] >> b) & 1u), s1 = (float)((c[r][1] >> b) & 1u), s2 = (float)((c[r][2] >> b) & 1u);
+      const float s3 = (float)((c[r][3] >> b) & 1u), s4 = (float)((c[r][4] >> b) & 1u);
+      float v = s2 * k2;              // plain operators: the pragma above governs them (not the bodies of inlined intrinsics)
+      v += (s1 + s3) * k1;
+      v += (s0 + s4) * k0;
+      t[r] = v;
+    }
+    float v = t[2] * k2;
+    v += (t[1] + t[3]) * k1;
+    v += (t[0] + t[4]) * k0;
+    out[(size_t)b * npix + i] = v;
+  }
+}
+
+// photobundle.cc:229-235 (IntensityAndGradient): channels I, Gx, Gy of the u8 frame as float (imgproc.cc:27-95: 0.5 *
+// central difference, zero one-pixel border)
+__global__ void k_channels_intensity_gradient(const uint8_t* __restrict__ img, float* __restrict__ out, int rows, int cols) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y;
+  if (x >= cols) return;
+  const size_t npix = (size_t)rows * cols, i = (size_t)y * cols + x;
+  float gx = 0.f, gy = 0.f;
+  if (y >= 1 && y < rows - 1 && x >= 1 && x < cols - 1) {
+    gx = 0.5f * __fsub_rn((float)img[i + 1], (float)img[i - 1]);
+    gy = 0.5f * __fsub_rn((float)img[i + cols], (float)img[i - cols]);
+  }
+  out[i] = (float)img[i];
+  out[npix + i] = gx;
+  out[2 * npix + i] = gy;
+}
+
+// cv::pyrDown on 8-bit images (photobundle_pyramid.cc pyrDownU8: [1 4 6 4 1] along the rows at the even columns, then
+// down the columns at the even rows, integers, (sum + 128) >> 8, REFLECT_101, size ((rows+1)/2, (cols+1)/2)).  The
+// source is a packed frame of the finer level's engine (intensity in the low byte) or a plain u8 image.
+template <class TSrc>
+__global__ void k_pyr_down(const TSrc* __restrict__ src, uint8_t* __restrict__ dst, int rows, int cols, int drows, int dcols) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y;
+  if (x >= dcols) return;
+  int xs[5];
+#pragma unroll
+  for (int d = 0; d < 5; ++d) xs[d] = reflect101_dev(2 * x + d - 2, cols);
+  const int w[5] = {1, 4, 6, 4, 1};
+  int acc = 0;
+#pragma unroll
+  for (int r = 0; r < 5; ++r) {
+    const TSrc* s = src + (size_t)reflect101_dev(2 * y + r - 2, rows) * cols;
+    int h = 0;
+#pragma unroll
+    for (int d = 0; d < 5; ++d) h += w[d] * (int)((unsigned)s[xs[d]] & 0xffu);
+    acc += w[r] * h;
+  }
+  dst[(size_t)y * dcols + x] = (uint8_t)((acc + 128) >> 8);
+}
+
 // Generic tap of one channel, any position (clamped / irregular observations).
 template <bool JAC>
 __device__ __forceinline__ void sample_generic_mc(const float4* __restrict__ frame, int rows, int cols, float yf, float xf,
@@ -1563,6 +1734,15 @@ __device__ __forceinline__ void sample_generic_mc(const float4* __restrict__ fra
     sgx = vlerp_exact(dy, omdy, hlerp_exact(dx, omdx, t11.y, t12.y), hlerp_exact(dx, omdx, t21.y, t22.y));
     sgy = vlerp_exact(dy, omdy, hlerp_exact(dx, omdx, t11.z, t12.z), hlerp_exact(dx, omdx, t21.z, t22.z));
   }
+}
+
+__global__ void k_sample_probe_mc(const float4* __restrict__ frame, int rows, int cols, int n, const float* __restrict__ y,
+                                  const float* __restrict__ x, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float sI, sgx, sgy;
+  sample_generic_mc<true>(frame, rows, cols, y[i], x[i], sI, sgx, sgy);
+  out[3 * i] = sI; out[3 * i + 1] = sgx; out[3 * i + 2] = sgy;
 }
 
 // The sampling pass over C channels: one lane per observation like k_sample; the channel loop is the outer (run time)

@@ -82,6 +82,37 @@ class Engine:
         assert ch.shape == (self.cfg.channels, self.cfg.rows, self.cfg.cols)
         self._check(self._L.pba_set_frame_channels_f32(self._h, int(slot), ch.shape[0], _ptr(ch)), "pba_set_frame_channels_f32")
 
+    DESCRIPTORS = {"Intensity": 0, "IntensityAndGradient": 1, "BitPlanes": 2}
+
+    def set_frame_descriptor(self, slot, image_u8, kind, sigma_ct=1.0, sigma_bp=1.5):
+        """The descriptor channels of `kind` built on the device from the u8 frame (pba_set_frame_descriptor_u8)."""
+        img = np.ascontiguousarray(image_u8, dtype=np.uint8)
+        assert img.shape == (self.cfg.rows, self.cfg.cols)
+        self._check(self._L.pba_set_frame_descriptor_u8(self._h, int(slot), _ptr(img), self.DESCRIPTORS[kind], float(sigma_ct), float(sigma_bp)),
+                    "pba_set_frame_descriptor_u8")
+
+    def set_frame_pyr_down(self, slot, finer, finer_slot, want_image=True):
+        """cv::pyrDown of a frame of the finer level's engine into this one, device to device; returns the u8 image."""
+        out = np.empty((self.cfg.rows, self.cfg.cols), np.uint8) if want_image else None
+        self._check(self._L.pba_set_frame_pyr_down(self._h, int(slot), finer._h, int(finer_slot), _ptr(out) if want_image else None),
+                    "pba_set_frame_pyr_down")
+        return out
+
+    def get_frame_channel(self, slot, channel):
+        out = np.empty((3, self.cfg.rows, self.cfg.cols), np.float32)
+        self._check(self._L.pba_get_frame_channel(self._h, int(slot), int(channel), _ptr(out[0]), _ptr(out[1]), _ptr(out[2])),
+                    "pba_get_frame_channel")
+        return out
+
+    def sample_frame(self, slot, y, x, channel=0):
+        """The engine's sampler at float positions: [n, 3] = value, Gx, Gy (pba_sample_frame)."""
+        y = np.ascontiguousarray(y, np.float32).ravel()
+        x = np.ascontiguousarray(x, np.float32).ravel()
+        assert y.shape == x.shape
+        out = np.empty((y.shape[0], 3), np.float32)
+        self._check(self._L.pba_sample_frame(self._h, int(slot), int(channel), y.shape[0], _ptr(y), _ptr(x), _ptr(out)), "pba_sample_frame")
+        return out
+
     def get_frame_planes(self, slot):
         out = np.empty((3, self.cfg.rows, self.cfg.cols), np.float32)
         self._check(self._L.pba_get_frame_planes(self._h, int(slot), _ptr(out[0]), _ptr(out[1]), _ptr(out[2])),

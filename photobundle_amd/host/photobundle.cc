@@ -286,8 +286,16 @@ void PhotometricBundleAdjustment::addFrame(const uint8_t* I_ptr, const float* Z_
   // the engine keeps its own device plane(s) of this frame in the ring slot id % window
   const int window = _options_ptr->slidingWindowSize;
   const int num_channels = (int)frame->numChannels();
-  if (num_channels == 1) {
+  static const bool host_channels = std::getenv("PBA_HOST_CHANNELS") != nullptr;    // test hook: hand the host's channel images over
+  if (_frame_resident) {
+    _frame_resident = false;                 // the pyramid class produced this level's frame on the device
+  } else if (num_channels == 1) {
     check(_engine, pba_set_frame_u8(_engine, (int)(_frame_id % window), I_ptr), "pba_set_frame_u8");
+  } else if (!host_channels) {
+    // the engine builds the same channel images on the device from the u8 frame (bit-identical to frame->channels,
+    // tests/test_gpu_producers.py): 0.47 MB up instead of 5.6 / 15 MB
+    const int32_t kind = _options_ptr->descriptorType == Options::DescriptorType::BitPlanes ? PBA_DESCRIPTOR_BITPLANES : PBA_DESCRIPTOR_INTENSITY_AND_GRADIENT;
+    check(_engine, pba_set_frame_descriptor_u8(_engine, (int)(_frame_id % window), I_ptr, kind, 1.0f, 1.5f), "pba_set_frame_descriptor_u8");
   } else {
     std::vector<float> flat((size_t)num_channels * rows * cols);
     for (int k = 0; k < num_channels; ++k)
@@ -578,4 +586,21 @@ PhotometricBundleAdjustment::ScenePointPointerList PhotometricBundleAdjustment::
   for (auto& p : _scene_points) (p->refFrameId() <= id ? remove : keep).push_back(std::move(p));
   _scene_points.swap(keep);
   return remove;
+}
+
+// C hook (tests bind it through ctypes): the channel images DescriptorFrame::Create builds on the host
+// (imgproc.h), [C][rows*cols]; kind 1 = IntensityAndGradient, 2 = BitPlanes; returns C
+extern "C" int pb_descriptor_channels(const uint8_t* img, int rows, int cols, int kind, float* out) {
+  std::vector<Image_<float>> ch;
+  const size_t n = (size_t)rows * cols;
+  if (kind == 2) {
+    imgproc::computeBitPlanes(img, rows, cols, ch);
+  } else {
+    ch.resize(3);
+    for (auto& c : ch) c.resize(rows, cols);
+    for (size_t i = 0; i < n; ++i) ch[0].d[i] = (float)img[i];
+    imgproc::imgradient(img, rows, cols, ch[1].data(), ch[2].data());
+  }
+  for (size_t k = 0; k < ch.size(); ++k) std::copy(ch[k].d.begin(), ch[k].d.end(), out + k * n);
+  return (int)ch.size();
 }

@@ -50,6 +50,7 @@ struct IterationSummary {
 }  // namespace ceres
 
 struct pba_engine;
+class PhotometricBundleAdjustmentPyr;
 
 // Same public surface as the reference class (nested Options / Result, addFrame, protected optimize); the private
 // part is this implementation's own.
@@ -143,6 +144,10 @@ class PhotometricBundleAdjustment {
   Image_<float> _saliency_map;
   Mat33 _K_inv;
   pba_engine* _engine = nullptr;
+  // set by the pyramid class when it has already put the next frame into the engine's ring slot on the device
+  // (pba_set_frame_pyr_down): addFrame() then skips its own upload
+  bool _frame_resident = false;
+  friend class PhotometricBundleAdjustmentPyr;
 };
 
 #endif

@@ -6,7 +6,11 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <stdexcept>
+#include <string>
+
+#include "../../include/pba.h"
 
 namespace {
 inline int reflect101(int i, int n) {
@@ -100,8 +104,28 @@ void PhotometricBundleAdjustmentPyr::addFrame(const uint8_t* image, const float*
   clock_gettime(CLOCK_MONOTONIC, &ts0);
   _im_pyr[0].assign(image, image + (size_t)_rows * _cols);
   _z_pyr[0].assign(depth, depth + (size_t)_rows * _cols);
+  // Intensity descriptors: the image pyramid is built on the device, level to level, straight into every level's ring slot
+  // (pba_set_frame_pyr_down; the host front-end of each level gets its u8 image back, 1/4 of the previous one).
+  // PBA_HOST_PYRAMID (test hook) / multi-channel descriptors: cv::pyrDown semantics on the host, every level uploads.
+  static const bool host_pyramid = std::getenv("PBA_HOST_PYRAMID") != nullptr;
+  const bool device_pyramid = !host_pyramid && n > 1 && _pyr[0]->_options_ptr->descriptorType == Options::DescriptorType::Intensity;
+  if (device_pyramid) {
+    const int window = _pyr[0]->_options_ptr->slidingWindowSize;
+    const int slot = (int)(_pyr[0]->_frame_id % window);
+    if (pba_set_frame_u8(_pyr[0]->_engine, slot, image) != PBA_OK) throw std::runtime_error(std::string("pba_set_frame_u8: ") + pba_last_error(_pyr[0]->_engine));
+    _pyr[0]->_frame_resident = true;
+  }
   for (int i = 1; i < n; ++i) {
-    pyrDownU8(_im_pyr[i - 1].data(), _sizes[i - 1].rows, _sizes[i - 1].cols, _im_pyr[i]);
+    if (device_pyramid) {
+      const int window = _pyr[i]->_options_ptr->slidingWindowSize;
+      _im_pyr[i].resize((size_t)_sizes[i].rows * _sizes[i].cols);
+      if (pba_set_frame_pyr_down(_pyr[i]->_engine, (int)(_pyr[i]->_frame_id % window), _pyr[i - 1]->_engine,
+                                 (int)(_pyr[i - 1]->_frame_id % window), _im_pyr[i].data()) != PBA_OK)
+        throw std::runtime_error(std::string("pba_set_frame_pyr_down: ") + pba_last_error(_pyr[i]->_engine));
+      _pyr[i]->_frame_resident = true;
+    } else {
+      pyrDownU8(_im_pyr[i - 1].data(), _sizes[i - 1].rows, _sizes[i - 1].cols, _im_pyr[i]);
+    }
     resizeBilinearF32(_z_pyr[i - 1].data(), _sizes[i - 1].rows, _sizes[i - 1].cols, _sizes[i].rows, _sizes[i].cols, _z_pyr[i]);
   }
   clock_gettime(CLOCK_MONOTONIC, &ts1);
