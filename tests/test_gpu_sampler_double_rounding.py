@@ -63,3 +63,64 @@ def test_probe_equals_the_oracle_on_random_positions():
     want = np.stack([oracle.sample_linear(planes, yy, xx) for yy, xx in zip(y, x)])
     assert np.array_equal(got, want)
     e.close()
+
+
+def _tap_positions(case):
+    """Float tap coordinates of a 3x3 patch whose FIRST tap is the case's position: the engine forms them as
+    (float)(u + (double)(j - R)) (photobundle.cc:715-717) with u = 3 - dx, v = 3 - dy."""
+    u, v = 3.0 - c_frac(case, "kx"), 3.0 - c_frac(case, "ky")
+    xs = [np.float32(u + float(j - 1)) for j in range(3)]
+    ys = [np.float32(v + float(j - 1)) for j in range(3)]
+    return u, v, ys, xs
+
+
+def c_frac(case, key):
+    return case[key] * 2.0 ** -23
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_walk_and_irregular_paths_reproduce_the_oracle_samples_exactly(mode):
+    """The kernels that run in a solve, not the probe: an identity camera with K = (1, 1, 0, 0) projects the point
+    (3 - dx, 3 - dy, 1) onto itself, so the first tap of its 3x3 patch is the golden position.  With the descriptor set to
+    the ORACLE's samples at the nine taps every residual is exactly zero -- iff the engine's samples are the same bits.
+    Float channels (mode 1) take the regular walk of k_sample_mc; u8 frames (mode 0) sit in the 4x4 corner that k_sample
+    routes to the per-tap path."""
+    from oracle import oracle
+    from photobundle_amd.engine import Engine
+    C = 3 if mode else 1
+    e = Engine(rows=8, cols=8, max_frames=2, radius=1, K=K, channels=C)
+    n = 0
+    for c in load_cases():
+        if c["mode"] != mode:
+            continue
+        u, v, ys, xs = _tap_positions(c)
+        assert ys[0] == position(c)[0] and xs[0] == position(c)[1]
+        base = plane(c)
+        base[3:5, 1:5] = base[1:3, 1:3].mean()             # something non-trivial under the other taps
+        if mode:
+            ch = np.zeros((3, 8, 8), np.float32)
+            ch[1] = base
+            for s in (0, 1):
+                e.set_frame_channels(s, ch)
+            planes = [oracle.channel_planes(ch)[3 * k: 3 * k + 3] for k in range(3)]
+        else:
+            img = base.astype(np.uint8)
+            for s in (0, 1):
+                e.set_frame(s, img)
+            planes = [oracle.planes_from_u8(img)]
+        desc = np.array([[float(oracle.sample_linear(pl, yy, xx)[0]) for yy in ys for xx in xs] for pl in planes]).reshape(1, -1)
+        e.set_problem(np.array([[u, v, 1.0]]), desc, [0, 0], [0, 1], np.ones(9))
+        e.set_cameras(np.zeros((2, 6)), fixed_slot=0)
+        cost = e.linearize()
+        rec = e.obs_records()
+        assert cost == 0.0 and np.all(rec[:, 5] == 0.0), (c, cost, rec[:, 5])
+        # ... and the test has teeth: the fused value in the descriptor instead gives a non-zero residual
+        wrong = c["fused_dy_top"] if c["fused_dy_top"] != c["expected"] else c["fused_omdy_bot"]
+        desc2 = desc.copy()
+        desc2[0, (9 if mode else 0)] = np.frombuffer(np.uint32(wrong).tobytes(), np.float32)[0]
+        e.set_problem(np.array([[u, v, 1.0]]), desc2, [0, 0], [0, 1], np.ones(9))
+        e.set_cameras(np.zeros((2, 6)), fixed_slot=0)
+        assert e.linearize() > 0.0
+        n += 1
+    assert n >= 5
+    e.close()

@@ -7,6 +7,10 @@
 //   gcc -O2 -march=native -ffp-contract=off -fopenmp tools/find_double_rounding_cases.c -o /tmp/find_cases -lm
 //   /tmp/find_cases <seed> <n_million_samples> <mode>      mode 0: u8 texels (single-channel frames)
 //                                                          mode 1: float texels (multi-channel descriptors)
+//                                                          mode 2: u8 / gradient texels at positions with x >= 4 or y >= 4 (any
+//                                                                  float coordinates): checks the claim behind vlerp_u8_interior
+//                                                                  (pba_kernels.h) -- no case may be found
+//                                                                  (1e11 samples, seed 5: none found, as the proof says)
 // Output lines: "case mode a11 a12 a21 a22 kx ky ok fa fb fh" -- texels (ints, or float bit patterns in mode 1),
 // dx = kx 2^-23, dy = ky 2^-23, then the float bit patterns of: the reference form; fma(dy, top, omdy*bot);
 // fma(omdy, bot, dy*top); (mode 1) the reference vertical blend over FUSED horizontal blends.
@@ -33,10 +37,11 @@ int main(int argc, char** argv) {
   for (long long c0 = 0; c0 < n; c0 += chunk) {
     uint64_t s = seed * 0x100000001b3ull + (uint64_t)c0;
     for (long long i = 0; i < chunk; ++i) {
-      const uint64_t r0 = rng_next(&s), r1 = rng_next(&s), r2 = mode ? rng_next(&s) : 0;
+      const uint64_t r0 = rng_next(&s), r1 = rng_next(&s), r2 = mode == 1 ? rng_next(&s) : 0;
       float a[4];
       uint32_t raw[4];
-      if (!mode) {
+      if (mode == 2) {
+      } else if (!mode) {
         for (int k = 0; k < 4; ++k) { raw[k] = (uint32_t)((r0 >> (8 * k)) & 0xff); a[k] = (float)raw[k]; }
       } else {
         // blurred bit planes: floats in [0, 1) with full 24-bit significands
@@ -44,9 +49,22 @@ int main(int argc, char** argv) {
         a[2] = (float)((r2 >> 8) & 0xffffff) * 0x1p-24f;  a[3] = (float)((r2 >> 36) & 0xffffff) * 0x1p-24f;
         for (int k = 0; k < 4; ++k) raw[k] = fbits(a[k]);
       }
-      const uint32_t kx = (uint32_t)(r1 & 0x7fffff), ky = (uint32_t)((r1 >> 23) & 0x7fffff);
+      uint32_t kx = (uint32_t)(r1 & 0x7fffff), ky = (uint32_t)((r1 >> 23) & 0x7fffff);
       if (!kx || !ky) continue;
-      const float dx = (float)kx * 0x1p-23f, dy = (float)ky * 0x1p-23f;
+      float dx = (float)kx * 0x1p-23f, dy = (float)ky * 0x1p-23f;
+      if (mode == 2) {
+        // texels: intensity 0..255 or doubled central difference -255..255; position: random float coordinates the way
+        // LinearInitAxis sees them (x in [0, 2048), y in [0, 512), any significand), at least one of them >= 4
+        for (int k = 0; k < 4; ++k) { const int v = (int)((r0 >> (9 * k)) & 0x1ff); a[k] = (float)((r0 >> 40) & 1 ? v - 255 : (v & 0xff)); raw[k] = (uint32_t)(int)a[k]; }
+        const uint64_t r3 = rng_next(&s);
+        // log-uniform magnitudes so that small coordinates (long fractions) are well represented
+        const float x = ldexpf((float)(kx | 0x800000) * 0x1p-23f, (int)(r3 % 12) - 1);       // [0.5, 2048)
+        const float y = ldexpf((float)(ky | 0x800000) * 0x1p-23f, (int)((r3 >> 8) % 10) - 1); // [0.5, 512)
+        if (x < 4.0f && y < 4.0f) continue;
+        const int ix = (int)x, iy = (int)y;
+        dx = (float)(ix + 1) - x; dy = (float)(iy + 1) - y;
+        kx = fbits(x); ky = fbits(y);
+      }
       const float omdy = 1.0f - dy;
       const double omdx = 1.0 - (double)dx;
       // reference form (this file is compiled with -ffp-contract=off)
@@ -57,7 +75,7 @@ int main(int argc, char** argv) {
       const float fa = (float)fma((double)dy, top, pb);
       const float fb = (float)fma((double)omdy, bot, pa);
       float fh = ok;
-      if (mode) {
+      if (mode == 1) {
         const double topf = fma(omdx, (double)a[1], (double)(dx * a[0]));
         const double botf = fma(omdx, (double)a[3], (double)(dx * a[2]));
         fh = (float)((double)dy * topf + (double)omdy * botf);
