@@ -28,8 +28,7 @@ struct pba_engine {
 
   // frames
   uint32_t* d_frames = nullptr;     // [max_frames][rows*cols] packed texels
-  float4* d_frames_mc = nullptr;    // channels > 1: [max_frames][channels][rows*cols] {value, Gx, Gy, 0}
-  float* d_ch_stage = nullptr;      // [rows*cols] one channel image on its way to d_frames_mc
+  float* d_frames_mc = nullptr;     // channels > 1: [max_frames][channels][rows*cols] channel VALUES (gradients are formed at use)
   int channels = 1;
   uint8_t* d_img_stage = nullptr;   // [rows*cols]
   uint8_t* h_img_stage = nullptr;   // pinned host copy of the frame being uploaded
@@ -40,7 +39,6 @@ struct pba_engine {
   bool img_stage_busy = false;
   hipEvent_t ev_xdep = nullptr;     // orders another engine's stream against this one (pba_set_frame_pyr_down)
   uint8_t* d_u8_work[2] = {nullptr, nullptr};   // device-side descriptor producers: smoothed frame, census image (on first use)
-  float* d_ch_all = nullptr;        // [channels][rows*cols] channel images produced on the device (on first use)
   std::vector<uint8_t> frame_set;
   uint32_t slot_mask = 0;           // window slots referenced by the observation list
 
@@ -200,7 +198,7 @@ void launch_sample_r(pba_engine* e, const SampleParams& sp) {
 template <int R, bool JAC, bool FUSED>
 void launch_sample_mc_r(pba_engine* e, const SampleParams& sp) {
   hipLaunchKernelGGL((k_sample_mc<R, JAC, kSampleWaves, FUSED>), dim3(FUSED ? e->fused_grid : e->sample_grid), dim3(kSampleWaves * 64), 0,
-                     e->stream, sp, (const float4*)e->d_frames_mc, e->channels);
+                     e->stream, sp, (const float*)e->d_frames_mc, e->channels);
 }
 template <bool JAC, bool FUSED = false>
 void launch_sample(pba_engine* e, const SampleParams& sp) {
@@ -469,8 +467,7 @@ int pba_create(const pba_config* cfg, pba_engine** out) {
   e->channels = std::max(1, cfg->channels);
   if (e->channels > 1) {
     if ((rc = dev_alloc(e, &e->d_frames_mc, npix * cfg->max_frames * e->channels))) return bail(rc);
-    if ((rc = dev_alloc(e, &e->d_ch_stage, npix))) return bail(rc);
-    if (hipMemsetAsync(e->d_frames_mc, 0, npix * cfg->max_frames * e->channels * sizeof(float4), e->stream) != hipSuccess) return bail(PBA_ERR_HIP);
+    if (hipMemsetAsync(e->d_frames_mc, 0, npix * cfg->max_frames * e->channels * sizeof(float), e->stream) != hipSuccess) return bail(PBA_ERR_HIP);
   }
   e->frame_set.assign(cfg->max_frames, 0);
   for (int k = 0; k < 2; ++k) {
@@ -536,7 +533,7 @@ void pba_destroy(pba_engine* e) {
   }
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   e->comm.shutdown();
-  dev_free(&e->d_frames); dev_free(&e->d_img_stage); dev_free(&e->d_frames_mc); dev_free(&e->d_ch_stage);
+  dev_free(&e->d_frames); dev_free(&e->d_img_stage); dev_free(&e->d_frames_mc);
   for (int k = 0; k < 2; ++k) { dev_free(&e->d_xyz[k]); dev_free(&e->d_cams[k]); dev_free(&e->d_geom[k]); dev_free(&e->d_block_cost[k]); dev_free(&e->d_block_fail[k]); }
   dev_free(&e->d_rays);
   dev_free(&e->d_desc); dev_free(&e->d_w2); dev_free(&e->d_obs_point); dev_free(&e->d_obs_slot); dev_free(&e->d_pt_begin);
@@ -550,7 +547,7 @@ void pba_destroy(pba_engine* e) {
   if (e->h_state_stage) (void)hipHostFree(e->h_state_stage);
   if (e->ev_img_stage) (void)hipEventDestroy(e->ev_img_stage);
   if (e->ev_xdep) (void)hipEventDestroy(e->ev_xdep);
-  dev_free(&e->d_u8_work[0]); dev_free(&e->d_u8_work[1]); dev_free(&e->d_ch_all);
+  dev_free(&e->d_u8_work[0]); dev_free(&e->d_u8_work[1]);
   if (e->h_log) (void)hipHostFree(e->h_log);
   dev_free(&e->d_lm);
   dev_free(&e->d_log);
@@ -566,15 +563,11 @@ int pba_set_frame_channels_f32(pba_engine* e, int slot, int32_t n_channels, cons
   PBA_NOT_POISONED(e);
   HIP_TRY(e, hipSetDevice(e->cfg.device));
   const size_t npix = (size_t)e->cfg.rows * e->cfg.cols;
-  dim3 grid((e->cfg.cols + 255) / 256, e->cfg.rows);
-  for (int k = 0; k < n_channels; ++k) {
-    // synchronous per channel (one staging buffer): this is the wide-descriptor path, not the headline one
-    HIP_TRY(e, hipMemcpyAsync(e->d_ch_stage, channels + (size_t)k * npix, npix * sizeof(float), hipMemcpyHostToDevice, e->stream));
-    hipLaunchKernelGGL(k_pack_channel, grid, dim3(256), 0, e->stream, (const float*)e->d_ch_stage,
-                       e->d_frames_mc + ((size_t)slot * n_channels + k) * npix, e->cfg.rows, e->cfg.cols);
-    HIP_TRY(e, hipGetLastError());
-    HIP_TRY(e, hipStreamSynchronize(e->stream));
-  }
+  // the slot keeps the channel VALUES as they come ([C][rows*cols], the layout of the argument): one copy, no kernel; the
+  // caller's buffer is only borrowed for the call
+  HIP_TRY(e, hipMemcpyAsync(e->d_frames_mc + (size_t)slot * n_channels * npix, channels, (size_t)n_channels * npix * sizeof(float),
+                            hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
   e->frame_set[slot] = 1;
   return PBA_OK;
 }
@@ -629,8 +622,8 @@ int pba_get_frame_channel(pba_engine* e, int slot, int32_t channel, float* I, fl
   const size_t npix = (size_t)e->cfg.rows * e->cfg.cols;
   float* d = nullptr;
   HIP_TRY(e, hipMalloc(reinterpret_cast<void**>(&d), 3 * npix * sizeof(float)));
-  hipLaunchKernelGGL(k_unpack_channel, dim3((npix + 255) / 256), dim3(256), 0, e->stream,
-                     (const float4*)e->d_frames_mc + ((size_t)slot * e->channels + channel) * npix, d, d + npix, d + 2 * npix, (int)npix);
+  hipLaunchKernelGGL(k_unpack_channel, dim3((e->cfg.cols + 255) / 256, e->cfg.rows), dim3(256), 0, e->stream,
+                     (const float*)e->d_frames_mc + ((size_t)slot * e->channels + channel) * npix, e->cfg.rows, e->cfg.cols, d, d + npix, d + 2 * npix);
   hipError_t r = hipMemcpyAsync(I, d, npix * sizeof(float), hipMemcpyDeviceToHost, e->stream);
   if (r == hipSuccess) r = hipMemcpyAsync(Gx, d + npix, npix * sizeof(float), hipMemcpyDeviceToHost, e->stream);
   if (r == hipSuccess) r = hipMemcpyAsync(Gy, d + 2 * npix, npix * sizeof(float), hipMemcpyDeviceToHost, e->stream);
@@ -653,7 +646,7 @@ int pba_sample_frame(pba_engine* e, int slot, int32_t channel, int32_t n, const 
   if (r == hipSuccess) {
     if (e->channels > 1)
       hipLaunchKernelGGL(k_sample_probe_mc, dim3((n + 255) / 256), dim3(256), 0, e->stream,
-                         (const float4*)e->d_frames_mc + ((size_t)slot * e->channels + channel) * npix, e->cfg.rows, e->cfg.cols, n,
+                         (const float*)e->d_frames_mc + ((size_t)slot * e->channels + channel) * npix, e->cfg.rows, e->cfg.cols, n,
                          (const float*)d, (const float*)(d + n), d + 2 * (size_t)n);
     else
       hipLaunchKernelGGL(k_sample_probe, dim3((n + 255) / 256), dim3(256), 0, e->stream, (const uint32_t*)(e->d_frames + npix * slot),
@@ -692,7 +685,6 @@ int pba_set_frame_descriptor_u8(pba_engine* e, int slot, const uint8_t* image, i
   const int rows = e->cfg.rows, cols = e->cfg.cols;
   const size_t npix = (size_t)rows * cols;
   int rc;
-  if (!e->d_ch_all && (rc = dev_alloc(e, &e->d_ch_all, npix * want))) return rc;
   if (descriptor == PBA_DESCRIPTOR_BITPLANES)
     for (int k = 0; k < 2; ++k)
       if (!e->d_u8_work[k] && (rc = dev_alloc(e, &e->d_u8_work[k], npix))) return rc;
@@ -701,8 +693,9 @@ int pba_set_frame_descriptor_u8(pba_engine* e, int slot, const uint8_t* image, i
   std::memcpy(e->h_img_stage, image, npix);
   HIP_TRY(e, hipMemcpyAsync(e->d_img_stage, e->h_img_stage, npix, hipMemcpyHostToDevice, e->stream));
   const dim3 grid((cols + 255) / 256, rows), block(256);
+  float* planes = e->d_frames_mc + (size_t)slot * want * npix;      // the slot's channel planes: produced in place
   if (descriptor == PBA_DESCRIPTOR_INTENSITY_AND_GRADIENT) {
-    hipLaunchKernelGGL(k_channels_intensity_gradient, grid, block, 0, e->stream, (const uint8_t*)e->d_img_stage, e->d_ch_all, rows, cols);
+    hipLaunchKernelGGL(k_channels_intensity_gradient, grid, block, 0, e->stream, (const uint8_t*)e->d_img_stage, planes, rows, cols);
   } else {
     const uint8_t* src = e->d_img_stage;
     if (sigma_ct > 0.0f) {
@@ -716,12 +709,9 @@ int pba_set_frame_descriptor_u8(pba_engine* e, int slot, const uint8_t* image, i
     hipLaunchKernelGGL(k_census, grid, block, 0, e->stream, src, e->d_u8_work[1], rows, cols);
     float k5[5] = {0.f, 0.f, 1.f, 0.f, 0.f};
     if (sigma_bp > 0.0f) gaussian_kernel_f32(5, (double)sigma_bp, k5);
-    hipLaunchKernelGGL(k_bitplanes, grid, block, 0, e->stream, (const uint8_t*)e->d_u8_work[1], e->d_ch_all, rows, cols,
+    hipLaunchKernelGGL(k_bitplanes, grid, block, 0, e->stream, (const uint8_t*)e->d_u8_work[1], planes, rows, cols,
                        sigma_bp > 0.0f ? 1 : 0, k5[0], k5[1], k5[2]);
   }
-  for (int k = 0; k < want; ++k)
-    hipLaunchKernelGGL(k_pack_channel, grid, block, 0, e->stream, (const float*)(e->d_ch_all + (size_t)k * npix),
-                       e->d_frames_mc + ((size_t)slot * want + k) * npix, rows, cols);
   HIP_TRY(e, hipGetLastError());
   HIP_TRY(e, hipEventRecord(e->ev_img_stage, e->stream));
   e->img_stage_busy = true;

@@ -1562,27 +1562,30 @@ void k_sample(SampleParams p_in) {
 // =====================================================================================================
 // multi-channel descriptors (reference photobundle.cc:229-245: IntensityAndGradient = 3 channels, BitPlanes = 8)
 // =====================================================================================================
-// One float4 texel per pixel and channel: {value, Gx, Gy, 0} with the gradients of the CHANNEL image
-// (DescriptorFrame ctor, photobundle.cc:172-175 -> imgradient on the float channel, imgproc.cc:27-95: 0.5 * central
-// difference, zero one-pixel border).
-__global__ void k_pack_channel(const float* __restrict__ ch, float4* __restrict__ tex, int rows, int cols) {
+// Multi-channel frames are kept as VALUE planes only ([slot][channel][rows*cols] float, 4 B per texel): the gradient
+// images of a channel (DescriptorFrame ctor, photobundle.cc:172-175 = imgproc.cc:27-95: 0.5 * central difference, zero on
+// the one-pixel border) are formed from the neighbouring values where they are used -- the same float subtraction and
+// exact halving, so the same bits -- instead of being stored next to the value.  r3: the {value, Gx, Gy, 0} float4 texels
+// of round 2 made k_sample_mc HBM-bound (1.67 GB fetched per launch at C = 8, 3.1 TB/s; 477 MB of frames for 8 slots x 8
+// channels, no reuse caught by the caches); planes of values are a quarter of that and fit the 256 MB MALL.
+__device__ __forceinline__ void mc_texel(const float* __restrict__ plane, int rows, int cols, int y, int x, float& v, float& gx, float& gy) {
+  const size_t i = (size_t)y * cols + x;
+  v = plane[i];
+  gx = 0.f; gy = 0.f;
+  if (y >= 1 && y < rows - 1 && x >= 1 && x < cols - 1) {
+    gx = 0.5f * __fsub_rn(plane[i + 1], plane[i - 1]);
+    gy = 0.5f * __fsub_rn(plane[i + cols], plane[i - cols]);
+  }
+}
+
+__global__ void k_unpack_channel(const float* __restrict__ plane, int rows, int cols, float* I, float* Gx, float* Gy) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
   const int y = blockIdx.y;
   if (x >= cols) return;
   const size_t i = (size_t)y * cols + x;
-  float gx = 0.f, gy = 0.f;
-  if (y >= 1 && y < rows - 1 && x >= 1 && x < cols - 1) {
-    gx = 0.5f * __fsub_rn(ch[i + 1], ch[i - 1]);
-    gy = 0.5f * __fsub_rn(ch[i + cols], ch[i - cols]);
-  }
-  tex[i] = make_float4(ch[i], gx, gy, 0.f);
-}
-
-__global__ void k_unpack_channel(const float4* __restrict__ tex, float* I, float* Gx, float* Gy, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const float4 t = tex[i];
-  I[i] = t.x; Gx[i] = t.y; Gy[i] = t.z;
+  float v, gx, gy;
+  mc_texel(plane, rows, cols, y, x, v, gx, gy);
+  I[i] = v; Gx[i] = gx; Gy[i] = gy;
 }
 
 // -----------------------------------------------------------------------------------------------------
@@ -1720,28 +1723,36 @@ __global__ void k_pyr_down(const TSrc* __restrict__ src, uint8_t* __restrict__ d
 
 // Generic tap of one channel, any position (clamped / irregular observations).
 template <bool JAC>
-__device__ __forceinline__ void sample_generic_mc(const float4* __restrict__ frame, int rows, int cols, float yf, float xf,
+__device__ __forceinline__ void sample_generic_mc(const float* __restrict__ plane, int rows, int cols, float yf, float xf,
                                                   float& sI, float& sgx, float& sgy) {
   int x1, x2, y1, y2; float dx, dy;
   linear_init_axis(yf, rows, y1, y2, dy);
   linear_init_axis(xf, cols, x1, x2, dx);
-  const float4 t11 = frame[(size_t)y1 * cols + x1], t12 = frame[(size_t)y1 * cols + x2];
-  const float4 t21 = frame[(size_t)y2 * cols + x1], t22 = frame[(size_t)y2 * cols + x2];
+  float v[4], gx[4] = {0.f, 0.f, 0.f, 0.f}, gy[4] = {0.f, 0.f, 0.f, 0.f};
+  if (JAC) {
+    mc_texel(plane, rows, cols, y1, x1, v[0], gx[0], gy[0]);
+    mc_texel(plane, rows, cols, y1, x2, v[1], gx[1], gy[1]);
+    mc_texel(plane, rows, cols, y2, x1, v[2], gx[2], gy[2]);
+    mc_texel(plane, rows, cols, y2, x2, v[3], gx[3], gy[3]);
+  } else {
+    v[0] = plane[(size_t)y1 * cols + x1]; v[1] = plane[(size_t)y1 * cols + x2];
+    v[2] = plane[(size_t)y2 * cols + x1]; v[3] = plane[(size_t)y2 * cols + x2];
+  }
   const double omdx = __dsub_rn(1.0, (double)dx);
   const float omdy = __fsub_rn(1.0f, dy);
-  sI = vlerp_exact(dy, omdy, hlerp_exact(dx, omdx, t11.x, t12.x), hlerp_exact(dx, omdx, t21.x, t22.x));
+  sI = vlerp_exact(dy, omdy, hlerp_exact(dx, omdx, v[0], v[1]), hlerp_exact(dx, omdx, v[2], v[3]));
   if (JAC) {
-    sgx = vlerp_exact(dy, omdy, hlerp_exact(dx, omdx, t11.y, t12.y), hlerp_exact(dx, omdx, t21.y, t22.y));
-    sgy = vlerp_exact(dy, omdy, hlerp_exact(dx, omdx, t11.z, t12.z), hlerp_exact(dx, omdx, t21.z, t22.z));
+    sgx = vlerp_exact(dy, omdy, hlerp_exact(dx, omdx, gx[0], gx[1]), hlerp_exact(dx, omdx, gx[2], gx[3]));
+    sgy = vlerp_exact(dy, omdy, hlerp_exact(dx, omdx, gy[0], gy[1]), hlerp_exact(dx, omdx, gy[2], gy[3]));
   }
 }
 
-__global__ void k_sample_probe_mc(const float4* __restrict__ frame, int rows, int cols, int n, const float* __restrict__ y,
+__global__ void k_sample_probe_mc(const float* __restrict__ plane, int rows, int cols, int n, const float* __restrict__ y,
                                   const float* __restrict__ x, float* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float sI, sgx, sgy;
-  sample_generic_mc<true>(frame, rows, cols, y[i], x[i], sI, sgx, sgy);
+  sample_generic_mc<true>(plane, rows, cols, y[i], x[i], sI, sgx, sgy);
   out[3 * i] = sI; out[3 * i + 1] = sgx; out[3 * i + 2] = sgy;
 }
 
@@ -1749,28 +1760,41 @@ __global__ void k_sample_probe_mc(const float4* __restrict__ frame, int rows, in
 // loop, inside it the footprint rows of that channel stream through LDS in batches and the lane accumulates the SAME six
 // sums across all channels in the reference's residual order (channel-major, photobundle.cc:708-722), because every
 // pixel of every channel shares the projection Jacobian A: M = sum_k sum_pix w^2 g g^T etc.
-constexpr int sample_mc_rows_per_batch(int R) { return (12 / (2 * R + 2)) > 0 ? 12 / (2 * R + 2) : 1; }
+#ifndef PBA_MC_WAVES_SMALL
+#define PBA_MC_WAVES_SMALL 2
+#endif
+#define PBA_MC_WAVES(R) ((R) <= 2 ? PBA_MC_WAVES_SMALL : 2)
+// footprint rows per staging batch: the whole footprint while its haloed window fits 64 floats per lane, two rows beyond
+// (measured at C = 8, 5x5: the whole footprint in one batch at 2 waves/SIMD 460 us per launch; two batches of three rows at 3
+// or 4 waves/SIMD -- 166 VGPRs, 42 KB of LDS -- 507 us: the second staging round costs more than the occupancy returns)
+#ifndef PBA_MC_RB2
+#define PBA_MC_RB2 6
+#endif
+constexpr int sample_mc_rows_per_batch(int R) { return R == 2 ? PBA_MC_RB2 : (((2 * R + 4) * (2 * R + 4) <= 64) ? 2 * R + 2 : 2); }
 
 //   FUSED: like k_sample's fused form -- back-substitution of the step for the workgroup's whole points first, sampling at
 //   the candidate it just formed, step finalisation (and, single rank, the trust-region decision) by the last workgroup.
 template <int R, bool JAC, int WAVES, bool FUSED>
-__global__ __launch_bounds__(WAVES * 64, 2) void k_sample_mc(SampleParams p_in, const float4* __restrict__ frames_mc, int n_channels) {
+__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(PBA_MC_WAVES(R), PBA_MC_WAVES(R)))) void k_sample_mc(SampleParams p_in, const float* __restrict__ frames_mc, int n_channels) {
   static_assert(!FUSED || (WAVES * 64) % 128 == 0, "fused tiles are 128 observations");
   SampleParams p = p_in;
   p.dbg = nullptr;
   if (FUSED && !fused_resolve_parity(p)) return;
   constexpr int W = 2 * R + 1, F = 2 * R + 2;
-  constexpr int RB = sample_mc_rows_per_batch(R);
+  constexpr int H = JAC ? 1 : 0;                    // halo: the gradients of a footprint texel need its four neighbours
+  constexpr int FW = F + 2 * H;                     // staged columns
+  constexpr int RB = sample_mc_rows_per_batch(R);   // footprint rows per batch
+  constexpr int SR = RB + 2 * H;                    // staged rows per batch
   constexpr int NB = (F + RB - 1) / RB;
-  constexpr int FF = RB * F;
+  constexpr int FF = SR * FW;
   constexpr int LSTRIDE = 65;
   constexpr int NPL = JAC ? 3 : 1;
-  constexpr size_t kTexBytes = sizeof(uint32_t) * WAVES * NPL * FF * LSTRIDE;
+  constexpr size_t kTexBytes = sizeof(float) * WAVES * FF * LSTRIDE;
   constexpr size_t kBsBytes = FUSED ? sizeof(double) * 3 * WAVES * 64 : 0;      // back-substitution scratch ahead of the tables
   constexpr size_t kPreBytes = kBsBytes + (FUSED ? 2 : 1) * kMaxFrames * sizeof(CamGeom);
   static_assert(!FUSED || kTexBytes >= sizeof(double) * 4 * WAVES * 64, "the finalisation reuses the texel region");
   __shared__ __attribute__((aligned(16))) char s_raw[kTexBytes > kPreBytes ? kTexBytes : kPreBytes];
-  float (*s_tex)[NPL * FF * LSTRIDE] = reinterpret_cast<float (*)[NPL * FF * LSTRIDE]>(s_raw);
+  float (*s_tex)[FF * LSTRIDE] = reinterpret_cast<float (*)[FF * LSTRIDE]>(s_raw);
   __shared__ int32_t s_base[WAVES][64];
   __shared__ double s_red[4 * WAVES];
   __shared__ int32_t s_fail;
@@ -1817,7 +1841,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_sample_mc(SampleParams p_in, 
     for (int j = 0; j < W; ++j) { xf[j] = (float)(u + (double)(j - R)); yf[j] = (float)(v + (double)(j - R)); }
     bx = trunc_x86(xf[0]);
     by = trunc_x86(yf[0]);
-    bool reg = (bx >= 0) && (bx + W - 1 <= p.cols - 2) && (by >= 0) && (by + W - 1 <= p.rows - 2);
+    // regular: consecutive taps whose whole footprint is INTERIOR (the gradients of its texels come from a one-pixel halo
+    // of values; the image border, where they are zero by definition, goes to the per-tap path)
+    bool reg = (bx >= 1) && (bx + F <= p.cols - 1) && (by >= 1) && (by + F <= p.rows - 1);
 #pragma unroll
     for (int j = 1; j < W; ++j) reg = reg && (trunc_x86(xf[j]) == bx + j) && (trunc_x86(yf[j]) == by + j);
     regular = reg;
@@ -1828,15 +1854,16 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_sample_mc(SampleParams p_in, 
       omdx[j] = __dsub_rn(1.0, (double)dxs[j]);
     }
   }
-  // texel index of the footprint's first pixel in channel 0 of the observation's frame (-1: not staged)
-  s_base[wave][lane] = (active && regular) ? (int32_t)((size_t)slot * n_channels * npix + (size_t)by * p.cols + bx) : -1;
+  // index of the first staged value (footprint origin minus the halo) in channel 0 of the observation's frame (-1: not staged)
+  s_base[wave][lane] = (active && regular) ? (int32_t)((size_t)slot * n_channels * npix + (size_t)(by - H) * p.cols + (bx - H)) : -1;
   lds_barrier();      // the camera table is dead from here on: its LDS is reused by the texel batches
 
   const bool walk = active && regular;
   double m11 = 0, m12 = 0, m22 = 0, b1 = 0, b2 = 0, cc = 0;
-  constexpr int OPI = 64 / F;                       // observations per staging pass: lane = (observation, texel column)
+  constexpr int OPI = 64 / FW;                      // observations per staging pass: lane = (observation, staged column)
   constexpr int NG = (64 + OPI - 1) / OPI;
-  const int oi = lane / F, tc = lane - oi * F;
+  const int oi = lane / FW, tc = lane - oi * FW;
+#pragma unroll 1
   for (int k = 0; k < n_channels; ++k) {
     const float* p0 = p.desc + ((size_t)pt * n_channels + k) * (W * W);
     double Hp[NPL][W];
@@ -1854,15 +1881,12 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_sample_mc(SampleParams p_in, 
         const int o = g * OPI + oi;
         const int32_t bs = (oi < OPI && o < 64) ? s_base[wave][o & 63] : -1;
         if (bs >= 0) {
-          const float4* src = frames_mc + (size_t)bs + (size_t)k * npix + tc;
+          const float* src = frames_mc + (size_t)bs + (size_t)k * npix + tc;
+          float tv[SR];
 #pragma unroll
-          for (int rr = 0; rr < RB; ++rr) {
-            if (rr >= nr) continue;
-            const float4 t = src[(size_t)(r0 + rr) * p.cols];
-            float* dst = &s_tex[wave][(rr * F + tc) * LSTRIDE + o];
-            dst[0] = t.x;
-            if (JAC) { dst[(NPL > 1 ? 1 : 0) * FF * LSTRIDE] = t.y; dst[(NPL > 2 ? 2 : 0) * FF * LSTRIDE] = t.z; }
-          }
+          for (int sr = 0; sr < SR; ++sr) if (sr < nr + 2 * H) tv[sr] = src[(size_t)(r0 + sr) * p.cols];     // all loads of the pass in flight
+#pragma unroll
+          for (int sr = 0; sr < SR; ++sr) if (sr < nr + 2 * H) s_tex[wave][(sr * FW + tc) * LSTRIDE + o] = tv[sr];
         }
       }
       wave_lds_sync();
@@ -1873,11 +1897,20 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_sample_mc(SampleParams p_in, 
           const int r = r0 + rr, i = r - 1;
           const float dy = dys[r >= 1 ? i : 0];
           const float omdy = __fsub_rn(1.0f, dy);
-          float t[NPL][F];
+          __builtin_amdgcn_sched_barrier(0);      // one footprint row at a time: hoisting the LDS reads of later rows costs registers (spills at R = 1, 3, 5)
+          // values of the footprint row (with its left / right halo) and, for the gradients, of the rows above and below
+          float vm[FW], t[NPL][F];
 #pragma unroll
-          for (int pl = 0; pl < NPL; ++pl)
+          for (int c = 0; c < FW; ++c) vm[c] = s_tex[wave][((rr + H) * FW + c) * LSTRIDE + lane];
 #pragma unroll
-            for (int c = 0; c < F; ++c) t[pl][c] = s_tex[wave][pl * FF * LSTRIDE + (rr * F + c) * LSTRIDE + lane];
+          for (int c = 0; c < F; ++c) {
+            t[0][c] = vm[c + H];
+            if (JAC) {
+              const float up = s_tex[wave][(rr * FW + c + H) * LSTRIDE + lane], dn = s_tex[wave][((rr + 2 * H) * FW + c + H) * LSTRIDE + lane];
+              t[NPL > 1 ? 1 : 0][c] = 0.5f * __fsub_rn(vm[c + 2 * H], vm[c]);       // imgproc.cc:27-95 on the channel image
+              t[NPL > 2 ? 2 : 0][c] = 0.5f * __fsub_rn(dn, up);
+            }
+          }
 #pragma unroll
           for (int j = 0; j < W; ++j) {
             const double h0 = hlerp_exact(dxs[j], omdx[j], t[0][j], t[0][j + 1]);
@@ -1906,9 +1939,11 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_sample_mc(SampleParams p_in, 
       }
     }
     if (active && !regular) {
-      const float4* frame = frames_mc + ((size_t)slot * n_channels + k) * npix;
+      const float* frame = frames_mc + ((size_t)slot * n_channels + k) * npix;
+#pragma unroll 1
       for (int i = 0; i < W; ++i) {
         const float yfi = (float)(v + (double)(i - R));
+#pragma unroll 1
         for (int j = 0; j < W; ++j) {
           const float xfj = (float)(u + (double)(j - R));
           float sI, sgx = 0.f, sgy = 0.f;
