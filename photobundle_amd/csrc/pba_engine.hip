@@ -197,8 +197,9 @@ void launch_sample_r(pba_engine* e, const SampleParams& sp) {
 }
 template <int R, bool JAC, bool FUSED>
 void launch_sample_mc_r(pba_engine* e, const SampleParams& sp) {
-  hipLaunchKernelGGL((k_sample_mc<R, JAC, kSampleWaves, FUSED>), dim3(FUSED ? e->fused_grid : e->sample_grid), dim3(kSampleWaves * 64), 0,
-                     e->stream, sp, (const float*)e->d_frames_mc, e->channels);
+  const dim3 grid(FUSED ? e->fused_grid : e->sample_grid), block(kSampleWaves * 64);
+  if (e->unit_weights) hipLaunchKernelGGL((k_sample_mc<R, JAC, kSampleWaves, FUSED, true>), grid, block, 0, e->stream, sp, (const float*)e->d_frames_mc, e->channels);
+  else hipLaunchKernelGGL((k_sample_mc<R, JAC, kSampleWaves, FUSED, false>), grid, block, 0, e->stream, sp, (const float*)e->d_frames_mc, e->channels);
 }
 template <bool JAC, bool FUSED = false>
 void launch_sample(pba_engine* e, const SampleParams& sp) {

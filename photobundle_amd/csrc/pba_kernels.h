@@ -1774,7 +1774,8 @@ constexpr int sample_mc_rows_per_batch(int R) { return R == 2 ? PBA_MC_RB2 : (((
 
 //   FUSED: like k_sample's fused form -- back-substitution of the step for the workgroup's whole points first, sampling at
 //   the candidate it just formed, step finalisation (and, single rank, the trust-region decision) by the last workgroup.
-template <int R, bool JAC, int WAVES, bool FUSED>
+//   UNITW: unit patch weights (MakePatchWeights without the Gaussian, the reference's default): w^2 = 1 is folded away.
+template <int R, bool JAC, int WAVES, bool FUSED, bool UNITW>
 __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(PBA_MC_WAVES(R), PBA_MC_WAVES(R)))) void k_sample_mc(SampleParams p_in, const float* __restrict__ frames_mc, int n_channels) {
   static_assert(!FUSED || (WAVES * 64) % 128 == 0, "fused tiles are 128 observations");
   SampleParams p = p_in;
@@ -1922,7 +1923,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(PBA_
             if (r >= 1) {
               const float sI = vlerp_exact(dy, omdy, Hp[0][j], h0);
               const double e = (double)p0[i * W + j] - (double)sI;
-              const double w2 = p.w2[i * W + j];
+              const double w2 = UNITW ? 1.0 : p.w2[i * W + j];
               cc += w2 * e * e;
               if (JAC) {
                 const double gx = (double)vlerp_exact(dy, omdy, Hp[NPL > 1 ? 1 : 0][j], h1);
