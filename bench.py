@@ -179,7 +179,7 @@ def main():
         return e_, "host-staged all-reduce via torch.distributed" + (" (RCCL init failed)" if want_rccl else "")
 
     if world > 1:
-        os.environ.setdefault("PBA_WAIT_TIMEOUT_S", "10")      # read at pba_create: a stuck exchange is an error after 10 s (well under the driver's compute-queue watchdog), not a hang
+        os.environ.setdefault("PBA_WAIT_TIMEOUT_S", "30")      # read at pba_create: a stuck exchange is an error after 30 s, not a hang (room for RCCL's lazy first-collective set-up, below the 60 s compute-queue watchdog)
     eng = new_engine()
     transport = "RCCL all-reduce of the reduced camera system"
     if world > 1:
