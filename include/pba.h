@@ -193,6 +193,10 @@ int pba_sample_frame(pba_engine* e, int slot, int32_t channel, int32_t n, const 
  * (photobundle_amd/host/imgproc.h), at 1/12 .. 1/32 of the upload. */
 enum { PBA_DESCRIPTOR_INTENSITY = 0, PBA_DESCRIPTOR_INTENSITY_AND_GRADIENT = 1, PBA_DESCRIPTOR_BITPLANES = 2 };
 int pba_set_frame_descriptor_u8(pba_engine* e, int slot, const uint8_t* image, int32_t descriptor, float sigma_ct, float sigma_bp);
+/* The channel images of a multi-channel slot back on the host, [C][rows*cols] (the layout pba_set_frame_channels_f32
+ * takes): a front-end that needs them (saliency over all channels, descriptor patches: photobundle.cc:213-221, :466-479)
+ * reads the device-produced ones instead of running DescriptorFrame::Create on the CPU as well. */
+int pba_get_frame_channels_f32(pba_engine* e, int slot, float* channels);
 /* cv::pyrDown of the frame in slot `finer_slot` of engine `finer` into slot `slot` of `e` (photobundle_pyramid.cc:45-52:
  * the next pyramid level; `e` must have been created for ((rows+1)/2, (cols+1)/2) on the same device), device to device.
  * `image_out` (nullable, (rows+1)/2 * (cols+1)/2 bytes) receives the down-sampled frame for the host front-end; the

@@ -69,7 +69,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int64, C.c_int32,
 # every symbol include/pba.h declares (tests check the library exports all of them)
 SYMBOLS = [
     "pba_status_string", "pba_last_error", "pba_default_solver_options", "pba_create", "pba_destroy",
-    "pba_set_frame_u8", "pba_set_frame_channels_f32", "pba_get_frame_planes", "pba_get_frame_channel", "pba_sample_frame", "pba_set_frame_descriptor_u8", "pba_set_frame_pyr_down", "pba_set_problem", "pba_set_cameras", "pba_set_inverse_depth", "pba_get_points_world", "pba_get_state",
+    "pba_set_frame_u8", "pba_set_frame_channels_f32", "pba_get_frame_planes", "pba_get_frame_channel", "pba_sample_frame", "pba_set_frame_descriptor_u8", "pba_get_frame_channels_f32", "pba_set_frame_pyr_down", "pba_set_problem", "pba_set_cameras", "pba_set_inverse_depth", "pba_get_points_world", "pba_get_state",
     "pba_linearize", "pba_step", "pba_accept", "pba_get_reduced_system", "pba_get_obs_records", "pba_solve",
     "pba_comm_unique_id", "pba_comm_init_rccl", "pba_comm_init_callback", "pba_comm_enable_peer_exchange", "pba_comm_transport", "pba_comm_rank_count",
     "pba_set_profiling", "pba_get_counters", "pba_reset_counters",
@@ -103,6 +103,7 @@ def lib():
     L.pba_get_frame_channel.argtypes = [C.c_void_p, C.c_int, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.pba_sample_frame.argtypes = [C.c_void_p, C.c_int, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.pba_set_frame_descriptor_u8.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int32, C.c_float, C.c_float]
+    L.pba_get_frame_channels_f32.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.pba_set_frame_pyr_down.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
     L.pba_set_problem.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.pba_set_cameras.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]

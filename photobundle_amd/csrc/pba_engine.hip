@@ -634,6 +634,18 @@ int pba_get_frame_channel(pba_engine* e, int slot, int32_t channel, float* I, fl
   return PBA_OK;
 }
 
+int pba_get_frame_channels_f32(pba_engine* e, int slot, float* channels) {
+  if (!e || slot < 0 || slot >= e->cfg.max_frames || !channels) return PBA_ERR_INVALID;
+  if (e->channels <= 1) return fail(e, PBA_ERR_INVALID, "pba_get_frame_channels_f32: single-channel engine");
+  if (!e->frame_set[slot]) return fail(e, PBA_ERR_STATE, "pba_get_frame_channels_f32: slot %d holds no frame", slot);
+  PBA_NOT_POISONED(e);
+  HIP_TRY(e, hipSetDevice(e->cfg.device));
+  const size_t n = (size_t)e->channels * e->cfg.rows * e->cfg.cols;
+  HIP_TRY(e, hipMemcpyAsync(channels, e->d_frames_mc + (size_t)slot * n, n * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  return PBA_OK;
+}
+
 int pba_sample_frame(pba_engine* e, int slot, int32_t channel, int32_t n, const float* y, const float* x, float* out3) {
   if (!e || slot < 0 || slot >= e->cfg.max_frames || n <= 0 || !y || !x || !out3 || channel < 0 || channel >= e->channels) return PBA_ERR_INVALID;
   if (!e->frame_set[slot]) return fail(e, PBA_ERR_STATE, "pba_sample_frame: slot %d holds no frame", slot);

@@ -91,6 +91,12 @@ class Engine:
         self._check(self._L.pba_set_frame_descriptor_u8(self._h, int(slot), _ptr(img), self.DESCRIPTORS[kind], float(sigma_ct), float(sigma_bp)),
                     "pba_set_frame_descriptor_u8")
 
+    def get_frame_channels(self, slot):
+        """[C, rows, cols] f32: the channel images of a multi-channel slot (pba_get_frame_channels_f32)."""
+        out = np.empty((self.cfg.channels, self.cfg.rows, self.cfg.cols), np.float32)
+        self._check(self._L.pba_get_frame_channels_f32(self._h, int(slot), _ptr(out)), "pba_get_frame_channels_f32")
+        return out
+
     def set_frame_pyr_down(self, slot, finer, finer_slot, want_image=True):
         """cv::pyrDown of a frame of the finer level's engine into this one, device to device; returns the u8 image."""
         out = np.empty((self.cfg.rows, self.cfg.cols), np.uint8) if want_image else None

@@ -203,6 +203,8 @@ struct PhotometricBundleAdjustment::DescriptorFrame {
   }
   DescriptorFrame(uint32_t frame_id, const uint8_t* img, int rows, int cols, DescriptorType type, int nt)
       : id(frame_id), channels(MakeChannels(img, rows, cols, type, nt)), I(channels[0]) {}
+  // channel images produced elsewhere (the engine's device-side producer): [C][rows*cols]
+  DescriptorFrame(uint32_t frame_id, std::vector<Image_<float>>&& ch) : id(frame_id), channels(std::move(ch)), I(channels[0]) {}
   size_t numChannels() const { return channels.size(); }
   void computeSaliencyMap(Image_<float>& smap, int nt) const {
     const int rows = I.rows(), cols = I.cols();
@@ -281,28 +283,45 @@ void PhotometricBundleAdjustment::addFrame(const uint8_t* I_ptr, const float* Z_
   double t_ph[6] = {0, 0, 0, 0, 0, 0};
   double t_last = wall_ms();
   auto lap = [&](int k) { const double t = wall_ms(); t_ph[k] += t - t_last; t_last = t; };
-  UniquePointer<DescriptorFrame> frame(new DescriptorFrame(_frame_id, I_ptr, rows, cols, _options_ptr->descriptorType, nt));
-  lap(5);
   // the engine keeps its own device plane(s) of this frame in the ring slot id % window
   const int window = _options_ptr->slidingWindowSize;
-  const int num_channels = (int)frame->numChannels();
-  static const bool host_channels = std::getenv("PBA_HOST_CHANNELS") != nullptr;    // test hook: hand the host's channel images over
-  if (_frame_resident) {
-    _frame_resident = false;                 // the pyramid class produced this level's frame on the device
-  } else if (num_channels == 1) {
-    check(_engine, pba_set_frame_u8(_engine, (int)(_frame_id % window), I_ptr), "pba_set_frame_u8");
-  } else if (!host_channels) {
-    // the engine builds the same channel images on the device from the u8 frame (bit-identical to frame->channels,
-    // tests/test_gpu_producers.py): 0.47 MB up instead of 5.6 / 15 MB
-    const int32_t kind = _options_ptr->descriptorType == Options::DescriptorType::BitPlanes ? PBA_DESCRIPTOR_BITPLANES : PBA_DESCRIPTOR_INTENSITY_AND_GRADIENT;
-    check(_engine, pba_set_frame_descriptor_u8(_engine, (int)(_frame_id % window), I_ptr, kind, 1.0f, 1.5f), "pba_set_frame_descriptor_u8");
+  const int slot = (int)(_frame_id % window);
+  const Options::DescriptorType dtype = _options_ptr->descriptorType;
+  static const bool host_channels = std::getenv("PBA_HOST_CHANNELS") != nullptr;    // test hook: the host-side channel producers
+  UniquePointer<DescriptorFrame> frame;
+  if (dtype != Options::DescriptorType::Intensity && !host_channels) {
+    // Multi-channel descriptors: the engine builds the channel images on the device from the u8 frame (0.47 MB up instead of
+    // 5.6 / 15 MB) and the front-end reads them back (saliency, descriptor patches) instead of running DescriptorFrame::Create
+    // on the CPU as well -- bit-identical images (tests/test_gpu_producers.py), ~190 ms less per KITTI frame for BitPlanes.
+    const int32_t kind = dtype == Options::DescriptorType::BitPlanes ? PBA_DESCRIPTOR_BITPLANES : PBA_DESCRIPTOR_INTENSITY_AND_GRADIENT;
+    const int C = dtype == Options::DescriptorType::BitPlanes ? 8 : 3;
+    check(_engine, pba_set_frame_descriptor_u8(_engine, slot, I_ptr, kind, 1.0f, 1.5f), "pba_set_frame_descriptor_u8");
+    std::vector<float> flat((size_t)C * rows * cols);
+    check(_engine, pba_get_frame_channels_f32(_engine, slot, flat.data()), "pba_get_frame_channels_f32");
+    std::vector<Image_<float>> ch(C);
+    for (int k = 0; k < C; ++k) {
+      ch[k].resize(rows, cols);
+      std::copy(flat.begin() + (size_t)k * rows * cols, flat.begin() + (size_t)(k + 1) * rows * cols, ch[k].d.begin());
+    }
+    frame.reset(new DescriptorFrame(_frame_id, std::move(ch)));
+    lap(5);
   } else {
-    std::vector<float> flat((size_t)num_channels * rows * cols);
-    for (int k = 0; k < num_channels; ++k)
-      std::copy(frame->channels[k].d.begin(), frame->channels[k].d.end(), flat.begin() + (size_t)k * rows * cols);
-    check(_engine, pba_set_frame_channels_f32(_engine, (int)(_frame_id % window), num_channels, flat.data()), "pba_set_frame_channels_f32");
+    frame.reset(new DescriptorFrame(_frame_id, I_ptr, rows, cols, dtype, nt));
+    lap(5);
+    if (_frame_resident) {
+      _frame_resident = false;                 // the pyramid class produced this level's frame on the device
+    } else if (frame->numChannels() == 1) {
+      check(_engine, pba_set_frame_u8(_engine, slot, I_ptr), "pba_set_frame_u8");
+    } else {
+      const int nc = (int)frame->numChannels();
+      std::vector<float> flat((size_t)nc * rows * cols);
+      for (int k = 0; k < nc; ++k)
+        std::copy(frame->channels[k].d.begin(), frame->channels[k].d.end(), flat.begin() + (size_t)k * rows * cols);
+      check(_engine, pba_set_frame_channels_f32(_engine, slot, nc, flat.data()), "pba_set_frame_channels_f32");
+    }
   }
 
+  const int num_channels = (int)frame->numChannels();
   const int B = std::max(_options_ptr->maskBlockRadius, std::max(2, _options_ptr->patchRadius));
   const int max_rows = rows - B - 1, max_cols = cols - B - 1;
   const int radius = _options_ptr->patchRadius, patch_length = PatchSizeFromRadius(radius);

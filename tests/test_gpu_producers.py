@@ -61,6 +61,7 @@ def test_descriptor_channels_on_device_equal_imgproc_h(kind, size):
     dev, via_host = _engine(size, channels=c), _engine(size, channels=c)
     dev.set_frame_descriptor(1, img, kind)
     via_host.set_frame_channels(1, ref)
+    assert np.array_equal(dev.get_frame_channels(1), ref) and np.array_equal(via_host.get_frame_channels(1), ref)   # what the class's front-end reads back
     for k in range(c):
         got = dev.get_frame_channel(1, k)
         assert np.array_equal(got[0], ref[k]), (kind, k, np.abs(got[0] - ref[k]).max())
