@@ -22,5 +22,5 @@ with open(cfg, "w") as f:
 r = subprocess.run([RUN, "-c", cfg, "-o", os.path.join(tmp, "o.txt")], capture_output=True, text=True, timeout=1500)
 print("rc", r.returncode)
 for l in (r.stderr + r.stdout).split("\n"):
-    if l.startswith(("addFrame", "optimize phases", "pba_solve:", "Using", "get_state", "solve_async")):
+    if l.startswith(("addFrame", "optimize phases", "pba_solve:", "Using", "get_state", "solve_async", "pyramid build")):
         print(l[:400])
