@@ -202,6 +202,64 @@ def test_lm_trace_matches_an_independent_dense_loop(huber, rot_deg):
     print("rejected steps in the trace:", rejected)
 
 
+@pytest.mark.parametrize("seed,rot_deg,trans,huber,kind", [(5, 0.05, 0.01, 0.0, "Parameter tolerance"), (6, 0.3, 0.05, 0.05, "Function tolerance"),
+                                                         (5, 1.0, 0.1, 0.0, "Function tolerance")])
+def test_termination_rules_against_the_dense_loop(seed, rot_deg, trans, huber, kind):
+    """Ceres' convergence tests with the reference's tolerances (photobundle.cc:738-761), restated on the dense loop: the
+    gradient test after every successful step, the parameter and function tolerance tests on the CANDIDATE before it is
+    accepted (the solve then ends WITHOUT taking that step and without logging the iteration) -- same termination kind, same
+    number of logged iterations, same final point as the oracle."""
+    from photobundle_amd import synthetic
+    p = synthetic.make_window(n_frames=3, n_points=36, radius=1, size=(96, 128), K=(150.0, 150.0, 64.0, 48.0), huber=huber,
+                              seed_offset=seed, rot_deg=rot_deg, trans=trans)
+    o = oracle.default_options()
+    ref = oracle.solve(p, o)
+    free = [c for c in range(p.n_frames) if c != p.fixed_slot]
+    cams, xyz = p.cams.copy(), p.xyz.copy()
+    cost = _huber_cost(p, cams, xyz)
+    radius, dec, scale, logged, why = o.initial_trust_region_radius, 2.0, None, 1, None
+    J, r, n_cam = _dense_system(p, cams, xyz)
+    while why is None:
+        if logged - 1 >= o.max_num_iterations:
+            why = "Maximum number of iterations"; break
+        if np.abs(J.T @ r).max() <= o.gradient_tolerance:
+            why = "Gradient tolerance"; break
+        if scale is None:
+            scale = 1.0 / (1.0 + np.sqrt((J * J).sum(0)))
+        Js = J * scale
+        D2 = np.clip((Js * Js).sum(0), o.min_lm_diagonal, o.max_lm_diagonal) / radius
+        step = -np.linalg.solve(Js.T @ Js + np.diag(D2), Js.T @ r)
+        model = Js @ step
+        model_cost_change = -model @ (r + model / 2)
+        delta = step * scale
+        cand_c, cand_x = cams.copy(), xyz.copy()
+        for i, c in enumerate(free):
+            cand_c[c] += delta[6 * i: 6 * i + 6]
+        cand_x += delta[n_cam:].reshape(-1, 3)
+        new_cost = _huber_cost(p, cand_c, cand_x)
+        x_norm = np.sqrt(sum((cams[c] ** 2).sum() for c in free) + (xyz ** 2).sum())
+        if np.linalg.norm(delta) <= o.parameter_tolerance * (x_norm + o.parameter_tolerance):
+            why = "Parameter tolerance"; break
+        if abs(cost - new_cost) <= o.function_tolerance * cost:
+            why = "Function tolerance"; break
+        rho = (cost - new_cost) / model_cost_change
+        if model_cost_change > 0 and rho > o.min_relative_decrease:
+            cams, xyz, cost = cand_c, cand_x, new_cost
+            radius = min(o.max_trust_region_radius, radius / max(1.0 / 3.0, 1.0 - (2.0 * rho - 1.0) ** 3))
+            dec = 2.0
+            J, r, n_cam = _dense_system(p, cams, xyz)
+        else:
+            radius /= dec
+            dec *= 2.0
+        logged += 1
+    print("dense loop:", why, logged, "| oracle:", ref["message"], len(ref["iterations"]))
+    assert ref["message"].startswith(why), (why, ref["message"])
+    assert why == kind
+    assert len(ref["iterations"]) == logged
+    assert np.isclose(ref["final_cost"], cost, rtol=1e-9)
+    assert np.abs(ref["cams"] - cams).max() <= 1e-7 and np.allclose(ref["xyz"], xyz, rtol=1e-7, atol=1e-7)
+
+
 def test_lm_trace_invariants(small_window):
     res = oracle.solve(small_window, oracle.default_options(max_num_iterations=30))
     its = res["iterations"]
