@@ -176,6 +176,16 @@ void Comm::close_peer() {
 }
 
 void Comm::shutdown(bool abort) {
+  if (abort) {
+    // the stream holds work that will never finish: abort the communicator FIRST and leak everything a free would have to
+    // synchronise for (hipFree / hipIpcCloseMemHandle wait for the device, and peers may still be polling this mailbox)
+    if (kind == 1 && nccl_comm && rccl().CommAbort) rccl().CommAbort(static_cast<ncclComm_t>(nccl_comm));
+    nccl_comm = nullptr;
+    for (int q = 0; q < kMaxPeers; ++q) mb_peer[q] = nullptr;
+    mb_own = nullptr; peer = false; h_stage = nullptr; stage_cap = 0; d_small = nullptr;
+    kind = 0; world = 1; rank = 0; fn = nullptr; ctx = nullptr; force = false;
+    return;
+  }
   close_peer();
   if (kind == 1 && nccl_comm) {
     // a communicator with a collective that will never complete must be aborted: ncclCommDestroy would wait for it

@@ -71,7 +71,9 @@ struct pba_engine {
   double* d_delta_c = nullptr;      // [kMaxFrames][6]
   double* d_partial = nullptr;      // [schur_grid][part_stride]
   double* d_red = nullptr;          // [kChunks][part_stride]
-  double* d_packed = nullptr;       // [part_stride]
+  double* d_packed = nullptr;       // [part_stride] (the tri layout of pba_solve.h needs packed_stride(n) < part_stride of them)
+  uint32_t* d_solve_tab = nullptr;  // window-shape index tables of the reduced solve (solve_tables), rebuilt when n_free changes
+  int solve_tab_nf = -1;
   double* d_S = nullptr;            // [n*n] debug copy
   double* d_rhs = nullptr;          // [n]
   double* d_block_cost[2] = {nullptr, nullptr};   // [sample_grid] block costs of the last pass at point parity k
@@ -147,6 +149,17 @@ int fail(pba_engine* e, int code, const char* fmt, ...) {
 // A timed-out publication wait leaves the stream stalled: every later call returns at once instead of hanging on it.
 #define PBA_NOT_POISONED(e) \
   do { if ((e)->poisoned) return fail((e), PBA_ERR_STATE, "the engine is unusable after a timed-out step (stalled stream / collective); destroy it"); } while (0)
+
+// A peer-exchange wait that timed out on the device (k_peer_allreduce / the solve's prologue) reports through a host-mapped
+// word.  The report is STICKY: the sums of that step were poisoned (NaN) on the device, the exchange sequence numbers may no
+// longer match the peers', so the engine is unusable from then on -- every later call fails with PBA_ERR_COMM / PBA_ERR_STATE.
+int comm_failed(pba_engine* e) {
+  if (!e->h_comm_err) return PBA_OK;
+  const unsigned int w = *reinterpret_cast<volatile unsigned int*>(e->h_comm_err);
+  if (!w) return PBA_OK;
+  e->poisoned = true;
+  return fail(e, PBA_ERR_COMM, "peer exchange timed out after %.0f s waiting for rank %u", 0.5 * e->wait_timeout_s, w - 1);
+}
 
 // Grow-only device buffers: a sliding-window caller re-submits a problem of similar size for every frame, and a
 // hipFree + hipMalloc pair per buffer per frame is pure overhead.  Contents are undefined after the call (every user
@@ -256,7 +269,7 @@ void ev_collect(pba_engine* e) {
 
 void launch_solve(pba_engine* e, const SolveParams& so, int n) {
   if (e->solve_kind == 0) {
-    if (e->n_free > kSolveNarrowFree) hipLaunchKernelGGL((k_solve_blocked<1024>), dim3(1), dim3(1024), solve_blocked_smem_bytes(n), e->stream, so);
+    if (e->n_free > kSolveNarrowFree) hipLaunchKernelGGL((k_solve_blocked<kSolveWideThreads>), dim3(1), dim3(kSolveWideThreads), solve_blocked_smem_bytes(n), e->stream, so);
     else hipLaunchKernelGGL((k_solve_blocked<kSolveBlockedThreads>), dim3(1), dim3(kSolveBlockedThreads), solve_blocked_smem_bytes(n), e->stream, so);
     return;
   }
@@ -285,7 +298,8 @@ double* peer_slot(pba_engine* e, int kind) {
 // the exchange itself: flags + rank-ordered sum of n doubles into `out` (device memory of this rank)
 int peer_allreduce(pba_engine* e, int kind, int n, double* out) {
   const unsigned long long x = ++(kind == 0 ? e->comm.seq_a : e->comm.seq_b);
-  const unsigned long long ticks = (unsigned long long)(e->wait_timeout_s * 1e8);
+  // device-side wait: half the host watchdog (100 MHz s_memrealtime), so that the recoverable PBA_ERR_COMM wins the race
+  const unsigned long long ticks = (unsigned long long)(0.5 * e->wait_timeout_s * 1e8);
   const int grid = std::max(1, std::min(32, (n + 255) / 256));
   hipLaunchKernelGGL(k_peer_allreduce, dim3(grid), dim3(256), 0, e->stream, peer_params(e), (int)Comm::flag_index(kind, x),
                      (unsigned long long)Comm::data_offset(kind, x), n, x, out, ticks, e->h_comm_err_dev);
@@ -294,40 +308,54 @@ int peer_allreduce(pba_engine* e, int kind, int n, double* out) {
 }
 
 // Reduction of the Schur partials + reduced solve.  One launch (k_reduce_solve) at a single rank; with more ranks the
-// all-reduce of the packed sums sits between the two, so they stay separate kernels.
-int launch_reduce_and_solve(pba_engine* e, const SolveParams& so, int n, int cur, int cand, const LmState* lm, int final_pass, int n_cost_blocks) {
+// exchange of the packed sums sits between the two, so they stay separate kernels.  With the peer exchange there is no
+// exchange kernel: the reduction's last workgroup raises this rank's mailbox flag, the solve's prologue waits for every
+// rank's flag and sums the mailbox slots in rank order (pba_solve.h).
+int launch_reduce_and_solve(pba_engine* e, SolveParams so, int n, int cur, int cand, const LmState* lm, int final_pass, int n_cost_blocks) {
   const bool multi = e->comm.multi();
   const int grid = (e->part_stride + kReduceEntries - 1) / kReduceEntries + 1;
+  const int pstride = packed_stride(n);
+  ReduceParams rp{};
+  rp.partial = e->d_partial; rp.n_blocks = e->schur_grid; rp.stride = e->part_stride; rp.n_free = e->n_free; rp.n_pairs = e->n_pairs;
+  rp.block_cost = e->d_block_cost[cur]; rp.block_fail = e->d_block_fail[cur]; rp.n_cost_blocks = n_cost_blocks;
+  rp.packed = e->d_packed; rp.scal = e->d_scal;
   if (!multi && e->solve_kind == 0 && !(PBA_PHASE_TIMING && getenv("PBA_SPLIT_SOLVE"))) {
-    ReduceSolveParams rp{};
-    rp.partial = e->d_partial; rp.n_blocks = e->schur_grid; rp.stride = e->part_stride;
-    rp.block_cost = e->d_block_cost[cur]; rp.block_fail = e->d_block_fail[cur]; rp.n_cost_blocks = n_cost_blocks;
-    rp.block_cost_alt = e->d_block_cost[cand]; rp.block_fail_alt = e->d_block_fail[cand];
-    rp.packed = e->d_packed; rp.scal = e->d_scal; rp.ticket = e->d_ticket_solve; rp.so = so;
-    rp.stamp = (lm && !final_pass) ? stamp_record(e) : nullptr;
+    ReduceSolveParams rsp{};
+    rsp.rp = rp;
+    rsp.block_cost_alt = e->d_block_cost[cand]; rsp.block_fail_alt = e->d_block_fail[cand];
+    rsp.ticket = e->d_ticket_solve; rsp.so = so;
+    rsp.stamp = (lm && !final_pass) ? stamp_record(e) : nullptr;
     ev_begin(e, 3);
-    hipLaunchKernelGGL(k_reduce_solve, dim3(grid), dim3(1024), solve_blocked_smem_bytes(n), e->stream, rp);
+    hipLaunchKernelGGL(k_reduce_solve, dim3(grid), dim3(kReduceThreads), solve_blocked_smem_bytes(n), e->stream, rsp);
     ev_end(e, 3);
     HIP_TRY(e, hipGetLastError());
     return PBA_OK;
   }
   const bool peer = multi && e->comm.peer;
-  if (peer && (size_t)e->part_stride > Comm::kCapA) return fail(e, PBA_ERR_COMM, "reduced system of %d doubles exceeds the peer mailbox", e->part_stride);
+  if (peer && (size_t)pstride > Comm::kCapA) return fail(e, PBA_ERR_COMM, "reduced system of %d doubles exceeds the peer mailbox", pstride);
+  ReduceFinalParams fp{};
+  fp.rp = rp; fp.lm = lm; fp.enq_cur = cur; fp.final_pass = final_pass;
+  fp.block_cost_alt = e->d_block_cost[cand]; fp.block_fail_alt = e->d_block_fail[cand];
+  fp.sys_stores = peer ? 1 : 0; fp.ticket = e->d_ticket_solve; fp.peer_flag = -1;
+  if (peer) {
+    const unsigned long long x = ++e->comm.seq_a;
+    fp.rp.packed = e->comm.mb_own + Comm::data_offset(0, x);
+    fp.peer_own = e->comm.mb_own; fp.peer_flag = (int)Comm::flag_index(0, x); fp.peer_seq = x;
+    so.peer = peer_params(e); so.peer_world = e->comm.world; so.peer_flag = (int)Comm::flag_index(0, x);
+    so.peer_off = (unsigned long long)Comm::data_offset(0, x); so.peer_seq = x;
+    so.peer_timeout = (unsigned long long)(0.5 * e->wait_timeout_s * 1e8);      // device-side wait: half the host watchdog, so that the recoverable error wins
+    so.peer_err = e->h_comm_err_dev;
+  }
   ev_begin(e, 3);
-  hipLaunchKernelGGL(k_reduce_final, dim3(grid), dim3(1024), 0, e->stream, e->d_partial, e->schur_grid, e->part_stride,
-                     e->d_block_cost[cur], e->d_block_fail[cur], n_cost_blocks, peer ? peer_slot(e, 0) : e->d_packed, e->d_scal, lm, cur,
-                     (const double*)e->d_block_cost[cand], (const int32_t*)e->d_block_fail[cand], final_pass, peer ? 1 : 0);
+  hipLaunchKernelGGL(k_reduce_final, dim3(grid), dim3(kReduceThreads), 0, e->stream, fp);
   ev_end(e, 3);
   HIP_TRY(e, hipGetLastError());
-  if (multi) ev_begin(e, 5);
-  if (peer) {
-    const int rcp = peer_allreduce(e, 0, e->part_stride - 1, e->d_packed);
-    if (rcp) return rcp;
-  } else if (multi) {
-    if (e->comm.allreduce_device(e->d_packed, (size_t)e->part_stride - 1, 0, e->stream))
+  if (multi && !peer) {
+    ev_begin(e, 5);
+    if (e->comm.allreduce_device(e->d_packed, (size_t)pstride, 0, e->stream))
       return fail(e, PBA_ERR_COMM, "allreduce(reduced system) failed: %s", e->comm.err.c_str());
+    ev_end(e, 5);
   }
-  if (multi) ev_end(e, 5);
   ev_begin(e, 4);
   launch_solve(e, so, n);
   ev_end(e, 4);
@@ -539,7 +567,7 @@ void pba_destroy(pba_engine* e) {
   dev_free(&e->d_rays);
   dev_free(&e->d_desc); dev_free(&e->d_w2); dev_free(&e->d_obs_point); dev_free(&e->d_obs_slot); dev_free(&e->d_pt_begin);
   dev_free(&e->d_tile_info); dev_free(&e->d_lane_rec); dev_free(&e->d_rec[0]); dev_free(&e->d_rec[1]); dev_free(&e->d_sp); dev_free(&e->d_ptrec); dev_free(&e->d_sc);
-  dev_free(&e->d_delta_c); dev_free(&e->d_partial); dev_free(&e->d_red); dev_free(&e->d_packed); dev_free(&e->d_S);
+  dev_free(&e->d_delta_c); dev_free(&e->d_partial); dev_free(&e->d_red); dev_free(&e->d_packed); dev_free(&e->d_solve_tab); dev_free(&e->d_S);
   dev_free(&e->d_rhs); dev_free(&e->d_bs_out); dev_free(&e->d_scal); dev_free(&e->d_xchg); dev_free(&e->d_ticket); dev_free(&e->d_ticket_solve); dev_free(&e->d_stamp);
   if (e->h_scal) (void)hipHostFree(e->h_scal);
   if (e->h_lm) (void)hipHostFree(e->h_lm);
@@ -876,6 +904,14 @@ int pba_set_cameras(pba_engine* e, const double* cams6, int32_t n_frames, int32_
   if ((rc = dev_alloc(e, &e->d_partial, (size_t)(256 * 4) * e->part_stride))) return rc;
   if ((rc = dev_alloc(e, &e->d_red, (size_t)pba_engine::kChunks * e->part_stride))) return rc;
   if ((rc = dev_alloc(e, &e->d_packed, (size_t)e->part_stride))) return rc;
+  if (e->solve_tab_nf != e->n_free) {
+    std::vector<uint32_t> tab((size_t)solve_table_words(e->n_free));
+    solve_tables(e->n_free, tab.data());
+    if ((rc = dev_alloc(e, &e->d_solve_tab, tab.size()))) return rc;
+    HIP_TRY(e, hipMemcpyAsync(e->d_solve_tab, tab.data(), sizeof(uint32_t) * tab.size(), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));      // (the host vector goes out of scope)
+    e->solve_tab_nf = e->n_free;
+  }
   HIP_TRY(e, hipMemcpyAsync(e->d_cams[e->cur], cams6, sizeof(double) * 6 * n_frames, hipMemcpyHostToDevice, e->stream));
   hipLaunchKernelGGL(k_cam_geom, dim3(1), dim3(64), 0, e->stream, e->d_cams[e->cur], e->d_geom[e->cur], n_frames, e->fixed_slot);
   HIP_TRY(e, hipGetLastError());
@@ -1036,7 +1072,7 @@ int pba_internal_step(pba_engine* e, double radius, int32_t init_scale, const pb
   so.cams = e->d_cams[cur]; so.cams_cand = e->d_cams[cand]; so.delta_c = e->d_delta_c;
   so.sc = e->d_sc; so.S_dbg = (e->cfg.flags & 1) ? e->d_S : nullptr; so.rhs_dbg = e->d_rhs; so.scal = e->d_scal; so.geom = e->d_geom[cur];
   so.n_frames = e->n_frames; so.n_free = e->n_free; so.n_pairs = e->n_pairs; so.stride = e->part_stride;
-  so.fixed_slot = e->fixed_slot;
+  so.fixed_slot = e->fixed_slot; so.tab = e->d_solve_tab;
   so.geom_cand = (!grad_only && fused_capable(e)) ? e->d_geom[cand] : nullptr;
   so.init_scale = init_scale; so.jacobi = o->jacobi_scaling; so.radius = radius; so.min_diag = o->min_lm_diagonal;
   so.max_diag = o->max_lm_diagonal;
@@ -1155,10 +1191,9 @@ int pba_internal_step(pba_engine* e, double radius, int32_t init_scale, const pb
     volatile unsigned long long* h_seq = reinterpret_cast<volatile unsigned long long*>(e->h_scal + kNumScal);
     unsigned long spins = 0;
     double t_first = -1.0;
+    { const int rcc = comm_failed(e); if (rcc) return rcc; }
     while (*h_seq != seq) {
-      if (*reinterpret_cast<volatile unsigned int*>(e->h_comm_err))
-        return fail(e, PBA_ERR_COMM, "peer exchange timed out after %.0f s waiting for rank %u", e->wait_timeout_s,
-                    *reinterpret_cast<volatile unsigned int*>(e->h_comm_err) - 1);
+      { const int rcc = comm_failed(e); if (rcc) return rcc; }
       // hipStreamQuery is not free for the device (it showed up as a ~6 us bubble in front of the next kernel), so it only
       // serves as a watchdog here: roughly every 50 ms of spinning
       if ((++spins & 0x3ffffff) == 0) {
@@ -1174,6 +1209,8 @@ int pba_internal_step(pba_engine* e, double radius, int32_t init_scale, const pb
       }
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    // the sequence number may already have been there when the wait was entered: the error word is checked on the way out too
+    { const int rcc = comm_failed(e); if (rcc) return rcc; }
   }
   if (e->profile) { HIP_TRY(e, hipStreamSynchronize(e->stream)); ev_collect(e); }
   double s[kNumScal];
@@ -1412,7 +1449,7 @@ int pba_internal_async_enqueue(pba_engine* e, int kind, int init_scale, const pb
   SolveParams so{};
   so.packed = e->d_packed; so.cams = e->d_cams[cur]; so.cams_cand = e->d_cams[cand]; so.delta_c = e->d_delta_c;
   so.sc = e->d_sc; so.S_dbg = (e->cfg.flags & 1) ? e->d_S : nullptr; so.rhs_dbg = e->d_rhs; so.scal = e->d_scal; so.geom = e->d_geom[cur];
-  so.n_frames = e->n_frames; so.n_free = e->n_free; so.n_pairs = e->n_pairs; so.stride = e->part_stride; so.fixed_slot = e->fixed_slot;
+  so.n_frames = e->n_frames; so.n_free = e->n_free; so.n_pairs = e->n_pairs; so.stride = e->part_stride; so.fixed_slot = e->fixed_slot; so.tab = e->d_solve_tab;
   so.geom_cand = (kind == 1) ? e->d_geom[cand] : nullptr;
   so.init_scale = init_scale; so.jacobi = o->jacobi_scaling; so.radius = 1.0; so.min_diag = o->min_lm_diagonal; so.max_diag = o->max_lm_diagonal;
   so.lm = e->d_lm; so.enq_cur = cur; so.final_pass = (kind == 2) ? 1 : 0; so.cams_alt = e->d_cams[cand]; so.cams_cand_alt = e->d_cams[cur]; so.geom_alt = e->d_geom[cand];
@@ -1456,11 +1493,9 @@ int pba_internal_async_wait(pba_engine* e, unsigned long long seq) {
   volatile unsigned long long* h_seq = reinterpret_cast<volatile unsigned long long*>(e->h_scal + kNumScal);
   unsigned long spins = 0;
   double t_first = -1.0;
+  { const int rcc = comm_failed(e); if (rcc) return rcc; }
   while (*h_seq < seq) {
-    if (*reinterpret_cast<volatile unsigned int*>(e->h_comm_err)) {
-      const unsigned int who = *reinterpret_cast<volatile unsigned int*>(e->h_comm_err) - 1;
-      return fail(e, PBA_ERR_COMM, "peer exchange timed out after %.0f s waiting for rank %u", e->wait_timeout_s, who);
-    }
+    { const int rcc = comm_failed(e); if (rcc) return rcc; }
     // hipStreamQuery is not free for the device (it showed up as a ~6 us bubble in front of the next kernel), so it only
     // serves as a watchdog here: roughly every 50 ms of spinning
     if ((++spins & 0x3ffffff) == 0) {
@@ -1483,7 +1518,7 @@ int pba_internal_async_wait(pba_engine* e, unsigned long long seq) {
     }
   }
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
-  return PBA_OK;
+  return comm_failed(e);      // (normal with the pipelined driver: the awaited number was already visible on entry)
 }
 
 const void* pba_internal_async_state(const pba_engine* e) { return e->h_lm; }
@@ -1494,6 +1529,7 @@ int pba_internal_async_end(pba_engine* e) {
   // the host mirror was written by the last publishing kernel the caller waited for; kernels enqueued after a
   // termination are no-ops, so nothing behind it touches the state
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  { const int rcc = comm_failed(e); if (rcc) return rcc; }
   const LmState st = *e->h_lm;
   e->cur = st.cur;
   e->lin_valid[e->cur] = true; e->lin_valid[1 - e->cur] = false;

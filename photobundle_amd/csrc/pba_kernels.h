@@ -544,20 +544,30 @@ struct PeerParams {
 __global__ __launch_bounds__(256) void k_peer_allreduce(PeerParams pp, int flag_idx, unsigned long long data_off, int n,
                                                          unsigned long long seq, double* __restrict__ out,
                                                          unsigned long long timeout_ticks, unsigned int* host_err) {
+  __shared__ int s_bad;
+  if (threadIdx.x == 0) s_bad = 0;
+  // the producer kernel (earlier on this stream) has retired, so its system-scope stores have; release ordering on the flag
   if (blockIdx.x == 0 && threadIdx.x == 0)
-    __hip_atomic_store(reinterpret_cast<unsigned long long*>(pp.own) + flag_idx, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(pp.own) + flag_idx, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  __syncthreads();
   if ((int)threadIdx.x < pp.world) {
-    const unsigned long long* f = reinterpret_cast<const unsigned long long*>(pp.mb[threadIdx.x]) + flag_idx;
+    const int t = threadIdx.x;
+    const double* mbq = t == 1 ? pp.mb[1] : t == 2 ? pp.mb[2] : t == 3 ? pp.mb[3] : t == 4 ? pp.mb[4] : t == 5 ? pp.mb[5]
+                      : t == 6 ? pp.mb[6] : t == 7 ? pp.mb[7] : pp.mb[0];
+    const unsigned long long* f = reinterpret_cast<const unsigned long long*>(mbq) + flag_idx;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+    while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
       if (__builtin_amdgcn_s_memrealtime() - t0 > timeout_ticks) {
         if (host_err) __hip_atomic_store(host_err, 1u + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        s_bad = 1;
         break;
       }
       __builtin_amdgcn_s_sleep(16);
     }
   }
   __syncthreads();
+  // a peer that never showed up: the sums are poisoned (NaN), so that a missed error word can never look like a step
+  const bool bad = s_bad != 0;
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
     double v[8];
 #pragma unroll
@@ -565,7 +575,7 @@ __global__ __launch_bounds__(256) void k_peer_allreduce(PeerParams pp, int flag_
     double acc = v[0];
 #pragma unroll
     for (int q = 1; q < 8; ++q) if (q < pp.world) acc += v[q];
-    out[e] = acc;
+    out[e] = bad ? __longlong_as_double(0x7ff8000000000000ll) : acc;
   }
 }
 __device__ inline void xchg_unpack(const double* xchg, double* scal, int world) {   // one thread
@@ -2471,781 +2481,12 @@ __global__ __launch_bounds__(kTile, 2) void k_schur(SchurParams p_in) {
   }
 }
 
-// Fixed-order reduction of the per-block partials + packing for the reduced solve / the multi-rank transport.
-// Workgroup = 32 entries x 32 sub-chunks: thread (ex, sub) sums blocks sub, sub + 32, ... of entry ex, then the 32
-// sub-sums are combined by a fixed LDS tree.
-//   packed[0, stride-3) = T | rhs | g_c | diag(U);  packed[stride-3] = cost at the linearisation point (sum of the
-//   Jacobian-pass block costs);  packed[stride-2] = sum g_p^2;  scal[kGmaxPts / kSchurFail / kEvalFailLin] = max group.
-constexpr int kReduceEntries = 16;      // packed entries per workgroup of k_reduce_final (x 64 sub-chunks of blocks)
-__global__ __launch_bounds__(1024) void k_reduce_final(const double* __restrict__ partial, int n_blocks, int stride,
-                                                        const double* __restrict__ block_cost,
-                                                        const int32_t* __restrict__ block_fail, int n_cost_blocks,
-                                                        double* __restrict__ packed, double* __restrict__ scal,
-                                                        const LmState* lm, int enq_cur, const double* block_cost_alt,
-                                                        const int32_t* block_fail_alt, int final_pass, int sys_stores) {
-  // sys_stores: `packed` is this rank's peer-exchange mailbox (read by other devices): write-through, cache-bypassing stores
-  if (lm) {
-    if (lm->done && !final_pass) return;
-    if (final_pass && !lm_final_pass_needed(lm)) return;
-    if (lm->cur != enq_cur) { block_cost = block_cost_alt; block_fail = block_fail_alt; }
-  }
-  constexpr int EX = kReduceEntries, SUB = 1024 / EX;
-  __shared__ double s_red[SUB][EX + 1];
-  __shared__ int s_f[1024];
-  const int tid = threadIdx.x;
-  const int ex = tid % EX, sub = tid / EX;
-  if ((int)blockIdx.x < (int)gridDim.x - 1) {
-    const int e = blockIdx.x * EX + ex;
-    const bool valid = e < stride;
-    const bool is_max = (e == stride - 3) || (e == stride - 1);
-    double acc = 0.0;
-    if (valid) {
-      // 16 loads in flight per thread (all of them for <= 1024 partials), summed in block order (fixed)
-      for (int b = sub; b < n_blocks; b += 16 * SUB) {
-        double v[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-          const int bb = b + SUB * k;
-          v[k] = (bb < n_blocks) ? partial[(size_t)bb * stride + e] : 0.0;
-        }
-#pragma unroll
-        for (int k = 0; k < 16; ++k) acc = is_max ? fmax(acc, v[k]) : acc + v[k];
-      }
-    }
-    // the four sub-chunks of a wave (lanes ex, ex + 16, ex + 32, ex + 48) combine by two cross-lane steps, the 16 waves
-    // through LDS, one thread per entry adds them in wave order: two barriers instead of a seven-level tree
-    static_assert(EX == 16, "lane = 16 (sub % 4) + ex");
-#pragma unroll
-    for (int off = 16; off <= 32; off <<= 1) {
-      const double o = __shfl_xor(acc, off);
-      acc = is_max ? fmax(acc, o) : acc + o;
-    }
-    if ((tid & 63) < EX) s_red[tid >> 6][ex] = acc;
-    __syncthreads();
-    if (sub == 0 && valid) {
-      double v = s_red[0][ex];
-#pragma unroll
-      for (int w = 1; w < 1024 / 64; ++w) v = is_max ? fmax(v, s_red[w][ex]) : v + s_red[w][ex];
-      if (e < stride - 3) { if (sys_stores) store_system_f64(packed + e, v); else packed[e] = v; }
-      else if (e == stride - 3) scal[kGmaxPts] = v;
-      else if (e == stride - 2) { if (sys_stores) store_system_f64(packed + stride - 2, v); else packed[stride - 2] = v; }
-      else scal[kSchurFail] = v;
-    }
-  } else {
-    // last workgroup: cost of the linearisation point = fixed-order sum of the Jacobian-pass block partials
-    static_assert(SUB * (EX + 1) >= 1024, "flat view");
-    double* flat = &s_red[0][0];
-    double acc = 0.0; int f = 0;
-    for (int b = tid; b < n_cost_blocks; b += 1024) { acc += block_cost[b]; f |= block_fail[b]; }
-    flat[tid] = acc; s_f[tid] = f;
-    __syncthreads();
-    for (int s = 512; s > 0; s >>= 1) { if (tid < s) { flat[tid] += flat[tid + s]; s_f[tid] |= s_f[tid + s]; } __syncthreads(); }
-    if (tid == 0) { if (sys_stores) store_system_f64(packed + stride - 3, flat[0]); else packed[stride - 3] = flat[0]; scal[kEvalFailLin] = (double)s_f[0]; }
-  }
-}
+}  // namespace pba
 
-// =====================================================================================================
-// reduced camera system: (level-2 reduction,) scaling, damping, dense Cholesky, camera step, candidate cameras
-// and their geometry.  One workgroup of 128 threads; thread r owns row r of the (<= 96 x 96) matrix in LDS.
-// =====================================================================================================
-struct SolveParams {
-  const double* packed;     // reduced (and, multi-rank, all-reduced) packed sums
-  const double* cams;       // current cameras [n_frames][6]
-  double* cams_cand;        // candidate cameras
-  double* delta_c;          // [n_frames][6] unscaled camera step (0 for the constant camera)
-  double* sc;               // [2][6 n_free] Jacobi scale of the camera columns | column-is-live flags (written when init_scale)
-  double* S_dbg;            // [n*n] scaled + damped reduced matrix (test hook), may be null
-  double* rhs_dbg;          // [n]
-  double* scal;
-  const CamGeom* geom;      // current geometry (free_index of every slot)
-  CamGeom* geom_cand;       // candidate geometry output (null: produced elsewhere)
-  int32_t n_frames, n_free, n_pairs, stride, fixed_slot;
-  int32_t init_scale, jacobi;
-  double radius, min_diag, max_diag;
-  // asynchronous driver
-  const LmState* lm;
-  int32_t enq_cur, final_pass;
-  int32_t dbg;
-  const double* cams_alt; double* cams_cand_alt; const CamGeom* geom_alt; CamGeom* geom_cand_alt;
-};
+// reduction of the Schur partials + the reduced camera solve (k_reduce_final, k_reduce_solve, k_solve_blocked, k_solve_generic)
+#include "pba_solve.h"
 
-__device__ __forceinline__ bool solve_resolve(SolveParams& p) {
-  if (!p.lm) return true;
-  if (p.lm->done && !p.final_pass) return false;
-  if (p.final_pass && !lm_final_pass_needed(p.lm)) return false;
-  if (p.lm->cur != p.enq_cur) {
-    p.cams = p.cams_alt; p.cams_cand = p.cams_cand_alt; p.geom = p.geom_alt;
-    if (p.geom_cand) p.geom_cand = p.geom_cand_alt;
-  }
-  p.radius = p.lm->radius;
-  return true;
-}
-
-
-// Shared prologue: scale / damp / scatter the packed pair blocks into the dense symmetric matrix S (LDS, leading
-// dimension ld), right-hand side into y.  T threads.
-template <int T>
-__device__ __forceinline__ void solve_prologue(const SolveParams& p, int n, int ld, double* S, double* y, double* sc,
-                                               double* D2, double* gcs, double* gc, int tid) {
-  const int nT = 36 * p.n_pairs;
-  const double* src = p.packed;
-  // first batch of packed entries: issued before anything else so that the whole prologue is ONE global round trip for
-  // n <= 42 (the scale / damping vectors below are loaded at the same time, not ahead of the blocks)
-  double val0[4];
-#pragma unroll
-  for (int u = 0; u < 4; ++u) { const int e = tid + u * T; val0[u] = (e < nT) ? src[e] : 0.0; }
-  for (int i = tid; i < n; i += T) {
-    const double du = src[nT + 2 * n + i];
-    const double g = src[nT + n + i];
-    double s;
-    // sc[n + i]: the column has a nonzero norm at the initial point.  A free camera whose six flags are all zero has no
-    // residual block anywhere (the sums are global at world > 1): not a parameter block of the Ceres program
-    if (p.init_scale) { s = p.jacobi ? 1.0 / (1.0 + sqrt(du)) : 1.0; p.sc[i] = s; p.sc[n + i] = du > 0.0 ? 1.0 : 0.0; }
-    else s = p.sc[i];
-    sc[i] = s;
-    D2[i] = fmin(fmax(s * s * du, p.min_diag), p.max_diag) / p.radius;
-    gc[i] = g;
-    gcs[i] = s * g;
-    y[i] = s * src[nT + i];
-  }
-  // pair index -> (a, b), decoded once (the packed blocks are enumerated row by row: (a, a..nf-1))
-  __shared__ unsigned char s_pa[kMaxFrames * (kMaxFrames + 1) / 2], s_pb[kMaxFrames * (kMaxFrames + 1) / 2];
-  for (int pr = tid; pr < p.n_pairs; pr += T) {
-    int a = 0, rem = pr;
-    while (rem >= p.n_free - a) { rem -= p.n_free - a; ++a; }
-    s_pa[pr] = (unsigned char)a; s_pb[pr] = (unsigned char)(a + rem);
-  }
-  __syncthreads();
-  // four packed entries in flight per thread (the loop is otherwise one dependent global load per trip)
-  for (int e0 = tid; e0 < nT; e0 += 4 * T) {
-    double val[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) { const int e = e0 + u * T; val[u] = (e0 == tid) ? val0[u] : ((e < nT) ? src[e] : 0.0); }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int e = e0 + u * T;
-      if (e >= nT) continue;
-      const int pair = e / 36, k = e - pair * 36;
-      const int i = k / 6, j = k - i * 6;
-      const int a = s_pa[pair], b = s_pb[pair];
-      const int r = 6 * a + i, c = 6 * b + j;
-      double v = sc[r] * val[u] * sc[c];
-      if (r == c) v += D2[r];
-      if (a != b || c >= r) S[r * ld + c] = v;   // diagonal blocks: take the upper triangle, mirror below
-      if (a != b || c > r) S[c * ld + r] = v;
-    }
-  }
-  __syncthreads();
-  if (p.S_dbg) {
-    for (int k = tid; k < n * n; k += T) p.S_dbg[k] = S[(k / n) * ld + (k % n)];
-    for (int i = tid; i < n; i += T) p.rhs_dbg[i] = y[i];
-  }
-  __syncthreads();
-}
-
-// Shared epilogue: camera step delta_c = -sc * y, candidate cameras, replicated scalars (wave 0 reduces them with a
-// fixed butterfly).  The candidate camera geometry is produced by the first workgroup of k_backsub.
-template <int T>
-__device__ __forceinline__ void solve_epilogue(const SolveParams& p, int n, const double* y, const double* sc,
-                                               const double* D2, const double* gcs, const double* gc, bool chol_ok,
-                                               int tid) {
-  if (tid < 6 * p.n_frames && !(p.final_pass && !p.init_scale)) {
-    const int slot = tid / 6, k = tid % 6;
-    const int fa = p.geom[slot].free_index;
-    double d = 0.0;
-    if (fa >= 0) d = -sc[6 * fa + k] * y[6 * fa + k];
-    p.delta_c[tid] = d;
-    p.cams_cand[tid] = p.cams[tid] + d;
-  }
-  if (p.geom_cand) {
-    // candidate camera geometry by the last wave (reads cams + delta directly: no dependency on the stores above)
-    const int c = tid - (T - 64);
-    if (c >= 0 && c < p.n_frames) {
-      double cam6[6];
-      const int fa = p.geom[c].free_index;
-      for (int k = 0; k < 6; ++k) cam6[k] = p.cams[6 * c + k] + (fa >= 0 ? -sc[6 * fa + k] * y[6 * fa + k] : 0.0);
-      cam_geom_one(cam6 - 6 * c, p.geom_cand, c, p.fixed_slot);
-    }
-  }
-  if (tid < 64) {
-    double mcc = 0.0, st2 = 0.0, x2 = 0.0, gmax = 0.0, gn2 = 0.0, bad = 0.0;
-    for (int i = tid; i < n; i += 64) {
-      mcc += 0.5 * y[i] * gcs[i] + 0.5 * D2[i] * y[i] * y[i];
-      const double d = sc[i] * y[i];
-      st2 += d * d;
-      gmax = fmax(gmax, fabs(gc[i]));
-      gn2 += gc[i] * gc[i];
-      if (!isfinite(y[i])) bad = 1.0;
-    }
-    for (int i = tid; i < 6 * p.n_frames; i += 64) {
-      const int fa = p.geom[i / 6].free_index;
-      if (fa < 0) continue;
-      const double* live = p.sc + n + 6 * fa;     // written by this kernel at the first linearisation (or just above)
-      if (live[0] + live[1] + live[2] + live[3] + live[4] + live[5] > 0.0) x2 += p.cams[i] * p.cams[i];
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      mcc += __shfl_xor(mcc, off); st2 += __shfl_xor(st2, off); x2 += __shfl_xor(x2, off);
-      gn2 += __shfl_xor(gn2, off); gmax = fmax(gmax, __shfl_xor(gmax, off)); bad = fmax(bad, __shfl_xor(bad, off));
-    }
-    if (tid == 0) {
-      p.scal[kMccCams] = mcc; p.scal[kStep2Cams] = st2; p.scal[kX2Cams] = x2;
-      p.scal[kGmaxCams] = gmax; p.scal[kGnorm2Cams] = gn2;
-      p.scal[kSolveOk] = (chol_ok && bad == 0.0) ? 1.0 : 0.0;
-      p.scal[kCostLin] = p.packed[p.stride - 3];
-      p.scal[kGnorm2Pts] = p.packed[p.stride - 2];
-    }
-  }
-}
-
-// (Rounds 1-2 had one- and two-wave kernels here, k_solve_wave<NF> / k_solve_wave2<NF>: a row of L per lane in registers,
-// v_readlane chains, ~50 KB of straight-line code per size, 16.4 us at n = 42 and 81.7 us at n = 90.  The blocked workgroup
-// solve below replaced them; profiles/r03/before_old_solve_*.csv keeps their timings.)
-
-// Generic path (any n <= 96; diagnostics, PBA_SOLVE=1): matrix in LDS, 256 threads, 2-D trailing update, one barrier pair per column.
-constexpr int kSolveThreads = 256;
-
-__global__ __launch_bounds__(kSolveThreads) void k_solve_generic(SolveParams p_in) {
-  SolveParams p = p_in;
-  if (!solve_resolve(p)) return;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int n = 6 * p.n_free;
-  const int ld = n + 1;
-  double* S = reinterpret_cast<double*>(smem);   // [n][ld]
-  double* y = S + n * ld;
-  double* sc = y + n;
-  double* D2 = sc + n;
-  double* gcs = D2 + n;
-  double* gc = gcs + n;
-  __shared__ int s_ok;
-  const int tid = threadIdx.x;
-  if (tid == 0) s_ok = 1;
-  solve_prologue<kSolveThreads>(p, n, ld, S, y, sc, D2, gcs, gc, tid);
-  const int tx = tid & 15, ty = tid >> 4;
-  for (int j = 0; j < n; ++j) {
-    const double d = S[j * ld + j];
-    const double dj = (d > 0.0) ? sqrt(d) : 1.0;
-    if (tid == 0 && (!(d > 0.0) || !isfinite(d))) s_ok = 0;
-    __syncthreads();
-    for (int r = j + tid; r < n; r += kSolveThreads) S[r * ld + j] = (r == j) ? dj : S[r * ld + j] / dj;
-    __syncthreads();
-    for (int r = j + 1 + ty; r < n; r += 16) {
-      const double lrj = S[r * ld + j];
-      for (int c = j + 1 + tx; c <= r; c += 16) S[r * ld + c] -= lrj * S[c * ld + j];
-    }
-    __syncthreads();
-  }
-  for (int j = 0; j < n; ++j) {
-    if (tid == 0) y[j] /= S[j * ld + j];
-    __syncthreads();
-    const double yj = y[j];
-    for (int r = j + 1 + tid; r < n; r += kSolveThreads) y[r] -= S[r * ld + j] * yj;
-    __syncthreads();
-  }
-  for (int j = n - 1; j >= 0; --j) {
-    if (tid == 0) y[j] /= S[j * ld + j];
-    __syncthreads();
-    const double yj = y[j];
-    for (int r = tid; r < j; r += kSolveThreads) y[r] -= S[j * ld + r] * yj;
-    __syncthreads();
-  }
-  solve_epilogue<kSolveThreads>(p, n, y, sc, D2, gcs, gc, s_ok != 0, tid);
-}
-
-// =====================================================================================================
-// Blocked dense factorisation of the reduced camera system on one 256-thread workgroup (any n = 6 nf <= 96).
-//
-// The one-wave kernels above walk 6 nf dependent columns (42 at BASELINE configs[1], 90 at configs[3]) through ~50 KB of
-// straight-line code; this one walks nf dependent PANELS of six columns with a small loop body, square-root free
-// (S = L D L^T, unit lower L: the pivot chain is reciprocal + multiply instead of reciprocal square root + two products):
-//   phase A (one thread per row at / below the panel, the right-hand side riding along as row n of the augmented matrix
-//            [S y; y^T .] -- its factor row is D^-1 L^-1 y, so the forward substitution and the diagonal scaling cost
-//            nothing extra): every thread factorises the 6x6 diagonal block itself (21 broadcast LDS reads, a chain of
-//            six reciprocals) and solves its own row of the panel against it; it keeps the row both unscaled (w = l d,
-//            for its own trailing updates) and scaled (l, what the other rows read);
-//   phase B (one thread per (row, 6-column block) of the trailing matrix): A_rc -= sum_m w_rm l_cm over the panel, 36 FMAs;
-// two workgroup barriers per panel.  Backward substitution L^T x = z runs panel by panel from the bottom (one barrier each):
-// every thread solves the 6x6 unit-triangular system of the panel itself and removes its contribution from its own unknown.
-// Replaces Ceres' dense Cholesky of the reduced system (SchurComplementSolver, reference src/photobundle.cc:743, :829).
-// =====================================================================================================
-constexpr int kSolveBlockedThreads = 256;
-constexpr int kSolveNarrowFree = 8;          // free cameras up to which four waves hold every phase-B item in one round
-__host__ __device__ inline size_t solve_blocked_smem_bytes(int n) {
-  // augmented matrix (n + 1) x (n + 1) | unscaled panel rows (n + 1) x 6 | xs, sc, D2, gcs, gc, dd (n each) | item table
-  const size_t items = (size_t)(n / 6) * (size_t)(n + 1);      // upper bound of the phase-B work items
-  return sizeof(double) * ((size_t)(n + 1) * (n + 1) + 6 * (size_t)(n + 1) + 6 * (size_t)n + 8) + sizeof(uint32_t) * items;
-}
-
-// LOADER: plain loads (the packed sums were produced by an earlier kernel / the all-reduce) or agent-scope loads (they
-// were produced by other workgroups of THIS launch, k_reduce_solve).
-template <bool AGENT>
-__device__ __forceinline__ double packed_load(const double* p) { return AGENT ? load_agent(p) : *p; }
-
-// Candidate camera geometry with the work of one camera spread over 32 consecutive lanes (cam_geom_one is ~400 fp64
-// operations, nine of them divisions, in ONE lane on the serial stretch of every LM iteration).  Every lane repeats the
-// short scalar part (angle, sine / cosine, R); lanes 0..8 then hold one entry of B each, and lanes 0..26 form one entry
-// of dR = R [B_k]x each from three cross-lane reads of B's column k.  Same formulas and operand order as cam_geom_one.
-__device__ inline void cam_geom_spread(const double cam6[6], CamGeom* __restrict__ out, int c, int fixed_slot, int sub) {
-  const double wx = cam6[0], wy = cam6[1], wz = cam6[2];
-  const double theta2 = wx * wx + wy * wy + wz * wz;
-  const bool rod = theta2 > DBL_EPSILON;
-  CamGeom& g = out[c];
-  if (sub < 3) { g.aa[sub] = cam6[sub]; g.t[sub] = cam6[3 + sub]; }
-  if (sub == 3) {
-    g.rodrigues = rod; g.is_free = (c != fixed_slot);
-    g.free_index = (c == fixed_slot) ? -1 : (fixed_slot >= 0 && c > fixed_slot ? c - 1 : c);
-    g.pad = 0;
-  }
-  const int e9 = sub < 9 ? sub : 8;                 // entry of a 3x3 this lane is responsible for (lanes 0..8)
-  const int ei = e9 / 3, ej = e9 - 3 * ei;
-  double Rv, dRv;
-  if (rod) {                                         // (uniform over the 32 lanes of a camera)
-    const double theta = sqrt(theta2);
-    double ct, st;
-    sincos_angle(theta, st, ct);
-    const double ti = 1.0 / theta;
-    const double ax = wx * ti, ay = wy * ti, az = wz * ti;
-    const double oc = 1.0 - ct;
-    const double R[9] = {ct + ax * ax * oc,      ax * ay * oc - az * st, ay * st + ax * az * oc,
-                         az * st + ax * ay * oc, ct + ay * ay * oc,      -ax * st + ay * az * oc,
-                         -ay * st + ax * az * oc, ax * st + ay * az * oc, ct + az * az * oc};
-    if (sub < 3) g.w[sub] = (sub == 0) ? ax : (sub == 1 ? ay : az);
-    if (sub == 4) { g.ct = ct; g.st = st; }
-    Rv = R[0];
-#pragma unroll
-    for (int k = 1; k < 9; ++k) Rv = (e9 == k) ? R[k] : Rv;
-    // lanes 0..8: B[3 i + j] = (w_i w_j + sum_q (R[3 q + i] - delta_iq) Wx[3 q + j]) / theta^2   (i = ei, j = ej)
-    const double W3[3] = {wx, wy, wz};
-    const double Wx[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
-    double wi = W3[0], wj = W3[0];
-#pragma unroll
-    for (int k = 1; k < 3; ++k) { wi = (ei == k) ? W3[k] : wi; wj = (ej == k) ? W3[k] : wj; }
-    double acc = wi * wj;
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      double rqi = R[3 * q], wxqj = Wx[3 * q];
-#pragma unroll
-      for (int k = 1; k < 3; ++k) { rqi = (ei == k) ? R[3 * q + k] : rqi; wxqj = (ej == k) ? Wx[3 * q + k] : wxqj; }
-      acc += (rqi - (ei == q ? 1.0 : 0.0)) * wxqj;
-    }
-    const double Bv = acc / theta2;
-    // lanes 0..26: dR[9 k + 3 i + j] = sum_m R[3 i + m] Bx_k[3 m + j],  Bx_k = [column k of B]x
-    const int s27 = sub < 27 ? sub : 26;
-    const int k = s27 / 9, ij = s27 - 9 * k, i = ij / 3, j = ij - 3 * i;
-    const int base = threadIdx.x & ~31;              // first lane of this camera's group within the wave (32-lane groups)
-    const int lane0 = (base & 63);
-    const double b0 = __shfl(Bv, lane0 + k), b1 = __shfl(Bv, lane0 + 3 + k), b2 = __shfl(Bv, lane0 + 6 + k);
-    const double r0 = __shfl(Rv, lane0 + 3 * i), r1 = __shfl(Rv, lane0 + 3 * i + 1), r2 = __shfl(Rv, lane0 + 3 * i + 2);
-    // column j of Bx = [0 -b2 b1; b2 0 -b0; -b1 b0 0]
-    const double x0 = (j == 0) ? 0.0 : (j == 1 ? -b2 : b1);
-    const double x1 = (j == 0) ? b2 : (j == 1 ? 0.0 : -b0);
-    const double x2 = (j == 0) ? -b1 : (j == 1 ? b0 : 0.0);
-    double a3 = 0.0;
-    a3 += r0 * x0; a3 += r1 * x1; a3 += r2 * x2;
-    dRv = a3;
-  } else {
-    if (sub < 3) g.w[sub] = 0.0;
-    if (sub == 4) { g.ct = 1.0; g.st = 0.0; }
-    const double R[9] = {1, -wz, wy, wz, 1, -wx, -wy, wx, 1};
-    Rv = R[0];
-#pragma unroll
-    for (int k = 1; k < 9; ++k) Rv = (e9 == k) ? R[k] : Rv;
-    const int s27 = sub < 27 ? sub : 26;
-    const int k = s27 / 9, m = s27 - 9 * k;
-    const double e0 = (k == 0), e1 = (k == 1), e2 = (k == 2);
-    const double Ex[9] = {0, -e2, e1, e2, 0, -e0, -e1, e0, 0};
-    dRv = Ex[0];
-#pragma unroll
-    for (int q = 1; q < 9; ++q) dRv = (m == q) ? Ex[q] : dRv;
-  }
-  if (sub < 9) g.R[sub] = Rv;
-  if (sub < 27) g.dR[sub] = dRv;
-}
-
-// T threads: 256 (four waves) up to eight free cameras, 1024 beyond (phase B of a 90 x 90 system has up to 644 work items)
-template <bool AGENT, int T>
-__device__ inline void solve_blocked(SolveParams& p, double* smem, int tid) {
-  const int nf = p.n_free;
-  const int n = 6 * nf;
-  const int ld = n + 1;                       // odd: consecutive rows start in different banks
-  double* A = smem;                           // [(n + 1)][ld] lower triangle + rhs row n
-  double* Wp = A + (size_t)(n + 1) * ld;      // [(n + 1)][6] the current panel's rows, unscaled (l d)
-  double* xs = Wp + (size_t)(n + 1) * 6;      // solution of the scaled system
-  double* sc = xs + n;
-  double* D2 = sc + n;
-  double* gcs = D2 + n;
-  double* gc = gcs + n;
-  double* dd = gc + n;                        // (unused slot kept for alignment of the item table)
-  uint32_t* items = reinterpret_cast<uint32_t*>(dd + n + 2);   // phase-B work items: row | block column << 16
-  __shared__ int s_ok;
-  __shared__ int s_item_start[kMaxFrames + 1];
-  __shared__ double s_cams[6 * kMaxFrames];     // current cameras and their free indices: requested with the first round trip,
-  __shared__ int s_free[kMaxFrames];            // consumed by the epilogue (which then has no global load on its path)
-  const int nT = 36 * p.n_pairs;
-  const double* src = p.packed;
-  unsigned long long ts[6] = {0, 0, 0, 0, 0, 0}, tsa = 0, tsb = 0, tsp[3] = {0, 0, 0}, tsl = 0;
-#define PBA_TS(k) do { if (PBA_PHASE_TIMING) ts[k] = __builtin_amdgcn_s_memtime(); } while (0)
-  PBA_TS(0);
-  // ---- prologue: scale / damp / scatter the packed pair blocks (one global round trip) --------------------------
-  double val0[4];
-#pragma unroll
-  for (int u = 0; u < 4; ++u) { const int e = tid + u * T; val0[u] = (e < nT) ? packed_load<AGENT>(src + e) : 0.0; }
-  // every global load of the prologue is issued before the first one is consumed: ONE round trip
-  const double cam_v = (tid < 6 * p.n_frames) ? p.cams[tid] : 0.0;
-  const int free_v = (tid < p.n_frames) ? p.geom[tid].free_index : -1;
-  static_assert(T >= 6 * kMaxFrames, "one thread per reduced-system row");
-  double du = 0.0, g = 0.0, y0 = 0.0, s_old = 1.0;
-  if (tid < n) {
-    du = packed_load<AGENT>(src + nT + 2 * n + tid);
-    g = packed_load<AGENT>(src + nT + n + tid);
-    y0 = packed_load<AGENT>(src + nT + tid);
-    if (!p.init_scale) s_old = p.sc[tid];
-  }
-  if (tid < 6 * p.n_frames) s_cams[tid] = cam_v;
-  if (tid < p.n_frames) s_free[tid] = free_v;
-  if (tid < n) {
-    const int i = tid;
-    double s;
-    if (p.init_scale) { s = p.jacobi ? 1.0 / (1.0 + sqrt(du)) : 1.0; p.sc[i] = s; p.sc[n + i] = du > 0.0 ? 1.0 : 0.0; }
-    else s = s_old;
-    sc[i] = s;
-    D2[i] = fmin(fmax(s * s * du, p.min_diag), p.max_diag) / p.radius;
-    gc[i] = g;
-    gcs[i] = s * g;
-    A[(size_t)n * ld + i] = s * y0;
-  }
-  if (PBA_PHASE_TIMING) tsp[0] = __builtin_amdgcn_s_memtime();
-  __shared__ unsigned char s_pa[kMaxFrames * (kMaxFrames + 1) / 2], s_pb[kMaxFrames * (kMaxFrames + 1) / 2];
-  for (int pr = tid; pr < p.n_pairs; pr += T) {
-    int a = 0, rem = pr;
-    while (rem >= nf - a) { rem -= nf - a; ++a; }
-    s_pa[pr] = (unsigned char)a; s_pb[pr] = (unsigned char)(a + rem);
-  }
-  // phase-B item table, ordered by block column j = 1 .. nf - 1 (the items of panel k are the suffix j > k): rows 6 j .. n
-  if (tid <= nf) {
-    int start = 0;
-    for (int j = 1; j < tid; ++j) start += n - 6 * j + 1;      // items of block columns 1 .. tid - 1
-    s_item_start[tid] = start;                                    // [j] = first item of block column j (j >= 1)
-  }
-  if (tid == 0) s_ok = 1;
-  __syncthreads();
-  if (PBA_PHASE_TIMING) tsp[1] = __builtin_amdgcn_s_memtime();
-  for (int j = 1; j < nf; ++j) {
-    const int base = s_item_start[j];
-    for (int r = 6 * j + tid; r <= n; r += T) items[base + (r - 6 * j)] = (uint32_t)r | ((uint32_t)j << 16);
-  }
-  for (int e0 = tid; e0 < nT; e0 += 4 * T) {
-    double val[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) { const int e = e0 + u * T; val[u] = (e0 == tid) ? val0[u] : ((e < nT) ? packed_load<AGENT>(src + e) : 0.0); }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int e = e0 + u * T;
-      if (e >= nT) continue;
-      const int pair = e / 36, k = e - pair * 36;
-      const int i = k / 6, j = k - i * 6;
-      const int a = s_pa[pair], b = s_pb[pair];
-      const int r = 6 * a + i, c = 6 * b + j;       // block (a, b), a <= b: entry (r, c) of the upper triangle / diagonal block
-      double v = sc[r] * val[u] * sc[c];
-      if (r == c) v += D2[r];
-      if (a != b) A[(size_t)c * ld + r] = v;        // mirrored into the lower triangle
-      else if (c >= r) A[(size_t)c * ld + r] = v;   // diagonal blocks: the upper triangle is the one that is kept (as in solve_prologue)
-    }
-  }
-  __syncthreads();
-  if (p.S_dbg) {
-    for (int k = tid; k < n * n; k += T) { const int r = k / n, c = k - r * n; p.S_dbg[k] = (r >= c) ? A[(size_t)r * ld + c] : A[(size_t)c * ld + r]; }
-    for (int i = tid; i < n; i += T) p.rhs_dbg[i] = A[(size_t)n * ld + i];
-    __syncthreads();
-  }
-  const int n_items = (nf > 1) ? s_item_start[nf - 1] + (n - 6 * (nf - 1) + 1) : 0;
-  PBA_TS(1);
-  if (!(p.final_pass && !p.init_scale)) {
-    // ---- factorisation S = L D L^T (unit lower L in A, the rhs row ends up as D^-1 L^-1 y) ---------------------------
-    for (int k = 0; k < nf; ++k) {
-      const int c0 = 6 * k;
-      if (PBA_PHASE_TIMING) tsl = __builtin_amdgcn_s_memtime();
-      for (int r = c0 + tid; r <= n; r += T) {
-        double Wd[21], Lt[21];      // diagonal block: unscaled (w = l d) and scaled entries, lower triangle packed i (i + 1) / 2 + m
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-#pragma unroll
-          for (int m = 0; m <= i; ++m) Wd[i * (i + 1) / 2 + m] = A[(size_t)(c0 + i) * ld + c0 + m];
-        double a[6];
-#pragma unroll
-        for (int m = 0; m < 6; ++m) a[m] = A[(size_t)r * ld + c0 + m];
-        double rd[6];
-        bool pd = true;
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-          // column j of the block: w_ij = a_ij - sum_{m<j} w_im l_jm (i >= j), d_j = w_jj, l_ij = w_ij / d_j
-#pragma unroll
-          for (int i = j; i < 6; ++i) {
-            double v = Wd[i * (i + 1) / 2 + j];
-#pragma unroll
-            for (int m = 0; m < j; ++m) v = fma(-Wd[i * (i + 1) / 2 + m], Lt[j * (j + 1) / 2 + m], v);
-            Wd[i * (i + 1) / 2 + j] = v;
-          }
-          const double d = Wd[j * (j + 1) / 2 + j];
-          const bool ok = (d > 0.0) && isfinite(d);
-          pd = pd && ok;
-          rd[j] = fast_rcp(ok ? d : 1.0);
-#pragma unroll
-          for (int i = j + 1; i < 6; ++i) Lt[i * (i + 1) / 2 + j] = Wd[i * (i + 1) / 2 + j] * rd[j];
-        }
-        // this row of the panel: w_j = a_j - sum_{m<j} w_m l_jm, l_j = w_j / d_j  (for the six rows of the diagonal block
-        // this repeats the recurrence above: l = 1 on the diagonal; entries right of it are never read)
-        double w[6], l[6];
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-          double v = a[j];
-#pragma unroll
-          for (int m = 0; m < j; ++m) v = fma(-w[m], Lt[j * (j + 1) / 2 + m], v);
-          w[j] = v;
-          l[j] = v * rd[j];
-        }
-#pragma unroll
-        for (int m = 0; m < 6; ++m) { A[(size_t)r * ld + c0 + m] = l[m]; Wp[(size_t)r * 6 + m] = w[m]; }
-        if (r == c0 && !pd) s_ok = 0;
-      }
-      __syncthreads();
-      if (PBA_PHASE_TIMING) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); tsa += tn - tsl; tsl = tn; }
-      if (k + 1 < nf) {
-        for (int it = s_item_start[k + 1] + tid; it < n_items; it += T) {
-          const uint32_t wd = items[it];
-          const int r = (int)(wd & 0xffffu), j = (int)(wd >> 16);
-          double wr[6], lc[36], acc[6];
-#pragma unroll
-          for (int m = 0; m < 6; ++m) wr[m] = Wp[(size_t)r * 6 + m];
-#pragma unroll
-          for (int e = 0; e < 6; ++e)
-#pragma unroll
-            for (int m = 0; m < 6; ++m) lc[6 * e + m] = A[(size_t)(6 * j + e) * ld + c0 + m];
-#pragma unroll
-          for (int e = 0; e < 6; ++e) acc[e] = A[(size_t)r * ld + 6 * j + e];
-#pragma unroll
-          for (int e = 0; e < 6; ++e)
-#pragma unroll
-            for (int m = 0; m < 6; ++m) acc[e] = fma(-wr[m], lc[6 * e + m], acc[e]);
-#pragma unroll
-          for (int e = 0; e < 6; ++e) A[(size_t)r * ld + 6 * j + e] = acc[e];
-        }
-        __syncthreads();
-        if (PBA_PHASE_TIMING) tsb += __builtin_amdgcn_s_memtime() - tsl;
-      }
-    }
-    PBA_TS(2);
-    // ---- backward substitution L^T x = z, z = row n (already D^-1 L^-1 y), L unit lower --------------------------------
-    {
-      for (int k = nf - 1; k >= 0; --k) {
-        const int c0 = 6 * k;
-        if (tid < c0 + 6) {
-          double L[21], z[6], x[6];
-#pragma unroll
-          for (int i = 0; i < 6; ++i)
-#pragma unroll
-            for (int m = 0; m < i; ++m) L[i * (i + 1) / 2 + m] = A[(size_t)(c0 + i) * ld + c0 + m];
-#pragma unroll
-          for (int m = 0; m < 6; ++m) z[m] = A[(size_t)n * ld + c0 + m];
-#pragma unroll
-          for (int j = 5; j >= 0; --j) {
-            double v = z[j];
-#pragma unroll
-            for (int m = 5; m > j; --m) v = fma(-L[m * (m + 1) / 2 + j], x[m], v);
-            x[j] = v;
-          }
-          if (tid < c0) {
-            double zc = A[(size_t)n * ld + tid];
-#pragma unroll
-            for (int m = 0; m < 6; ++m) zc = fma(-A[(size_t)(c0 + m) * ld + tid], x[m], zc);
-            A[(size_t)n * ld + tid] = zc;
-          } else {
-            double xv = x[0];
-#pragma unroll
-            for (int m = 1; m < 6; ++m) xv = (tid - c0 == m) ? x[m] : xv;
-            xs[tid] = xv;
-          }
-        }
-        __syncthreads();
-      }
-    }
-  } else {
-    for (int i = tid; i < n; i += T) xs[i] = 0.0;
-    __syncthreads();
-  }
-  PBA_TS(3);
-  // ---- epilogue (camera step, candidate cameras + geometry, replicated scalars) -----------------------------------
-  const bool chol_ok = s_ok != 0;
-  if (tid < 6 * p.n_frames && !(p.final_pass && !p.init_scale)) {
-    const int slot = tid / 6, k = tid % 6;
-    const int fa = s_free[slot];
-    double d = 0.0;
-    if (fa >= 0) d = -sc[6 * fa + k] * xs[6 * fa + k];
-    p.delta_c[tid] = d;
-    p.cams_cand[tid] = s_cams[tid] + d;
-  }
-  if (p.geom_cand) {
-    // candidate camera geometry: 32 lanes per camera, eight cameras per pass
-    for (int c = tid / 32; c < p.n_frames; c += T / 32) {
-      double cam6[6];
-      const int fa = s_free[c];
-      for (int k = 0; k < 6; ++k) cam6[k] = s_cams[6 * c + k] + (fa >= 0 ? -sc[6 * fa + k] * xs[6 * fa + k] : 0.0);
-      cam_geom_spread(cam6, p.geom_cand, c, p.fixed_slot, tid & 31);
-    }
-  }
-  PBA_TS(5);
-  if (tid < 64) {
-    double mcc = 0.0, st2 = 0.0, x2 = 0.0, gmax = 0.0, gn2 = 0.0, bad = 0.0;
-    for (int i = tid; i < n; i += 64) {
-      mcc += 0.5 * xs[i] * gcs[i] + 0.5 * D2[i] * xs[i] * xs[i];
-      const double d = sc[i] * xs[i];
-      st2 += d * d;
-      gmax = fmax(gmax, fabs(gc[i]));
-      gn2 += gc[i] * gc[i];
-      if (!isfinite(xs[i])) bad = 1.0;
-    }
-    for (int i = tid; i < 6 * p.n_frames; i += 64) {
-      const int fa = s_free[i / 6];
-      if (fa < 0) continue;
-      const double* live = p.sc + n + 6 * fa;
-      if (live[0] + live[1] + live[2] + live[3] + live[4] + live[5] > 0.0) x2 += s_cams[i] * s_cams[i];
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      mcc += __shfl_xor(mcc, off); st2 += __shfl_xor(st2, off); x2 += __shfl_xor(x2, off);
-      gn2 += __shfl_xor(gn2, off); gmax = fmax(gmax, __shfl_xor(gmax, off)); bad = fmax(bad, __shfl_xor(bad, off));
-    }
-    if (tid == 0) {
-      p.scal[kMccCams] = mcc; p.scal[kStep2Cams] = st2; p.scal[kX2Cams] = x2;
-      p.scal[kGmaxCams] = gmax; p.scal[kGnorm2Cams] = gn2;
-      p.scal[kSolveOk] = (chol_ok && bad == 0.0) ? 1.0 : 0.0;
-      p.scal[kCostLin] = packed_load<AGENT>(p.packed + p.stride - 3);
-      p.scal[kGnorm2Pts] = packed_load<AGENT>(p.packed + p.stride - 2);
-    }
-  }
-  PBA_TS(4);
-  if (PBA_PHASE_TIMING && p.dbg && tid == T - 1)
-    printf("solve_blocked n %d cycles: prologue %llu (first round trip %llu, tables %llu, scatter %llu) factorisation %llu (phase A %llu, phase B %llu) substitution %llu epilogue (geometry lane) %llu (to the end of the geometry %llu)\n",
-           n, ts[1] - ts[0], tsp[0] - ts[0], tsp[1] - tsp[0], ts[1] - tsp[1], ts[2] - ts[1], tsa, tsb, ts[3] - ts[2], ts[4] - ts[3], ts[5] - ts[3]);
-#undef PBA_TS
-}
-
-// The reduced solve as its own launch: multi-rank steps (the all-reduce of the packed sums sits between the reduction
-// and the solve) and the PBA_FUSE_SOLVE=0 diagnostics path.
-template <int T>
-__global__ __launch_bounds__(T) void k_solve_blocked(SolveParams p_in) {
-  SolveParams p = p_in;
-  if (!solve_resolve(p)) return;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  solve_blocked<false, T>(p, reinterpret_cast<double*>(smem), threadIdx.x);
-}
-
-// Reduction of the per-workgroup Schur partials AND the reduced solve in ONE launch (single-rank steps): the workgroups
-// reduce kReduceEntries packed entries each exactly like k_reduce_final (same sums, same order, same bits), publish
-// them with agent-scope (write-through) stores and take a ticket; the LAST workgroup to arrive keeps its first four
-// waves and runs the blocked solve on the packed sums it reads back with agent-scope loads.  Saves a launch (its drain
-// + ramp-up and a cold instruction cache) per LM iteration.
-struct ReduceSolveParams {
-  const double* partial; int32_t n_blocks, stride;
-  const double* block_cost; const int32_t* block_fail; int32_t n_cost_blocks;
-  const double* block_cost_alt; const int32_t* block_fail_alt;
-  double* packed; double* scal;
-  unsigned int* ticket;          // zero between launches
-  unsigned long long* stamp;     // null, or the device time-stamp block (kStamp*)
-  SolveParams so;                // lm / enq_cur / final_pass of the step live here
-};
-
-__global__ __launch_bounds__(1024) void k_reduce_solve(ReduceSolveParams rp) {
-  const LmState* lm = rp.so.lm;
-  const double* block_cost = rp.block_cost;
-  const int32_t* block_fail = rp.block_fail;
-  if (lm) {
-    if (lm->done && !rp.so.final_pass) return;
-    if (rp.so.final_pass && !lm_final_pass_needed(lm)) return;
-    if (lm->cur != rp.so.enq_cur) { block_cost = rp.block_cost_alt; block_fail = rp.block_fail_alt; }
-  }
-  extern __shared__ __attribute__((aligned(16))) char dyn_smem[];      // the solve's matrix (last workgroup only)
-  const unsigned long long t_k0 = PBA_PHASE_TIMING ? __builtin_amdgcn_s_memrealtime() : 0ull;
-  constexpr int EX = kReduceEntries, SUB = 1024 / EX;
-  __shared__ double s_red[SUB][EX + 1];
-  __shared__ int s_f[1024];
-  __shared__ int s_last;
-  const int tid = threadIdx.x;
-  const int ex = tid % EX, sub = tid / EX;
-  const int stride = rp.stride, n_blocks = rp.n_blocks;
-  if ((int)blockIdx.x < (int)gridDim.x - 1) {
-    const int e = blockIdx.x * EX + ex;
-    const bool valid = e < stride;
-    const bool is_max = (e == stride - 3) || (e == stride - 1);
-    double acc = 0.0;
-    if (valid) {
-      for (int b = sub; b < n_blocks; b += 16 * SUB) {
-        double v[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-          const int bb = b + SUB * k;
-          v[k] = (bb < n_blocks) ? rp.partial[(size_t)bb * stride + e] : 0.0;
-        }
-#pragma unroll
-        for (int k = 0; k < 16; ++k) acc = is_max ? fmax(acc, v[k]) : acc + v[k];
-      }
-    }
-    static_assert(EX == 16, "lane = 16 (sub % 4) + ex");
-#pragma unroll
-    for (int off = 16; off <= 32; off <<= 1) {
-      const double o = __shfl_xor(acc, off);
-      acc = is_max ? fmax(acc, o) : acc + o;
-    }
-    if ((tid & 63) < EX) s_red[tid >> 6][ex] = acc;
-    __syncthreads();
-    if (sub == 0 && valid) {
-      double v = s_red[0][ex];
-#pragma unroll
-      for (int w = 1; w < 1024 / 64; ++w) v = is_max ? fmax(v, s_red[w][ex]) : v + s_red[w][ex];
-      if (e < stride - 3) store_agent(rp.packed + e, v);
-      else if (e == stride - 3) rp.scal[kGmaxPts] = v;
-      else if (e == stride - 2) store_agent(rp.packed + stride - 2, v);
-      else rp.scal[kSchurFail] = v;
-    }
-  } else {
-    static_assert(SUB * (EX + 1) >= 1024, "flat view");
-    double* flat = &s_red[0][0];
-    double acc = 0.0; int f = 0;
-    for (int b = tid; b < rp.n_cost_blocks; b += 1024) { acc += block_cost[b]; f |= block_fail[b]; }
-    flat[tid] = acc; s_f[tid] = f;
-    __syncthreads();
-    for (int s = 512; s > 0; s >>= 1) { if (tid < s) { flat[tid] += flat[tid + s]; s_f[tid] |= s_f[tid + s]; } __syncthreads(); }
-    if (tid == 0) { store_agent(rp.packed + stride - 3, flat[0]); rp.scal[kEvalFailLin] = (double)s_f[0]; }
-  }
-  // ---- ticket: the last workgroup to arrive solves ----------------------------------------------------------------
-  // every storing thread waits until its write-through stores have left the CU, then the workgroup takes its ticket
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (tid == 0) {
-    const unsigned t = __hip_atomic_fetch_add(rp.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = (t == gridDim.x - 1) ? 1 : 0;
-  }
-  __syncthreads();
-  if (!s_last) return;
-  const bool wide = rp.so.n_free > kSolveNarrowFree;
-  if (!wide && tid >= kSolveBlockedThreads) return;   // twelve of the sixteen waves leave; barriers below count the remaining four
-  if (tid == 0) *rp.ticket = 0;
-  const unsigned long long t_k1 = PBA_PHASE_TIMING ? __builtin_amdgcn_s_memrealtime() : 0ull;
-  SolveParams so = rp.so;
-  if (so.lm) {
-    if (so.lm->cur != so.enq_cur) {
-      so.cams = so.cams_alt; so.cams_cand = so.cams_cand_alt; so.geom = so.geom_alt;
-      if (so.geom_cand) so.geom_cand = so.geom_cand_alt;
-    }
-    so.radius = so.lm->radius;
-  }
-  if (wide) solve_blocked<true, 1024>(so, reinterpret_cast<double*>(dyn_smem), tid);
-  else solve_blocked<true, kSolveBlockedThreads>(so, reinterpret_cast<double*>(dyn_smem), tid);
-  if (rp.stamp && tid == 0) rp.stamp[kStampEndSolve] = __builtin_amdgcn_s_memrealtime();
-  if (PBA_PHASE_TIMING && rp.so.dbg && tid == 0)
-    printf("k_reduce_solve: last workgroup %d of %d reached the solve %.2f us after its own start, finished it %.2f us later\n", (int)blockIdx.x,
-           (int)gridDim.x, 0.01 * (double)(t_k1 - t_k0), 0.01 * (double)(__builtin_amdgcn_s_memrealtime() - t_k1));
-}
+namespace pba {
 
 // =====================================================================================================
 // back-substitution (SchurEliminator::BackSubstitute): one lane per point
