@@ -199,6 +199,59 @@ def gaussian_blur_f32_5x5(img, sigma):
     return out
 
 
+# ---- image / depth pyramid (reference src/photobundle_pyramid.cc:45-56; BASELINE configs[2]) --------------------------------
+# The reference hands both to OpenCV, which is absent here: restated from OpenCV's documented behaviour in numpy integer /
+# float32 arithmetic (doubly unpinned, like the two GaussianBlur restatements above -- see pba_oracle.h).
+def _reflect101(i, n):
+    i = np.abs(i)
+    return np.where(i >= n, 2 * n - 2 - i, i)
+
+
+def pyr_down_u8(img):
+    """cv::pyrDown(8U) as called at photobundle_pyramid.cc:45-47: separable [1 4 6 4 1] / 16 at the even pixels,
+    BORDER_REFLECT_101, integer sums, (sum + 128) >> 8, destination size ((cols + 1) / 2, (rows + 1) / 2)."""
+    img = np.asarray(img)
+    rows, cols = img.shape
+    w = np.array([1, 4, 6, 4, 1], np.int64)
+    drows, dcols = (rows + 1) // 2, (cols + 1) // 2
+    xs = 2 * np.arange(dcols)[:, None] + np.arange(-2, 3)[None, :]
+    h = (img.astype(np.int64)[:, _reflect101(xs, cols)] * w).sum(-1)                 # [rows, dcols]
+    ys = 2 * np.arange(drows)[:, None] + np.arange(-2, 3)[None, :]
+    v = (h[_reflect101(ys, rows), :] * w[None, :, None]).sum(1)                      # [drows, dcols]
+    return ((v + 128) >> 8).astype(np.uint8)
+
+
+def resize_bilinear_f32(src, drows, dcols):
+    """cv::resize(32F, dsize) with its default INTER_LINEAR, as called on the depth map at photobundle_pyramid.cc:54-56 (the
+    comment there says "nearest neighbor"; the call is bilinear): source coordinate (d + 0.5) * scale - 0.5 in float, the
+    horizontal pass then the vertical one, float arithmetic, border taps clamped."""
+    src = np.asarray(src)
+    rows, cols = src.shape
+    f32 = np.float32
+
+    def axis(n_src, n_dst):
+        f = ((np.arange(n_dst) + 0.5) * (n_src / n_dst) - 0.5).astype(f32)
+        i = np.floor(f).astype(np.int64)
+        a = (f - i.astype(f32)).astype(f32)
+        lo = i < 0
+        a[lo] = 0
+        i[lo] = 0
+        hi = i >= n_src - 1
+        a[hi] = 0
+        i[hi] = n_src - 1
+        return i, a
+    ix, ax = axis(cols, dcols)
+    iy, ay = axis(rows, drows)
+    x1 = np.minimum(ix + 1, cols - 1)
+    y1 = np.minimum(iy + 1, rows - 1)
+    s = src.astype(f32)
+    a0 = (f32(1) - ax).astype(f32)
+    h0 = (s[iy][:, ix] * a0 + s[iy][:, x1] * ax).astype(f32)
+    h1 = (s[y1][:, ix] * a0 + s[y1][:, x1] * ax).astype(f32)
+    b1 = ay[:, None]
+    return (h0 * (f32(1) - b1) + h1 * b1).astype(f32)
+
+
 def sample_linear(planes, y, x):
     planes = np.ascontiguousarray(planes, dtype=np.float32)
     _, rows, cols = planes.shape

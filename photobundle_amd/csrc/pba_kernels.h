@@ -36,6 +36,21 @@
 #define PBA_WALK_ROWWISE 0
 #endif
 
+// How the Jacobian-pass records / the Schur partials leave the CU (A/B switches): 0 nontemporal (records) or plain (partials),
+// 1 agent-scope write-through (`sc1`: the line does not stay dirty in the XCD's L2, so the kernel does not end with its
+// write-back -- MI355X_MICROARCH.md "boundary": + B / 6 TB/s for B dirty bytes)
+#ifndef PBA_REC_SC1
+#define PBA_REC_SC1 1
+#endif
+#ifndef PBA_PARTIAL_SC1
+#define PBA_PARTIAL_SC1 1
+#endif
+// Pair blocks inside a Schur partial: 0 block-major [pair][36] (a thread's 36 stores are 288 B apart from its neighbour's),
+// 1 entry-major [36][n_pairs] (one store instruction writes n_pairs consecutive doubles)
+#ifndef PBA_PARTIAL_T
+#define PBA_PARTIAL_T 1
+#endif
+
 namespace pba {
 
 // Agent-scope relaxed 8-byte store / load (gfx950: write-through `sc1` store, L1-bypassing `sc1` load).  Used for the
@@ -1538,12 +1553,12 @@ void k_sample(SampleParams p_in) {
     if (JAC) {
       // streamed: the records are next read by another kernel (and, the L2 being per XCD, from HBM anyway); keeping
       // them out of the L2 as dirty lines also shortens the write-back at the end of the kernel
-      __builtin_nontemporal_store(rho1 * m11, p.rec + 0 * p.rec_stride + obs);
-      __builtin_nontemporal_store(rho1 * m12, p.rec + 1 * p.rec_stride + obs);
-      __builtin_nontemporal_store(rho1 * m22, p.rec + 2 * p.rec_stride + obs);
-      __builtin_nontemporal_store(rho1 * b1, p.rec + 3 * p.rec_stride + obs);
-      __builtin_nontemporal_store(rho1 * b2, p.rec + 4 * p.rec_stride + obs);
-      __builtin_nontemporal_store(cost_obs, p.rec + 5 * p.rec_stride + obs);
+      const double rv[6] = {rho1 * m11, rho1 * m12, rho1 * m22, rho1 * b1, rho1 * b2, cost_obs};
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        if (PBA_REC_SC1) store_agent(p.rec + k * p.rec_stride + obs, rv[k]);
+        else __builtin_nontemporal_store(rv[k], p.rec + k * p.rec_stride + obs);
+      }
     }
   }
   // deterministic block reductions: butterfly inside each wave, then the waves in order
@@ -2462,7 +2477,10 @@ __global__ __launch_bounds__(kTile, 2) void k_schur(SchurParams p_in) {
         for (int j = 0; j < 6; ++j) acc[6 * i + j] += U[sym6(i, j)];
     }
 #pragma unroll
-    for (int k = 0; k < 36; ++k) out[pair * 36 + k] = acc[k];
+    for (int k = 0; k < 36; ++k) {
+      double* dst = PBA_PARTIAL_T ? out + k * p.n_pairs + pair : out + pair * 36 + k;
+      if (PBA_PARTIAL_SC1) store_agent(dst, acc[k]); else *dst = acc[k];
+    }
   }
   lds_barrier();
   // block reductions of the point-gradient statistics (butterfly per wave, then the two waves in order)

@@ -38,7 +38,7 @@ inline void solve_tables(int nf, uint32_t* tab) {
 __device__ __forceinline__ int packed_dest(int e, int nf, int n_pairs) {
   const int n = 6 * nf, nT = 36 * n_pairs;
   if (e < nT) {
-    const int pair = e / 36, k = e - 36 * pair, i = k / 6, j = k - 6 * i;
+    const int pair = PBA_PARTIAL_T ? e % n_pairs : e / 36, k = PBA_PARTIAL_T ? e / n_pairs : e - 36 * pair, i = k / 6, j = k - 6 * i;
     int a = 0, rem = pair;
     while (rem >= nf - a) { rem -= nf - a; ++a; }      // pairs enumerated row by row: (a, a..nf-1)
     const int b = a + rem;

@@ -1,5 +1,6 @@
 // calibration.h -- pinhole stereo calibration; call-compatible with the reference's Calibration
-// (reference src/calibration.h:10-84): fx()/fy()/cx()/cy()/b()/K()/baseline()/project()/setParameters()/pyrDown().
+// (reference src/calibration.h:10-84): fx()/fy()/cx()/cy()/b()/K()/baseline()/project()/triangulate()/setParameters()/
+// scale()/pyrDown().
 //
 // Representation differs from the reference (which keeps only an Eigen 3x3): the four intrinsics and the baseline are
 // the source of truth and the matrix view is rebuilt on mutation through the accessors below.
@@ -32,8 +33,18 @@ class Calibration {
   // u = fx X/Z + cx, v = fy Y/Z + cy, for any scalar type with * / + (the device kernels use the same order)
   template <typename Scalar>
   void project(const Scalar* X, Scalar& u, Scalar& v) const;
+  template <typename Scalar>
+  void project(const Scalar* X, Scalar* uv) const { project(X, uv[0], uv[1]); }
   // homogeneous form used by the front-end: (K X) / (K X)_z
   Vec2 project(const Vec3& X) const;
+
+  // (u, v, disparity) -> camera-frame point: depth from the stereo relation z = b fx / d, then the pinhole back-projection
+  // (reference src/calibration.h:46-53)
+  template <typename UvdType>
+  Vec3 triangulate(const UvdType& uvd) const;
+
+  // image shrunk by a factor s > 1: the intrinsics divide by s, the baseline multiplies (reference :64-70; s <= 1 is ignored there too)
+  void scale(double s);
 
   // one pyramid level down: focal lengths and principal point halve, the baseline doubles
   Calibration pyrDown() const;
@@ -75,6 +86,25 @@ inline Vec2 Calibration::project(const Vec3& X) const {
   uv[0] = inv_w * h[0];
   uv[1] = inv_w * h[1];
   return uv;
+}
+
+template <typename UvdType>
+inline Vec3 Calibration::triangulate(const UvdType& uvd) const {
+  const double depth = (b() * fx()) * (1.0 / uvd[2]);
+  Vec3 X;
+  X[0] = (uvd[0] - cx()) * depth / fx();
+  X[1] = (uvd[1] - cy()) * depth / fy();
+  X[2] = depth;
+  return X;
+}
+
+inline void Calibration::scale(double s) {
+  if (!(s > 1.0)) return;
+  const double inv = 1.0 / s;
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) _K(r, c) = _K(r, c) * inv;
+  _K(2, 2) = 1.0;
+  _baseline = _baseline * s;
 }
 
 inline Calibration Calibration::pyrDown() const {

@@ -5,6 +5,9 @@
 // problem the reference hands to Ceres (reference :764-876) and solves it through the C-ABI of include/pba.h.
 #include "photobundle.h"
 
+#include <ostream>
+#include <sstream>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -166,6 +169,17 @@ PhotometricBundleAdjustment::Options::Options(const utils::ConfigFile& cf)
       numThreads(cf.get<int>("numThreads", -1)),
       verbose((bool)cf.get<int>("verbose", 1)),
       device(cf.get<int>("device", 0)) {}
+
+std::ostream& operator<<(std::ostream& os, const PhotometricBundleAdjustment::Options& o) {
+  using DT = PhotometricBundleAdjustment::Options::DescriptorType;
+  const char* dt = o.descriptorType == DT::BitPlanes ? "BitPlanes" : (o.descriptorType == DT::IntensityAndGradient ? "IntensityAndGradient" : "Intensity");
+  os << "maxNumPoints = " << o.maxNumPoints << "\nnonMaxSuppRadius = " << o.nonMaxSuppRadius << "\nmaskBlockRadius = " << o.maskBlockRadius
+     << "\nmaxFrameDistance = " << o.maxFrameDistance << "\nminScore = " << o.minScore << "\nminValidDepth = " << o.minValidDepth
+     << "\nmaxValidDepth = " << o.maxValidDepth << "\nslidingWindowSize = " << o.slidingWindowSize << "\npatchRadius = " << o.patchRadius
+     << "\ndoGaussianWeighting = " << (o.doGaussianWeighting ? 1 : 0) << "\nrobustThreshold = " << o.robustThreshold
+     << "\ndescriptorType = " << dt << "\nnumThreads = " << o.numThreads << "\nverbose = " << (o.verbose ? 1 : 0) << "\ndevice = " << o.device << "\n";
+  return os;
+}
 
 bool PhotometricBundleAdjustment::Result::Writer::add(const Result&) {
   std::fprintf(stderr, "Result::Writer needs cereal (dead code in the reference's default build too)\n");
@@ -609,6 +623,32 @@ PhotometricBundleAdjustment::ScenePointPointerList PhotometricBundleAdjustment::
 
 // C hook (tests bind it through ctypes): the channel images DescriptorFrame::Create builds on the host
 // (imgproc.h), [C][rows*cols]; kind 1 = IntensityAndGradient, 2 = BitPlanes; returns C
+// test hook (tests/test_host_api_cpu.py): the small API pieces of the reference headers that nothing else in the library calls
+extern "C" int pb_api_probe(char* text, int cap, double* out8) {
+  PhotometricBundleAdjustment::Options o;
+  o.patchRadius = 3;
+  o.descriptorType = PhotometricBundleAdjustment::Options::DescriptorType::BitPlanes;
+  std::ostringstream ss;
+  ss << o;
+  const std::string t = ss.str();
+  if ((int)t.size() + 1 > cap) return -1;
+  std::memcpy(text, t.c_str(), t.size() + 1);
+  Mat33 K = Mat33::Identity();
+  K(0, 0) = 718.856; K(1, 1) = 718.856; K(0, 2) = 607.1928; K(1, 2) = 185.2157;
+  Calibration c(K, 0.5372);
+  const double uvd[3] = {700.0, 100.0, 12.5};
+  const Vec3 X = c.triangulate(uvd);
+  out8[0] = X[0]; out8[1] = X[1]; out8[2] = X[2];
+  const double Xp[3] = {X[0], X[1], X[2]};
+  double uv[2];
+  c.project(Xp, uv);
+  out8[3] = uv[0]; out8[4] = uv[1];
+  c.scale(2.0);
+  out8[5] = c.fx(); out8[6] = c.cx(); out8[7] = c.b();
+  c.scale(0.5);      // ignored (s <= 1)
+  return (c.fx() == out8[5]) ? 0 : -2;
+}
+
 extern "C" int pb_descriptor_channels(const uint8_t* img, int rows, int cols, int kind, float* out) {
   std::vector<Image_<float>> ch;
   const size_t n = (size_t)rows * cols;

@@ -94,6 +94,11 @@ class PhotometricBundleAdjustment {
 
     Options() {}
     Options(const utils::ConfigFile& cf);
+
+   private:
+    // declared by the reference (src/photobundle.h:81-82) and never defined there: prints the settings as ConfigFile lines
+    // (key = value, the keys Options(const ConfigFile&) reads), so that the output of one run configures the next
+    friend std::ostream& operator<<(std::ostream&, const Options&);
   };
 
   // ---- what an optimisation reports ----

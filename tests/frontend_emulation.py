@@ -204,44 +204,8 @@ def _reflect101(i, n):
     return np.where(i >= n, 2 * n - 2 - i, i)
 
 
-def pyr_down_u8(img):
-    """cv::pyrDown for u8: 5x5 binomial, BORDER_REFLECT_101, (sum + 128) >> 8, size ((cols+1)/2, (rows+1)/2)."""
-    rows, cols = img.shape
-    w = np.array([1, 4, 6, 4, 1], np.int64)
-    drows, dcols = (rows + 1) // 2, (cols + 1) // 2
-    xs = 2 * np.arange(dcols)[:, None] + np.arange(-2, 3)[None, :]
-    h = (img.astype(np.int64)[:, _reflect101(xs, cols)] * w).sum(-1)                 # [rows, dcols]
-    ys = 2 * np.arange(drows)[:, None] + np.arange(-2, 3)[None, :]
-    v = (h[_reflect101(ys, rows), :] * w[None, :, None]).sum(1)                      # [drows, dcols]
-    return ((v + 128) >> 8).astype(np.uint8)
-
-
-def resize_bilinear_f32(src, drows, dcols):
-    """cv::resize INTER_LINEAR for float32 (horizontal pass then vertical, float arithmetic)."""
-    rows, cols = src.shape
-    f32 = np.float32
-
-    def axis(n_src, n_dst):
-        f = ((np.arange(n_dst) + 0.5) * (n_src / n_dst) - 0.5).astype(f32)
-        i = np.floor(f).astype(np.int64)
-        a = (f - i.astype(f32)).astype(f32)
-        lo = i < 0
-        a[lo] = 0
-        i[lo] = 0
-        hi = i >= n_src - 1
-        a[hi] = 0
-        i[hi] = n_src - 1
-        return i, a
-    ix, ax = axis(cols, dcols)
-    iy, ay = axis(rows, drows)
-    x1 = np.minimum(ix + 1, cols - 1)
-    y1 = np.minimum(iy + 1, rows - 1)
-    s = src.astype(f32)
-    a0 = (f32(1) - ax).astype(f32)
-    h0 = (s[iy][:, ix] * a0 + s[iy][:, x1] * ax).astype(f32)
-    h1 = (s[y1][:, ix] * a0 + s[y1][:, x1] * ax).astype(f32)
-    b1 = ay[:, None]
-    return (h0 * (f32(1) - b1) + h1 * b1).astype(f32)
+# cv::pyrDown / cv::resize restatements live with the rest of the oracle (oracle/oracle.py: pyr_down_u8, resize_bilinear_f32)
+from oracle.oracle import pyr_down_u8, resize_bilinear_f32  # noqa: E402,F401
 
 
 class PyramidEmulator:

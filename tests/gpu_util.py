@@ -125,6 +125,28 @@ def pose_rmse(a, b):
     return float(np.sqrt(np.mean(d[:, :3] ** 2))), float(np.sqrt(np.mean(d[:, 3:] ** 2)))
 
 
+def camera_centres(cams):
+    """World positions C = -R(w)^T t of world->camera parameters [w, t] (reference photobundle.cc:774-778: the optimised
+    blocks are the INVERSES of the world poses)."""
+    from scipy.spatial.transform import Rotation
+    R = Rotation.from_rotvec(cams[:, :3]).as_matrix()
+    return -np.einsum("nji,nj->ni", R, cams[:, 3:])
+
+
+def pose_rmse_gauge_fixed(a, b):
+    """Pose distance with the window's FREE GAUGE taken out.  Only camera 0 is constant (photobundle.cc:809-813) and the points
+    are free, so rotation and translation of the world are pinned by camera 0 but its SCALE about camera 0's centre is not
+    observable: (C_i - C_0, X_p - C_0) -> s (C_i - C_0, X_p - C_0) leaves every residual unchanged.  Two solves that end in
+    the same optimum up to that gauge differ by a scale of the camera centres only.  Returns (rotation RMSE [rad] -- rotations
+    are gauge-invariant --, RMSE of the camera centres [m] after the least-squares scale s* of `a` onto `b`, s* - 1), over
+    the free cameras."""
+    Ca, Cb = camera_centres(a), camera_centres(b)
+    da, db = Ca[1:] - Ca[0], Cb[1:] - Cb[0]
+    s = float((da * db).sum() / (da * da).sum())
+    rot = float(np.sqrt(np.mean((a[1:, :3] - b[1:, :3]) ** 2)))
+    return rot, float(np.sqrt(np.mean((s * da - db) ** 2))), s - 1.0
+
+
 def referee_parity(q, twins, res, tag):
     """Long solves of this problem are CHAOTIC in the rounding: the objective is piecewise bilinear in u8 images and the
     window has a free scale gauge (only camera 0 is constant, photobundle.cc:809-813), so double-precision evaluations of
@@ -135,7 +157,8 @@ def referee_parity(q, twins, res, tag):
     runs of the oracle (dual numbers, analytic Jacobian), `res` is the engine.  Per iteration i:
       * engine-to-referee distance <= 2 x the largest twin-to-referee distance seen up to iteration i + 1 (an amplifier
         of ~100x per iteration makes "one iteration later" the natural granularity), with a floor of 1e-9 (the trace
-        tolerance of every other parity test) for the first 10 iterations (their trace length) and 1e-5 afterwards.
+        tolerance of every other parity test) for the first 10 iterations (their trace length) and 1e-7 afterwards (r4;
+        it was 1e-5 -- a floor that would have hidden a 1e-6 defect in a late iteration).
         The later floor is for a DISCRETE event the twins almost never see: sample positions are rounded to float
         (sample_eigen.h:117-118), so a parameter vector that differs by 1e-12 from the referee's now and then rounds ONE
         of ~10^5 - 10^7 positions to the neighbouring float; the cost then differs by ~1e-9 and the gap grows from there.
@@ -164,7 +187,7 @@ def referee_parity(q, twins, res, tag):
         same = same and max(run, d_en[i]) <= 1e-6
         if same:
             assert gi[i]["step_is_successful"] == qi[i]["step_is_successful"] and gi[i]["step_is_valid"] == qi[i]["step_is_valid"], (tag, i)
-        floor = 1e-9 if i < 10 else 1e-5
+        floor = 1e-9 if i < 10 else 1e-7
         assert d_en[i] <= max(floor, 2.0 * run), (tag, i, d_en[i], d_tw[i], run, digits(d_en), digits(d_tw))
         worst = max(worst, d_en[i] / max(floor, run))
         if tight == i and d_en[i] <= 1e-9:
@@ -177,6 +200,12 @@ def referee_parity(q, twins, res, tag):
     fc_en = abs(res["final_cost"] - fq) / fq
     pose_tw = [max(pose_rmse(t["cams"], q["cams"])[k] for t in twins) for k in (0, 1)]
     pose_en = pose_rmse(res["cams"], q["cams"])
+    # the same distances in a gauge-fixed metric (scale of the camera centres about camera 0 removed)
+    gf_en = pose_rmse_gauge_fixed(res["cams"], q["cams"])
+    gf_tw = [pose_rmse_gauge_fixed(t["cams"], q["cams"]) for t in twins]
+    print("%s: GAUGE-FIXED pose distance to the referee at convergence (scale about camera 0 removed): engine rot %.2e rad, centres %.2e m "
+          "(scale drift %.2e); twins rot %s, centres %s m (scale drift %s)"
+          % (tag, gf_en[0], gf_en[1], gf_en[2], ["%.2e" % g[0] for g in gf_tw], ["%.2e" % g[1] for g in gf_tw], ["%.1e" % g[2] for g in gf_tw]))
     print("%s: digits of agreement with the referee per iteration: engine %s | twins %s" % (tag, digits(d_en), digits(d_tw)))
     print("%s: iterations referee %d / twins %s / engine %d; within 1e-9 of the referee: engine %d iterations, twins %d; largest "
           "engine / twin distance ratio %.2f; final cost engine %.8e referee %.8e twins %s (relative distance engine %.2e, twins %.2e); "
@@ -187,6 +216,9 @@ def referee_parity(q, twins, res, tag):
     assert tight >= min(tw_tight, n, 10) - 1, (tag, tight, tw_tight)  # over the first 10 iterations the engine stays tight about as long as the double oracle does
     assert fc_en <= max(1e-5, 2.0 * fc_tw) or res["final_cost"] <= min([fq] + [t["final_cost"] for t in twins])
     assert pose_en[0] <= 2.0 * pose_tw[0] + 1e-5 and pose_en[1] <= 2.0 * pose_tw[1] + 1e-5
+    # gauge-fixed: no farther from the referee than twice the worst double-precision run of the oracle itself (+ the bar)
+    assert gf_en[1] <= 2.0 * max(g[1] for g in gf_tw) + 1e-5, (tag, gf_en, gf_tw)
+    referee_parity.last_gauge_fixed = (gf_en, gf_tw)
     return tight
 
 

@@ -50,6 +50,7 @@ def _host_channels(L, img, kind):
 @pytest.mark.parametrize("kind", ["IntensityAndGradient", "BitPlanes"])
 @pytest.mark.parametrize("size", [(37, 53), (376, 1241), (16, 16)])
 def test_descriptor_channels_on_device_equal_imgproc_h(kind, size):
+    from oracle import oracle
     from photobundle_amd import imgproc
     L = _host()
     rng = np.random.default_rng(11 + size[0])
@@ -57,6 +58,12 @@ def test_descriptor_channels_on_device_equal_imgproc_h(kind, size):
     ref = _host_channels(L, img, kind)
     assert np.array_equal(ref, imgproc.descriptor_channels(img, kind))       # the numpy mirror bench.py uses
     planes = imgproc.channel_planes(ref).reshape(ref.shape[0], 3, *size)
+    # ... and the ORACLE's DescriptorFrame::Create (oracle/pba_oracle.cpp: census imgproc.cc:126-197, the two GaussianBlur
+    # restatements, imgradient imgproc.cc:27-95): the device channels and their gradient planes are checked against it
+    # directly below, at every size incl. 376 x 1241, not only through the product's own host code
+    o_ch = oracle.descriptor_channels(img, kind)
+    o_planes = oracle.channel_planes(o_ch).reshape(o_ch.shape[0], 3, *size)
+    assert np.array_equal(o_ch, ref) and np.array_equal(o_planes, planes)
     c = KINDS[kind][1]
     dev, via_host = _engine(size, channels=c), _engine(size, channels=c)
     dev.set_frame_descriptor(1, img, kind)
@@ -64,6 +71,8 @@ def test_descriptor_channels_on_device_equal_imgproc_h(kind, size):
     assert np.array_equal(dev.get_frame_channels(1), ref) and np.array_equal(via_host.get_frame_channels(1), ref)   # what the class's front-end reads back
     for k in range(c):
         got = dev.get_frame_channel(1, k)
+        assert np.array_equal(got[0], o_ch[k]), (kind, k, np.abs(got[0] - o_ch[k]).max())      # device vs oracle
+        assert np.array_equal(got, o_planes[k])
         assert np.array_equal(got[0], ref[k]), (kind, k, np.abs(got[0] - ref[k]).max())
         assert np.array_equal(got, planes[k])
         assert np.array_equal(got, via_host.get_frame_channel(1, k))
@@ -71,8 +80,8 @@ def test_descriptor_channels_on_device_equal_imgproc_h(kind, size):
 
 
 def test_bitplanes_without_smoothing():
-    """sigma <= 0 skips the 3x3 / 5x5 smoothing (imgproc.h:124-141 with sigma_ct / sigma_bp <= 0)."""
-    from photobundle_amd import imgproc
+    """sigma <= 0 skips the 3x3 / 5x5 smoothing (imgproc.h:124-141 with sigma_ct / sigma_bp <= 0).  Against the oracle's pieces."""
+    from oracle import oracle as imgproc
     size = (41, 67)
     img = _image(np.random.default_rng(3), size)
     e = _engine(size, channels=8)
@@ -107,6 +116,7 @@ def test_descriptor_producer_argument_checks():
 def test_pyr_down_on_device_equals_host(size):
     """Three levels, level to level on the device: every level's u8 image equals pyrDownU8 of the previous one, and the
     planes the coarse engine samples equal those of an engine that was handed the host's image."""
+    from oracle import oracle
     L = _host()
     img = _image(np.random.default_rng(size[1]), size)
     sizes = [size]
@@ -119,6 +129,8 @@ def test_pyr_down_on_device_equals_host(size):
         want = np.empty(sizes[lvl], np.uint8)
         L.pb_pyr_down_u8(prev.ctypes.data, prev.shape[0], prev.shape[1], want.ctypes.data)
         got = engines[lvl].set_frame_pyr_down(0, engines[lvl - 1], 1 if lvl == 1 else 0)
+        assert np.array_equal(got, oracle.pyr_down_u8(prev)), lvl            # device vs the oracle's cv::pyrDown restatement
+        assert np.array_equal(engines[lvl].get_frame_planes(0), oracle.planes_from_u8(got))   # and the planes the level samples
         assert np.array_equal(got, want), (lvl, np.abs(got.astype(int) - want).max())
         ref = _engine(sizes[lvl])
         ref.set_frame(0, want)

@@ -1,0 +1,27 @@
+"""CPU checks of the small pieces of the reference's public headers that the drop-in host library (photobundle_amd/host) carries
+for source compatibility: operator<<(std::ostream&, const Options&) (reference src/photobundle.h:81-82, declared there and never
+defined), Calibration::triangulate / scale / project(ptr, ptr) (reference src/calibration.h:40-70)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_options_stream_and_calibration_helpers():
+    L = C.CDLL(os.path.join(ROOT, "photobundle_amd", "libphotobundle.so"))
+    buf = C.create_string_buffer(2048)
+    out = np.zeros(8)
+    assert L.pb_api_probe(buf, 2048, out.ctypes.data_as(C.c_void_p)) == 0
+    kv = dict(l.split(" = ") for l in buf.value.decode().strip().split("\n"))
+    # the keys Options(const ConfigFile&) reads (reference src/photobundle.cc:88-103) with the defaults of the reference
+    assert kv["maxNumPoints"] == "4096" and kv["slidingWindowSize"] == "5" and kv["patchRadius"] == "3"
+    assert kv["descriptorType"] == "BitPlanes" and kv["minScore"] == "0.75" and kv["robustThreshold"] == "0.05"
+    assert set(kv) >= {"nonMaxSuppRadius", "maskBlockRadius", "maxFrameDistance", "minValidDepth", "maxValidDepth",
+                       "doGaussianWeighting", "numThreads", "verbose"}
+    fx, fy, cx, cy, b = 718.856, 718.856, 607.1928, 185.2157, 0.5372
+    z = b * fx / 12.5
+    assert np.allclose(out[:3], [(700.0 - cx) * z / fx, (100.0 - cy) * z / fy, z], rtol=1e-15)
+    assert np.allclose(out[3:5], [700.0, 100.0], rtol=1e-13)           # project(triangulate(u, v, d)) = (u, v)
+    assert np.allclose(out[5:], [fx / 2, cx / 2, 2 * b], rtol=1e-15)   # scale(2): K / 2, baseline x 2; scale(0.5) is ignored
