@@ -7,16 +7,21 @@
 One "step" = one trust-region LM iteration of the reference's solve (reference src/photobundle.cc:829): damped Schur
 solve of the stored linearisation + candidate cost pass, and -- when the step is accepted -- the Jacobian pass at the
 new point.  Workload at N = 1: BASELINE.json configs[1] (8-frame window, 50k points, 5x5 patch, single level, synthetic
-KITTI-shaped frames).  N > 1 is WEAK scaling: every rank owns 50k points of one N*50k-point window, all
-cameras/frames replicated, one RCCL all-reduce of the reduced camera system per step; `value` is the whole-job rate
-in 50k-point-window LM iterations per second (= N * iterations/sec), `residuals_per_sec` is the same thing in scalar
-residual evaluations.  Inputs are resident in HBM before the timed region.
+KITTI-shaped frames).  N > 1 is WEAK scaling: every rank owns 50k points of ONE N*50k-point window, all
+cameras/frames replicated, the reduced camera system and the step scalars exchanged once per step; `value` is the
+LM iterations per second OF THAT WINDOW (it is NOT multiplied by N: an exchange that doubled the step time would halve
+it), `residuals_per_sec` -- scalar residual evaluations of all ranks per second -- is the quantity that grows with N.
+With N > 1 the same launch also appends a `strong` record: BASELINE.json configs[3] (ONE 16-frame x 200k-point window)
+solved by rank 0 alone and then point-sharded over the N ranks, time per LM iteration of each and their ratio
+(PBA_BENCH_STRONG=0 skips it).  Inputs are resident in HBM before the timed region.
 
---config 3 is BASELINE.json configs[3] as a STRONG-scaling workload: ONE 16-frame x 200k-point window whose points are
-sharded over the N ranks (`value` = LM iterations per second of that one window, not multiplied by N); --config 4 is
-configs[4] (11x11 patches + Huber 0.05, weak scaling like configs[1]).
+--config 3 is configs[3] as the STRONG-scaling workload itself (`value` = LM iterations per second of the one window);
+`--config 3 --emulate-rank-of R` runs, on ONE GPU, the full window AND one rank's 1/R shard through the multi-rank code
+path (peer exchange at world = 1) and prints the projected R-GPU speed-up; --config 4 is configs[4] (11x11 patches +
+Huber 0.05, weak scaling like configs[1]).
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -43,6 +48,16 @@ def algorithmic_bytes(radius, n_bar, channels=1):
     return dict(sample_jac=sample_jac, schur=schur, b_jac=b_jac, b_cost=b_cost, b_res=b_res)
 
 
+def kernel_source_id():
+    """sha1 (12 hex digits) over the device sources: ties profiles/traffic.json (tools/collect_profiles.py stores the id of the
+    build its counters were taken on) to the build that prints the line."""
+    h = hashlib.sha1()
+    for f in ("pba_kernels.h", "pba_solve.h", "pba_device.h", "pba_engine.hip"):
+        with open(os.path.join(ROOT, "photobundle_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:12]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -67,6 +82,13 @@ def main():
     ap.add_argument("--repeats", type=int, default=25,
                     help="the K-step solve is timed this many times (each bracketed by barrier + synchronize, state reset outside "
                          "the bracket); `value` / `ms_per_step` come from the MEDIAN repeat, min / max are reported beside it")
+    ap.add_argument("--emulate-rank-of", type=int, default=0,
+                    help="with --config 3 on ONE GPU: time the full window (single-rank path), then one rank's 1/R shard through the "
+                         "multi-rank code path (PBA_FORCE_MULTI: reduction -> mailbox -> solve with the peer wait, k_decide with the peer "
+                         "wait) and print `strong_projection` (t_full / (t_rank + assumed xGMI latency of the two exchanges))")
+    ap.add_argument("--xgmi-exchange-us", type=float, default=5.0,
+                    help="--emulate-rank-of: latency ASSUMED per cross-device exchange on top of the measured single-device path "
+                         "(flag write -> remote poll -> R mailbox reads of <= 35 KB over xGMI); no multi-GPU box was available to measure it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-points", type=int, default=50000, help="points of the bounded CPU-baseline sample")
     ap.add_argument("--cpu-steps", type=int, default=20)
@@ -78,6 +100,9 @@ def main():
         if getattr(args, k) is None:
             setattr(args, k, v)
     strong = args.config == 3
+    emulate = args.emulate_rank_of if (strong and args.gpus == 1) else 0
+    if emulate:
+        args.no_cpu_baseline = True
 
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -313,7 +338,7 @@ def main():
     n_jac, n_cost, n_res = tot["n_jac"], tot["n_cost"], tot["n_res"]
     n_obs_global = res["num_residual_blocks"]
     iters_per_sec = iters_done / elapsed
-    value = iters_per_sec if strong else world * iters_per_sec
+    value = iters_per_sec          # LM iterations per second of the ONE window the ranks solve together (never x N)
     residuals_per_sec = n_obs_global * P * (n_jac + n_cost) / elapsed   # residuals actually evaluated by the engine
 
     ab = algorithmic_bytes(prob.radius, n_bar, args.channels)
@@ -345,18 +370,27 @@ def main():
     # VALU instruction count, which gives the issue floor: wave instructions x 4 cycles / (1024 SIMDs x 2.4 GHz)
     traffic = valu_insts = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    traffic_sha = traffic_src_id = None
+    src_id = kernel_source_id()
     if os.path.exists(tpath) and default_shape and args.config == 1:
         try:
-            tj = json.load(open(tpath))
+            raw = open(tpath, "rb").read()
+            traffic_sha = hashlib.sha1(raw).hexdigest()[:12]
+            tj = json.loads(raw)
             traffic = tj.get(dom.split(" ")[0])
             valu_insts = tj.get(dom.split(" ")[0] + "_valu_insts")
+            traffic_src_id = tj.get("kernel_source_id")
         except Exception:
             traffic = valu_insts = None
     roofline = {
         "bound": "hbm", "kernel": dom, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
         "frac": achieved / HBM_PEAK, "traffic": traffic,
-        "traffic_source": ("profiles/traffic.json (committed rocprofv3 --pmc passes of this workload; NOT measured in this run)"
+        "traffic_source": ("profiles/traffic.json sha1 %s (committed rocprofv3 --pmc passes of this workload; NOT measured in this run); "
+                           "counters taken on kernel sources %s, this build is %s: %s"
+                           % (traffic_sha, traffic_src_id, src_id, "MATCH" if traffic_src_id == src_id else "STALE counter file")
                            if traffic else None),
+        "traffic_matches_build": (traffic_src_id == src_id) if traffic else None,
+        "kernel_source_id": src_id,
         "traffic_frac": (traffic / avg_s / HBM_PEAK) if (traffic and avg_s > 0) else None,
         "valu_floor_us": (valu_insts * 4.0 / (1024 * 2.4e9) * 1e6) if valu_insts else None,
         "avg_launch_us": avg_s * 1e6, "timing_source": timing_source, "algorithmic_bytes_per_obs": bytes_per_obs,
@@ -372,7 +406,8 @@ def main():
     out = {
         "metric": "LM iters/sec + residuals/sec, 8-frame KITTI window, 50k pts, 5x5 patch",
         "value": value, "unit": ("LM iters/s of the one %d-point window (strong scaling)" % args.points) if strong
-                                 else "LM iters/s (%dk-point windows; x N under weak scaling)" % (args.points // 1000),
+                                 else "LM iters/s of the one %d-point window (%dk points per GPU: weak scaling; not multiplied by N)"
+                                      % (args.points * world, args.points // 1000),
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(1, iters_done),
         "repeats": len(times), "ms_per_step_min": 1e3 * times[0] / max(1, iters_done),
         "ms_per_step_max": 1e3 * times[-1] / max(1, iters_done), "timed_region_ms": 1e3 * sum(times),
@@ -399,6 +434,113 @@ def main():
         "device_copy_GBps": copy_gbps,
         "gen_seconds": t_gen,
     }
+
+    def measure(eng_, prob_, steps, repeats, collective):
+        """Median seconds per LM iteration of `repeats` timed solves of `steps` iterations on another engine / window
+        (same bracket as the headline: barrier + synchronize on both sides, state reset outside)."""
+        def reset():
+            eng_.set_problem(prob_.xyz, prob_.desc, prob_.obs_point, prob_.obs_slot, prob_.weights)
+            eng_.set_cameras(prob_.cams, prob_.fixed_slot)
+        eng_.solve(opts(min(steps, 5)))
+        ts = []
+        for _ in range(max(1, repeats)):
+            reset()
+            torch.cuda.synchronize()
+            if collective and dist is not None:
+                dist.barrier()
+            t1_ = time.perf_counter()
+            raw_ = eng_.solve_raw(opts(steps), buffers=raw_buffers)
+            torch.cuda.synchronize()
+            if collective and dist is not None:
+                dist.barrier()
+            dt = time.perf_counter() - t1_
+            n_it = len(Engine.unpack_solve(*raw_)["iterations"]) - 1
+            if collective and dist is not None:
+                t_ = torch.tensor([dt], dtype=torch.float64, device=ctl)
+                dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+                dt = float(t_.item())
+            ts.append(dt / max(1, n_it))
+        ts.sort()
+        return ts[len(ts) // 2]
+
+    def plain_engine(prob_):
+        _, rws, cls = prob_.images.shape
+        e_ = Engine(rws, cls, prob_.K, prob_.radius, prob_.n_frames, huber=prob_.huber, device=local_rank)
+        e_.load(prob_)
+        return e_
+
+    # ---- strong-scaling record of the SAME launch (N > 1, weak-scaling run): configs[3] by rank 0 alone, then sharded over the N ranks
+    if world > 1 and not strong and os.environ.get("PBA_BENCH_STRONG", "1") != "0":
+        try:
+            n3 = int(os.environ.get("PBA_BENCH_STRONG_POINTS", "200000"))      # (tests shrink the window)
+            whole3 = synthetic.make_window(n_frames=16, n_points=n3, radius=2, huber=0.0, dense_births=(0, 8))
+            t1_full = None
+            if rank == 0:
+                e1 = plain_engine(whole3)
+                t1_full = measure(e1, whole3, 20, 5, collective=False)
+                e1.close()
+            dist.barrier()
+            sh3 = whole3.shard(rank, world)
+            del whole3
+            e3 = plain_engine(sh3)
+            if backend == "nccl":
+                uid3 = torch.zeros(128, dtype=torch.uint8, device=ctl)
+                if rank == 0:
+                    uid3.copy_(torch.frombuffer(bytearray(Engine.comm_unique_id()), dtype=torch.uint8))
+                dist.broadcast(uid3, 0)
+                e3.comm_init_rccl(bytes(uid3.cpu().numpy().tobytes()), rank, world)
+            else:
+                e3.comm_init_callback(_allreduce, rank, world)
+            if os.environ.get("PBA_PEER", "1") != "0":
+                e3.comm_enable_peer_exchange()
+            tn = measure(e3, sh3, 20, 5, collective=True)
+            tr3 = e3.comm_transport()
+            e3.close()
+            if rank == 0:
+                out["strong"] = {"workload": "configs[3]: ONE 16-frame window, %d points (%d residual blocks), points sharded over the ranks" % (n3, 16 * n3),
+                                 "us_per_iteration_1gpu": 1e6 * t1_full, "us_per_iteration": 1e6 * tn, "n_gpus": world,
+                                 "speedup_vs_1gpu_same_run": t1_full / tn, "transport": tr3, "steps": 20, "repeats": 5}
+        except Exception as exc:      # the headline line must survive a failure of the extra record
+            if rank == 0:
+                out["strong"] = {"error": repr(exc)}
+
+    # ---- one rank of R on ONE GPU: the multi-rank code path at world = 1 and the projected strong-scaling speed-up ----------
+    if emulate and world == 1:
+        R = emulate
+        os.environ["PBA_FORCE_MULTI"] = "1"          # read at pba_comm_init_*: the exchange path runs although world == 1
+        sh = prob.shard(0, R)
+        e2 = plain_engine(sh)
+        e2.comm_init_rccl(Engine.comm_unique_id(), 0, 1)
+        e2.comm_enable_peer_exchange()
+        t_rank = measure(e2, sh, args.steps, max(3, args.repeats // 3), collective=False)
+        tr2 = e2.comm_transport()
+        # per-kernel shares of the rank's iteration: HIP events of the host-stepped driver (the async pipeline has no event mode)
+        e2.set_problem(sh.xyz, sh.desc, sh.obs_point, sh.obs_slot, sh.weights)
+        e2.set_cameras(sh.cams, sh.fixed_slot)
+        e2.reset_counters()
+        e2.solve(opts(min(args.steps, 10)))
+        c2 = e2.counters()
+        e2.close()
+        del os.environ["PBA_FORCE_MULTI"]
+        t_full = elapsed / max(1, iters_done)
+        xg = 1e-6 * args.xgmi_exchange_us
+        per = lambda k: (1e3 * c2[k + "_ms"] / c2[k + "_launches"]) if c2[k + "_launches"] else 0.0
+        out["strong_projection"] = {
+            "what": "configs[3] strong scaling projected from ONE GPU: the full window on the single-rank path, and rank 0's shard of %d "
+                    "(%d points, %d residual blocks) on the MULTI-RANK path at world = 1 -- k_schur, k_reduce_final writing the mailbox slot + "
+                    "flag, k_solve_blocked waiting for the flags and summing the slots, fused k_sample raising the flag, k_decide waiting and "
+                    "summing -- so everything but the xGMI hop is measured" % (R, sh.n_points, sh.n_obs),
+            "ranks": R, "us_per_iteration_full_window_1gpu": 1e6 * t_full, "us_per_iteration_one_rank": 1e6 * t_rank,
+            "transport": tr2,
+            "assumed_xgmi_us_per_exchange": args.xgmi_exchange_us, "exchanges_per_iteration": 2,
+            "projected_us_per_iteration": 1e6 * (t_rank + 2 * xg),
+            "projected_speedup": t_full / (t_rank + 2 * xg),
+            "projected_speedup_if_exchange_free": t_full / t_rank,
+            "bar": "north_star: >= 6x at 8 GPUs, i.e. <= %.1f us per iteration per rank" % (1e6 * t_full / 6.0),
+            "rank_kernels_us_host_stepped": {"k_sample (fused)": per("linearize"), "k_schur": per("schur"),
+                                             "k_reduce_final + k_solve_blocked (incl. its peer wait)": per("solve"),
+                                             "scalar exchange kernel (host-stepped driver only)": per("exchange")},
+        }
 
     # ---- CPU baseline: the oracle ("restated Ceres-equivalent CPU path") on a bounded sample, rank 0, N = 1 ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.cpu_steps > 0 and not args.inverse_depth:

@@ -901,7 +901,7 @@ int pba_set_cameras(pba_engine* e, const double* cams6, int32_t n_frames, int32_
   e->part_stride = 36 * e->n_pairs + 3 * 6 * e->n_free + 3;
   if (e->n_pairs > kTile) return fail(e, PBA_ERR_INVALID, "too many free cameras for the Schur tile (%d pairs)", e->n_pairs);
   int rc;
-  if ((rc = dev_alloc(e, &e->d_partial, (size_t)(256 * 4) * e->part_stride))) return rc;
+  if ((rc = dev_alloc(e, &e->d_partial, (size_t)(256 * 4) * (((size_t)e->part_stride + 15) / 16 * 16)))) return rc;      // [entry / 16][workgroup][16]
   if ((rc = dev_alloc(e, &e->d_red, (size_t)pba_engine::kChunks * e->part_stride))) return rc;
   if ((rc = dev_alloc(e, &e->d_packed, (size_t)e->part_stride))) return rc;
   if (e->solve_tab_nf != e->n_free) {
@@ -1456,6 +1456,7 @@ int pba_internal_async_enqueue(pba_engine* e, int kind, int init_scale, const pb
   so.geom_cand_alt = e->d_geom[cur];
   { const int rcs = launch_reduce_and_solve(e, so, n, cur, cand, e->d_lm, kind == 2 ? 1 : 0, e->fused_grid); if (rcs) return rcs; }
   const unsigned long long seq = ++e->seq;
+  unsigned long long fused_x = 0;      // exchange number of the step scalars when k_decide does the exchange itself
   if (kind == 1) {
     SampleParams sp = sample_params(false);
     sp.lm = e->d_lm; sp.enq_cur = cur; sp.decide = multi ? 0 : 1;
@@ -1467,19 +1468,32 @@ int pba_internal_async_enqueue(pba_engine* e, int kind, int init_scale, const pb
       if (rcx) return rcx;
       sp.xchg = e->comm.peer ? peer_slot(e, 1) : e->d_xchg; sp.xchg_sys = e->comm.peer ? 1 : 0;
       sp.xchg_rank = e->comm.rank; sp.xchg_world = e->comm.world;
+      if (e->comm.peer) {
+        // the exchange of the step scalars has no kernel of its own: the sampling kernel's last workgroup raises the flag,
+        // k_decide waits for every rank's and sums the slots
+        fused_x = ++e->comm.seq_b;
+        sp.xchg = e->comm.mb_own + Comm::data_offset(1, fused_x);
+        sp.xchg_flag = reinterpret_cast<unsigned long long*>(e->comm.mb_own) + Comm::flag_index(1, fused_x);
+        sp.xchg_seq = fused_x;
+      }
     }
     launch_sample<true, true>(e, sp);
     e->jac_passes++;
     HIP_TRY(e, hipGetLastError());
   }
-  if (multi) {
+  if (multi && !fused_x) {
     int rc2 = exchange_step_scalars(e, kind == 1);
     if (rc2) return rc2;
   }
   if (multi || kind == 2) {
     DecideParams dp{};
+    if (fused_x) {
+      dp.peer = peer_params(e); dp.peer_world = e->comm.world; dp.peer_flag = (int)Comm::flag_index(1, fused_x);
+      dp.peer_off = (unsigned long long)Comm::data_offset(1, fused_x); dp.peer_seq = fused_x;
+      dp.peer_timeout = (unsigned long long)(0.5 * e->wait_timeout_s * 1e8); dp.peer_err = e->h_comm_err_dev;
+    }
     dp.lm = e->d_lm; dp.host_state = e->h_lm_dev; dp.scal = e->d_scal; dp.host_scal = e->h_scal_dev; dp.log = e->d_log;
-    dp.xchg = multi ? e->d_xchg : nullptr; dp.world = e->comm.world;
+    dp.xchg = (multi && !fused_x) ? e->d_xchg : nullptr; dp.world = e->comm.world;
     dp.max_log = pba_engine::kMaxLog; dp.grad_only = (kind == 2) ? 1 : 0; dp.seq = seq;
     dp.host_seq = (kind == 1) ? nullptr : h_seq_dev;      // a full step is published by the next k_schur / k_flush
     hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, e->stream, dp);

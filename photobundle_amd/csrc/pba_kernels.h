@@ -556,6 +556,43 @@ struct PeerParams {
   double* own;
   int32_t world, rank;
 };
+
+// Peer exchange folded into a consumer kernel: raise nothing (the producer kernel's last workgroup raised this rank's flag
+// when its stores had left), wait -- bounded -- until every rank's flag shows `seq`.  A timeout is reported through the
+// host-mapped word AND poisons the result (the caller writes NaNs), so that a missed flag can never look like a step.
+__device__ __forceinline__ bool peer_wait_all(const PeerParams& pp, int world, int flag_idx, unsigned long long seq,
+                                              unsigned long long timeout_ticks, unsigned int* host_err, int tid) {
+  __shared__ int s_peer_bad;
+  if (tid == 0) s_peer_bad = 0;
+  __syncthreads();
+  if (tid < world) {
+    // (select chain: a runtime index moves the whole kernel-parameter block to scratch)
+    const double* mbq = tid == 1 ? pp.mb[1] : tid == 2 ? pp.mb[2] : tid == 3 ? pp.mb[3] : tid == 4 ? pp.mb[4] : tid == 5 ? pp.mb[5]
+                      : tid == 6 ? pp.mb[6] : tid == 7 ? pp.mb[7] : pp.mb[0];
+    const unsigned long long* f = reinterpret_cast<const unsigned long long*>(mbq) + flag_idx;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+      if (__builtin_amdgcn_s_memrealtime() - t0 > timeout_ticks) {
+        if (host_err) __hip_atomic_store(host_err, 1u + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        s_peer_bad = 1;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(8);
+    }
+  }
+  __syncthreads();
+  return s_peer_bad == 0;
+}
+__device__ __forceinline__ double peer_sum(const PeerParams& pp, int world, unsigned long long off, int idx) {
+  double v[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) v[q] = (q < world) ? load_system_f64(pp.mb[q] + off + idx) : 0.0;
+  double acc = v[0];
+#pragma unroll
+  for (int q = 1; q < 8; ++q) if (q < world) acc += v[q];      // rank order: the same bits on every rank
+  return acc;
+}
+
 __global__ __launch_bounds__(256) void k_peer_allreduce(PeerParams pp, int flag_idx, unsigned long long data_off, int n,
                                                          unsigned long long seq, double* __restrict__ out,
                                                          unsigned long long timeout_ticks, unsigned int* host_err) {
@@ -608,11 +645,28 @@ struct DecideParams {
   const double* xchg; int32_t world;
   pba_iteration_summary* log; int32_t max_log; int32_t grad_only;
   unsigned long long* host_seq; unsigned long long seq;
+  // peer exchange of the step scalars folded into this kernel (peer_world > 0): the producer -- the last workgroup of the
+  // fused sampling kernel -- wrote this rank's contribution into its mailbox slot and raised the rank's flag; here every
+  // rank's flag is awaited and the slots are summed in rank order (no exchange kernel in between)
+  PeerParams peer; int32_t peer_world, peer_flag;
+  unsigned long long peer_off, peer_seq, peer_timeout;
+  unsigned int* peer_err;
 };
 
 __global__ void k_decide(DecideParams p) {
+  __shared__ double s_x[kSumBCount + kMaxCount * 8];
+  const double* xchg = p.xchg;
+  if (p.peer_world > 0) {
+    // (a terminated solve: every rank's producer was a no-op and raised nothing -- nothing to wait for)
+    if (p.lm->done) return;
+    const bool ok = peer_wait_all(p.peer, p.peer_world, p.peer_flag, p.peer_seq, p.peer_timeout, p.peer_err, threadIdx.x);
+    const int n = kSumBCount + kMaxCount * p.peer_world;
+    for (int e = threadIdx.x; e < n; e += blockDim.x) s_x[e] = ok ? peer_sum(p.peer, p.peer_world, p.peer_off, e) : __longlong_as_double(0x7ff8000000000000ll);
+    __syncthreads();
+    xchg = s_x;
+  }
   if (threadIdx.x == 0) {
-    if (p.xchg) xchg_unpack(p.xchg, p.scal, p.world);
+    if (xchg) xchg_unpack(xchg, p.scal, p.world);
     lm_decide(p.lm, p.scal, p.log, p.max_log, p.grad_only);
     if (p.lm->done && p.lm->done_seq == 0) p.lm->done_seq = p.seq;
   }
@@ -745,6 +799,8 @@ struct SampleParams {
   double* xchg;               // multi-rank: exchange buffer of the step scalars, packed by the last workgroup
   int32_t xchg_rank, xchg_world;
   int32_t xchg_sys;           // the exchange buffer is this rank's peer mailbox: system-scope stores
+  unsigned long long* xchg_flag;   // null, or this rank's mailbox flag of the exchange: raised (xchg_seq) by the last workgroup
+  unsigned long long xchg_seq;     // once its contribution has left, for the consumer kernel (k_decide) of every rank
   unsigned long long* dbg;    // optional [gridDim.x][8] per-phase cycle stamps of thread 0 (diagnostics)
 };
 
@@ -986,6 +1042,11 @@ __device__ __forceinline__ void fused_finalize(const SampleParams& p, int lane, 
     if (p.xchg) {
       __syncthreads();
       xchg_pack(p.scal, p.xchg, p.xchg_rank, p.xchg_world, threadIdx.x, NTH, p.xchg_sys != 0);
+      if (p.xchg_flag) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every thread's system-scope stores have left
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(p.xchg_flag, p.xchg_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
     }
     if (p.host_scal) {
       __syncthreads();
@@ -2434,7 +2495,10 @@ __global__ __launch_bounds__(kTile, 2) void k_schur(SchurParams p_in) {
 #undef PBA_TICK
 
   // ---- combine the point groups (fixed order), then per-block partials -----------------------------------
-  double* out = p.partial + (size_t)blockIdx.x * p.part_stride;
+  // Partial layout (r4): entry e of workgroup b at ((e >> 4) * gridDim.x + b) * 16 + (e & 15) -- 16-entry (128-byte) chunks, all
+  // workgroups' copies of one chunk contiguous: the reduction workgroup of a chunk then reads ONE sequential region of
+  // gridDim.x x 128 bytes (it used to gather 128-byte pieces 9 - 37 KB apart: 2.4 TB/s), a store here still fills whole lines.
+  auto out_at = [&](int e) -> double* { return p.partial + ((size_t)(e >> 4) * gridDim.x + blockIdx.x) * 16 + (e & 15); };
   if (owner && grp > 0) {
     double* dst = s_obs + ((grp - 1) * p.n_pairs + pair) * 36;
 #pragma unroll
@@ -2458,12 +2522,12 @@ __global__ __launch_bounds__(kTile, 2) void k_schur(SchurParams p_in) {
     if (e < kCamVals * nf) {
       s_cam[e] = acc_cam[u];
       const int a = e / kCamVals, v = e - a * kCamVals;
-      if (v >= 27) out[36 * p.n_pairs + n + 6 * a + (v - 27)] = acc_cam[u];            // g_c
-      else if (v >= 21) out[36 * p.n_pairs + 6 * a + (v - 21)] = acc_cam[u];          // rhs
+      if (v >= 27) *out_at(36 * p.n_pairs + n + 6 * a + (v - 27)) = acc_cam[u];            // g_c
+      else if (v >= 21) *out_at(36 * p.n_pairs + 6 * a + (v - 21)) = acc_cam[u];          // rhs
       else {
         // packed upper triangle: entry v is a diagonal (i, i) iff v == sym6(i, i) = 6 i - i (i - 1) / 2
 #pragma unroll
-        for (int i = 0; i < 6; ++i) if (v == 6 * i - (i * (i - 1)) / 2) out[36 * p.n_pairs + 2 * n + 6 * a + i] = acc_cam[u];   // diag(U)
+        for (int i = 0; i < 6; ++i) if (v == 6 * i - (i * (i - 1)) / 2) *out_at(36 * p.n_pairs + 2 * n + 6 * a + i) = acc_cam[u];   // diag(U)
       }
     }
   }
@@ -2478,7 +2542,7 @@ __global__ __launch_bounds__(kTile, 2) void k_schur(SchurParams p_in) {
     }
 #pragma unroll
     for (int k = 0; k < 36; ++k) {
-      double* dst = PBA_PARTIAL_T ? out + k * p.n_pairs + pair : out + pair * 36 + k;
+      double* dst = out_at(PBA_PARTIAL_T ? k * p.n_pairs + pair : pair * 36 + k);
       if (PBA_PARTIAL_SC1) store_agent(dst, acc[k]); else *dst = acc[k];
     }
   }
@@ -2491,9 +2555,9 @@ __global__ __launch_bounds__(kTile, 2) void k_schur(SchurParams p_in) {
     if (tid == 0) {
       double a = 0.0, m = 0.0, f = 0.0;
       for (int w = 0; w < kTile / 64; ++w) { a += s_red[3 * w]; m = fmax(m, s_red[3 * w + 1]); f = fmax(f, s_red[3 * w + 2]); }
-      out[36 * p.n_pairs + 3 * n + 0] = m;
-      out[36 * p.n_pairs + 3 * n + 1] = a;
-      out[36 * p.n_pairs + 3 * n + 2] = f;
+      *out_at(36 * p.n_pairs + 3 * n + 0) = m;
+      *out_at(36 * p.n_pairs + 3 * n + 1) = a;
+      *out_at(36 * p.n_pairs + 3 * n + 2) = f;
       if (p.stamp && blockIdx.x < kStampSchurBlocks) p.stamp[kStampSchur0 + blockIdx.x] = __builtin_amdgcn_s_memrealtime();
     }
   }

@@ -67,7 +67,7 @@ constexpr int kReduceEntries = 16;      // packed entries per workgroup (x 32 su
 constexpr int kReduceThreads = 512;
 constexpr int kReduceInFlight = 32;
 struct ReduceParams {
-  const double* partial; int32_t n_blocks, stride;      // k_schur partials [n_blocks][stride]
+  const double* partial; int32_t n_blocks, stride;      // k_schur partials: `stride` entries per workgroup, [entry / 16][n_blocks][16]
   int32_t n_free, n_pairs;
   const double* block_cost; const int32_t* block_fail; int32_t n_cost_blocks;
   double* packed; double* scal;
@@ -90,7 +90,7 @@ __device__ __forceinline__ void reduce_partials(const ReduceParams& rp, double (
 #pragma unroll
       for (int k = 0; k < NF; ++k) {
         const int bb = sub + SUB * k;
-        v[k] = (bb < n_blocks) ? rp.partial[(size_t)bb * stride + e] : 0.0;
+        v[k] = (bb < n_blocks) ? rp.partial[((size_t)blockIdx.x * n_blocks + bb) * EX + ex] : 0.0;
       }
     }
     // destination of this entry: integer work under the loads
@@ -102,7 +102,7 @@ __device__ __forceinline__ void reduce_partials(const ReduceParams& rp, double (
 #pragma unroll
         for (int k = 0; k < NF; ++k) {
           const int bb = b + SUB * k;
-          v[k] = (bb < n_blocks) ? rp.partial[(size_t)bb * stride + e] : 0.0;
+          v[k] = (bb < n_blocks) ? rp.partial[((size_t)blockIdx.x * n_blocks + bb) * EX + ex] : 0.0;
         }
 #pragma unroll
         for (int k = 0; k < NF; ++k) acc = is_max ? fmax(acc, v[k]) : acc + v[k];
@@ -194,42 +194,6 @@ __device__ __forceinline__ void tri_row_col(int t, int& r, int& c) {
   while (tri_index(r + 1) <= t) ++r;
   while (tri_index(r) > t) --r;
   c = t - tri_index(r);
-}
-
-// Peer exchange folded into a consumer kernel: raise nothing (the producer kernel's last workgroup raised this rank's flag
-// when its stores had left), wait -- bounded -- until every rank's flag shows `seq`.  A timeout is reported through the
-// host-mapped word AND poisons the result (the caller writes NaNs), so that a missed flag can never look like a step.
-__device__ __forceinline__ bool peer_wait_all(const PeerParams& pp, int world, int flag_idx, unsigned long long seq,
-                                              unsigned long long timeout_ticks, unsigned int* host_err, int tid) {
-  __shared__ int s_peer_bad;
-  if (tid == 0) s_peer_bad = 0;
-  __syncthreads();
-  if (tid < world) {
-    // (select chain: a runtime index moves the whole kernel-parameter block to scratch)
-    const double* mbq = tid == 1 ? pp.mb[1] : tid == 2 ? pp.mb[2] : tid == 3 ? pp.mb[3] : tid == 4 ? pp.mb[4] : tid == 5 ? pp.mb[5]
-                      : tid == 6 ? pp.mb[6] : tid == 7 ? pp.mb[7] : pp.mb[0];
-    const unsigned long long* f = reinterpret_cast<const unsigned long long*>(mbq) + flag_idx;
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
-      if (__builtin_amdgcn_s_memrealtime() - t0 > timeout_ticks) {
-        if (host_err) __hip_atomic_store(host_err, 1u + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        s_peer_bad = 1;
-        break;
-      }
-      __builtin_amdgcn_s_sleep(8);
-    }
-  }
-  __syncthreads();
-  return s_peer_bad == 0;
-}
-__device__ __forceinline__ double peer_sum(const PeerParams& pp, int world, unsigned long long off, int idx) {
-  double v[8];
-#pragma unroll
-  for (int q = 0; q < 8; ++q) v[q] = (q < world) ? load_system_f64(pp.mb[q] + off + idx) : 0.0;
-  double acc = v[0];
-#pragma unroll
-  for (int q = 1; q < 8; ++q) if (q < world) acc += v[q];      // rank order: the same bits on every rank
-  return acc;
 }
 
 // LOADER of the packed sums: plain loads (an earlier kernel / the all-reduce produced them), agent-scope loads (other

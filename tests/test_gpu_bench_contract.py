@@ -28,13 +28,13 @@ def test_single_gpu_line():
     assert r.returncode == 0, r.stderr[-2000:]
     d = _json_line(r.stdout)
     assert KEYS <= set(d) and d["n_gpus"] == 1 and d["steps"] == 10 and d["value"] > 0 and d["scaling"] == "weak"
-    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(d["roofline"])
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_source_id", "traffic_matches_build"} <= set(d["roofline"])
     assert {"value", "unit", "cores", "kind", "sample"} <= set(d["cpu_baseline"]) and d["cpu_baseline"]["kind"] == "port"
 
 
 @pytest.mark.timeout(900)
 def test_two_rank_launch_path():
-    env = dict(os.environ, PBA_BENCH_BACKEND="gloo")
+    env = dict(os.environ, PBA_BENCH_BACKEND="gloo", PBA_BENCH_STRONG_POINTS="6000")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                         "127.0.0.1", "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8",
                         "--warmup", "2", "--points", "10000"], capture_output=True, text=True, timeout=850, cwd=ROOT, env=env)
@@ -42,4 +42,27 @@ def test_two_rank_launch_path():
     d = _json_line(r.stdout)
     assert d["n_gpus"] == 2 and d["steps"] == 8 and d["value"] > 0
     assert d["config"]["observations"] == 2 * 10000 * 8           # whole-job aggregate over both shards
-    assert abs(d["value"] - 2 * d["iters_per_sec"]) < 1e-6 * d["value"]
+    # `value` is the rate of the ONE window both ranks solve together, never multiplied by the rank count ...
+    assert d["value"] == d["iters_per_sec"] and abs(d["value"] * d["ms_per_step"] * 1e-3 - 1.0) < 1e-6
+    # ... what scales with N is the residual rate: all 2 x 80k blocks x 25 residuals per Jacobian pass
+    assert d["residuals_per_sec"] > 0.9 * d["value"] * 2 * 10000 * 8 * 25
+    # the strong-scaling record of the same launch (configs[3] shape, shrunk here): rank 0 alone, then both ranks
+    st = d["strong"]
+    assert "error" not in st, st
+    assert st["n_gpus"] == 2 and st["us_per_iteration_1gpu"] > 0 and st["us_per_iteration"] > 0
+    assert abs(st["speedup_vs_1gpu_same_run"] - st["us_per_iteration_1gpu"] / st["us_per_iteration"]) < 1e-9
+
+
+@pytest.mark.timeout(900)
+def test_rank_of_eight_emulation_and_counter_file_id():
+    """--config 3 --emulate-rank-of 8: the multi-rank code path at world = 1 on a shard, projected speed-up printed;
+    and the roofline object says which build the committed counter file belongs to."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "3", "--emulate-rank-of", "8", "--points", "16000",
+                        "--steps", "6", "--warmup", "2", "--repeats", "3"], capture_output=True, text=True, timeout=850, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _json_line(r.stdout)
+    sp = d["strong_projection"]
+    assert sp["ranks"] == 8 and sp["transport"].endswith("+peer"), sp
+    assert 0 < sp["us_per_iteration_one_rank"] < sp["us_per_iteration_full_window_1gpu"]
+    assert abs(sp["projected_speedup"] - sp["us_per_iteration_full_window_1gpu"] / sp["projected_us_per_iteration"]) < 1e-9
+    assert len(d["roofline"]["kernel_source_id"]) == 12

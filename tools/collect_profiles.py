@@ -77,7 +77,10 @@ if sq:
 per = {k: {"fetch_bytes": 2.0 * fetch.get(k, 0.0), "write_bytes": write.get(k, 0.0),
            "total_bytes": 2.0 * fetch.get(k, 0.0) + write.get(k, 0.0), "valu_insts": valu.get(k)}
        for k in sorted(set(fetch) | set(write)) if "pba::" in k}
+sys.path.insert(0, os.getcwd())
+import bench  # noqa: E402  (kernel_source_id: ties the counters to the build they were taken on)
 out = {
+    "kernel_source_id": bench.kernel_source_id(),
     "unit": "bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) KiB x 1024 from separate rocprofv3 --pmc passes; the x2 on "
             "FETCH_SIZE is the gfx950 correction of MI355X_MICROARCH.md, calibrated on these kernels' own access widths "
             "(profiles/r02/fetch_calibration.txt: ratio 0.500 for dword..dwordx4 streams, 0.532 for the footprint row "
