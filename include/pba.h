@@ -204,6 +204,36 @@ int pba_get_frame_channels_f32(pba_engine* e, int slot, float* channels);
  * photobundle.cc:540-560), so cv::resize of the depth (:54-56) stays with the caller. */
 int pba_set_frame_pyr_down(pba_engine* e, int slot, pba_engine* finer, int finer_slot, uint8_t* image_out);
 
+/* ---- device front-end (round 4): the per-frame work of PhotometricBundleAdjustment::addFrame on the frame that already sits in
+ * the engine (reference src/photobundle.cc:505-603), so that neither the float planes nor the channel images travel back:
+ *   pba_frontend_visibility   ZNCC test of the tracked points (ZnccPatch_<2, float>, :315-361, :512-542) on the u8 frame MOST
+ *                             RECENTLY handed to pba_set_frame_u8 / pba_set_frame_descriptor_u8 (or produced by
+ *                             pba_set_frame_pyr_down).  uv [n][2]: projections K (T_c X) of the points the caller already found
+ *                             inside the border (:519-523), rc [n][2]: their rounded (row, column), patches [n][26]: the stored
+ *                             zero-mean 5x5 patch and its norm.  hit[i] = score > min_score; the (2 mask_radius + 1)^2 block around
+ *                             every hit leaves the engine's selection mask (:536-538), which the call first resets.  n may be 0.
+ *   pba_frontend_candidates   saliency map of the frame in `slot` (sum over the channels of |Ix| + |Iy|, :213-221), then every pixel
+ *                             of [border, rows - border - 1) x [border, cols - border - 1) with min_depth <= depth <= max_depth
+ *                             that is unmasked and a STRICT local maximum of the saliency over (2 nms_radius + 1)^2 (:555-573,
+ *                             src/imgproc.h:176-212; nms_radius <= 0: every valid-depth pixel).  depth: rows * cols floats of the
+ *                             caller (borrowed for the call).  *n_out = number of candidates, kept on the device in the row-major
+ *                             order of the reference's scan;
+ *   pba_frontend_get_candidates   copies the first n of them out (the caller selects the maxNumPoints most salient, :578-585);
+ *   pba_frontend_descriptors  ExtractPatch (:466-479, :597-603) at n integer pixels xy [n][2] = (x, y): desc [n][C][(2 R + 1)^2]
+ *                             channel values as float (exact: the reference stores the same floats widened to double).
+ * Same arithmetic, type by type and in the same order, as the host restatement in photobundle_amd/host/photobundle.cc: the
+ * class produces byte-identical trajectories with either (PBA_HOST_FRONTEND=1 selects the host one). */
+typedef struct pba_candidate { float saliency; int32_t x, y; } pba_candidate;
+int pba_frontend_visibility(pba_engine* e, int32_t n, const double* uv, const int32_t* rc, const float* patches26, double min_score,
+                            int32_t mask_radius, uint8_t* hit);
+int pba_frontend_candidates(pba_engine* e, int32_t slot, const float* depth, double min_depth, double max_depth, int32_t nms_radius,
+                            int32_t border, int32_t* n_out);
+int pba_frontend_get_candidates(pba_engine* e, pba_candidate* out, int32_t n);
+int pba_frontend_descriptors(pba_engine* e, int32_t slot, int32_t n, const int32_t* xy, float* desc);
+/* Test hook: what pba_frontend_visibility computes for point i, out27[27 i ..] = the zero-mean patch of the new frame at uv (25),
+ * its norm, the score against patches26[i] (-1 when the product of the norms is <= 1e-6).  No mask, no flags. */
+int pba_frontend_zncc_probe(pba_engine* e, int32_t n, const double* uv, const float* patches26, float* out27);
+
 /* ---- problem: replaces the AddResidualBlock loop (photobundle.cc:786-806) -------------------------------
  * Call order: pba_set_frame_u8 (every slot the observation list uses), pba_set_problem and pba_set_cameras may come in
  * any order, all three before pba_linearize / pba_solve; a pass that finds one of them missing, an observation whose

@@ -73,6 +73,7 @@ SYMBOLS = [
     "pba_linearize", "pba_step", "pba_accept", "pba_get_reduced_system", "pba_get_obs_records", "pba_solve",
     "pba_comm_unique_id", "pba_comm_init_rccl", "pba_comm_init_callback", "pba_comm_enable_peer_exchange", "pba_comm_transport", "pba_comm_rank_count",
     "pba_set_profiling", "pba_get_counters", "pba_reset_counters",
+    "pba_frontend_visibility", "pba_frontend_candidates", "pba_frontend_get_candidates", "pba_frontend_descriptors", "pba_frontend_zncc_probe",
 ]
 
 
@@ -105,6 +106,11 @@ def lib():
     L.pba_set_frame_descriptor_u8.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int32, C.c_float, C.c_float]
     L.pba_get_frame_channels_f32.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.pba_set_frame_pyr_down.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    L.pba_frontend_visibility.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int32, C.c_void_p]
+    L.pba_frontend_candidates.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_double, C.c_double, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]
+    L.pba_frontend_get_candidates.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+    L.pba_frontend_zncc_probe.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.pba_frontend_descriptors.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     L.pba_set_problem.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.pba_set_cameras.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
     L.pba_get_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]

@@ -7,6 +7,7 @@
 #include "pba_comm.h"
 #include "pba_internal.h"
 #include "pba_kernels.h"
+#include "pba_frontend.h"
 
 #include <algorithm>
 #include <chrono>
@@ -39,6 +40,18 @@ struct pba_engine {
   bool img_stage_busy = false;
   hipEvent_t ev_xdep = nullptr;     // orders another engine's stream against this one (pba_set_frame_pyr_down)
   uint8_t* d_u8_work[2] = {nullptr, nullptr};   // device-side descriptor producers: smoothed frame, census image (on first use)
+  // device front-end (pba_frontend_*), everything on first use
+  uint8_t* d_fe_mask = nullptr;     // [rows*cols] selection mask (1 = free)
+  uint8_t* d_fe_flag = nullptr;     // [rows*cols] candidate flags
+  float* d_fe_smap = nullptr;       // [rows*cols] saliency
+  float* d_fe_depth = nullptr;      // [rows*cols]
+  int32_t* d_fe_rows = nullptr;     // [2 rows + 1] per-row counts | offsets
+  pba_candidate* d_fe_cand = nullptr;   // [rows*cols]
+  char* d_fe_io = nullptr;          // grow-only device scratch of the visibility / descriptor calls
+  char* h_fe_io = nullptr;          // pinned staging (grow-only)
+  size_t h_fe_cap = 0;
+  bool fe_mask_valid = false;       // pba_frontend_visibility ran for the current frame
+  int fe_n_cand = 0;
   std::vector<uint8_t> frame_set;
   uint32_t slot_mask = 0;           // window slots referenced by the observation list
 
@@ -577,6 +590,9 @@ void pba_destroy(pba_engine* e) {
   if (e->ev_img_stage) (void)hipEventDestroy(e->ev_img_stage);
   if (e->ev_xdep) (void)hipEventDestroy(e->ev_xdep);
   dev_free(&e->d_u8_work[0]); dev_free(&e->d_u8_work[1]);
+  dev_free(&e->d_fe_mask); dev_free(&e->d_fe_flag); dev_free(&e->d_fe_smap); dev_free(&e->d_fe_depth); dev_free(&e->d_fe_rows);
+  dev_free(&e->d_fe_cand); dev_free(&e->d_fe_io);
+  if (e->h_fe_io) (void)hipHostFree(e->h_fe_io);
   if (e->h_log) (void)hipHostFree(e->h_log);
   dev_free(&e->d_lm);
   dev_free(&e->d_log);
@@ -788,6 +804,152 @@ int pba_set_frame_pyr_down(pba_engine* e, int slot, pba_engine* finer, int finer
     HIP_TRY(e, hipStreamSynchronize(e->stream));
   }
   e->frame_set[slot] = 1;
+  return PBA_OK;
+}
+
+// ---- device front-end ---------------------------------------------------------------------------------------------------
+static int fe_stage(pba_engine* e, size_t bytes) {      // pinned staging buffer of the front-end calls, grow-only
+  if (e->h_fe_cap >= bytes) return PBA_OK;
+  if (e->h_fe_io) { (void)hipHostFree(e->h_fe_io); e->h_fe_io = nullptr; e->h_fe_cap = 0; }
+  const size_t want = bytes + bytes / 4 + 4096;
+  HIP_TRY(e, hipHostMalloc(reinterpret_cast<void**>(&e->h_fe_io), want, hipHostMallocDefault));
+  e->h_fe_cap = want;
+  return PBA_OK;
+}
+
+int pba_frontend_visibility(pba_engine* e, int32_t n, const double* uv, const int32_t* rc, const float* patches26, double min_score,
+                            int32_t mask_radius, uint8_t* hit) {
+  if (!e || n < 0 || mask_radius < 0 || (n > 0 && (!uv || !rc || !patches26 || !hit))) return PBA_ERR_INVALID;
+  PBA_NOT_POISONED(e);
+  HIP_TRY(e, hipSetDevice(e->cfg.device));
+  const int rows = e->cfg.rows, cols = e->cfg.cols;
+  const size_t npix = (size_t)rows * cols;
+  int rcode;
+  if ((rcode = dev_alloc(e, &e->d_fe_mask, npix))) return rcode;
+  HIP_TRY(e, hipMemsetAsync(e->d_fe_mask, 1, npix, e->stream));
+  e->fe_mask_valid = true;
+  if (n == 0) return PBA_OK;
+  for (int i = 0; i < n; ++i)
+    if (rc[2 * i] < mask_radius || rc[2 * i] >= rows - mask_radius || rc[2 * i + 1] < mask_radius || rc[2 * i + 1] >= cols - mask_radius)
+      return fail(e, PBA_ERR_INVALID, "pba_frontend_visibility: point %d at (row %d, col %d) is closer than the mask radius to the border", i, rc[2 * i], rc[2 * i + 1]);
+  // one upload: uv (16 B) | patches (104 B) | rc (8 B) per point; hits come back through the same pinned buffer
+  const size_t o_uv = 0, o_pt = o_uv + (size_t)n * 16, o_rc = o_pt + (size_t)n * 104, o_hit = o_rc + (size_t)n * 8, total = o_hit + (size_t)n;
+  if ((rcode = fe_stage(e, total))) return rcode;
+  if ((rcode = dev_alloc(e, &e->d_fe_io, total + total / 4))) return rcode;
+  std::memcpy(e->h_fe_io + o_uv, uv, (size_t)n * 16);
+  std::memcpy(e->h_fe_io + o_pt, patches26, (size_t)n * 104);
+  std::memcpy(e->h_fe_io + o_rc, rc, (size_t)n * 8);
+  HIP_TRY(e, hipMemcpyAsync(e->d_fe_io, e->h_fe_io, o_hit, hipMemcpyHostToDevice, e->stream));
+  uint8_t* d_hit = reinterpret_cast<uint8_t*>(e->d_fe_io + o_hit);
+  hipLaunchKernelGGL(k_fe_visibility, dim3((n + 127) / 128), dim3(128), 0, e->stream, (const uint8_t*)e->d_img_stage, rows, cols, n,
+                     reinterpret_cast<const double*>(e->d_fe_io + o_uv), reinterpret_cast<const float*>(e->d_fe_io + o_pt), min_score, d_hit, (float*)nullptr);
+  hipLaunchKernelGGL(k_fe_mask_stamp, dim3((n + 255) / 256), dim3(256), 0, e->stream, n, reinterpret_cast<const int2*>(e->d_fe_io + o_rc),
+                     (const uint8_t*)d_hit, mask_radius, e->d_fe_mask, cols);
+  HIP_TRY(e, hipGetLastError());
+  HIP_TRY(e, hipMemcpyAsync(e->h_fe_io + o_hit, d_hit, (size_t)n, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  std::memcpy(hit, e->h_fe_io + o_hit, (size_t)n);
+  return PBA_OK;
+}
+
+int pba_frontend_zncc_probe(pba_engine* e, int32_t n, const double* uv, const float* patches26, float* out27) {
+  if (!e || n <= 0 || !uv || !patches26 || !out27) return PBA_ERR_INVALID;
+  PBA_NOT_POISONED(e);
+  HIP_TRY(e, hipSetDevice(e->cfg.device));
+  const size_t o_pt = (size_t)n * 16, o_out = o_pt + (size_t)n * 104, total = o_out + (size_t)n * 108;
+  int rcode;
+  if ((rcode = fe_stage(e, total))) return rcode;
+  if ((rcode = dev_alloc(e, &e->d_fe_io, total + total / 4))) return rcode;
+  std::memcpy(e->h_fe_io, uv, (size_t)n * 16);
+  std::memcpy(e->h_fe_io + o_pt, patches26, (size_t)n * 104);
+  HIP_TRY(e, hipMemcpyAsync(e->d_fe_io, e->h_fe_io, o_out, hipMemcpyHostToDevice, e->stream));
+  hipLaunchKernelGGL(k_fe_visibility, dim3((n + 127) / 128), dim3(128), 0, e->stream, (const uint8_t*)e->d_img_stage, e->cfg.rows, e->cfg.cols, n,
+                     reinterpret_cast<const double*>(e->d_fe_io), reinterpret_cast<const float*>(e->d_fe_io + o_pt), 0.0, (uint8_t*)nullptr,
+                     reinterpret_cast<float*>(e->d_fe_io + o_out));
+  HIP_TRY(e, hipGetLastError());
+  HIP_TRY(e, hipMemcpyAsync(e->h_fe_io + o_out, e->d_fe_io + o_out, (size_t)n * 108, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  std::memcpy(out27, e->h_fe_io + o_out, (size_t)n * 108);
+  return PBA_OK;
+}
+
+int pba_frontend_candidates(pba_engine* e, int32_t slot, const float* depth, double min_depth, double max_depth, int32_t nms_radius,
+                            int32_t border, int32_t* n_out) {
+  if (!e || !depth || !n_out || slot < 0 || slot >= e->cfg.max_frames || border < 0) return PBA_ERR_INVALID;
+  if (!e->frame_set[slot]) return fail(e, PBA_ERR_STATE, "pba_frontend_candidates: slot %d holds no frame", slot);
+  if (nms_radius > border) return fail(e, PBA_ERR_INVALID, "pba_frontend_candidates: nms radius %d reaches over the border %d", nms_radius, border);
+  PBA_NOT_POISONED(e);
+  HIP_TRY(e, hipSetDevice(e->cfg.device));
+  const int rows = e->cfg.rows, cols = e->cfg.cols;
+  const size_t npix = (size_t)rows * cols;
+  int rcode;
+  if ((rcode = dev_alloc(e, &e->d_fe_mask, npix))) return rcode;
+  if (!e->fe_mask_valid) HIP_TRY(e, hipMemsetAsync(e->d_fe_mask, 1, npix, e->stream));      // no visibility call for this frame: nothing is masked
+  e->fe_mask_valid = false;       // (consumed: the next frame starts from a fresh mask)
+  if ((rcode = dev_alloc(e, &e->d_fe_flag, npix))) return rcode;
+  if ((rcode = dev_alloc(e, &e->d_fe_smap, npix))) return rcode;
+  if ((rcode = dev_alloc(e, &e->d_fe_depth, npix))) return rcode;
+  if ((rcode = dev_alloc(e, &e->d_fe_rows, (size_t)2 * rows + 1))) return rcode;
+  if ((rcode = dev_alloc(e, &e->d_fe_cand, npix))) return rcode;
+  if ((rcode = fe_stage(e, npix * sizeof(float)))) return rcode;
+  std::memcpy(e->h_fe_io, depth, npix * sizeof(float));
+  HIP_TRY(e, hipMemcpyAsync(e->d_fe_depth, e->h_fe_io, npix * sizeof(float), hipMemcpyHostToDevice, e->stream));
+  const dim3 grid((cols + 255) / 256, rows), block(256);
+  const bool mc = e->channels > 1;
+  hipLaunchKernelGGL(k_fe_saliency, grid, block, 0, e->stream, (const uint32_t*)(e->d_frames + npix * slot),
+                     mc ? (const float*)(e->d_frames_mc + (size_t)slot * e->channels * npix) : (const float*)nullptr, e->channels, rows, cols, e->d_fe_smap);
+  CandParams cp{};
+  cp.smap = e->d_fe_smap; cp.depth = e->d_fe_depth; cp.mask = e->d_fe_mask; cp.rows = rows; cp.cols = cols; cp.border = border; cp.nms = nms_radius;
+  cp.min_depth = min_depth; cp.max_depth = max_depth; cp.flag = e->d_fe_flag; cp.row_count = e->d_fe_rows; cp.row_offset = e->d_fe_rows + rows;
+  cp.out = e->d_fe_cand;
+  hipLaunchKernelGGL(k_fe_cand_flags, dim3(rows), dim3(256), 0, e->stream, cp);
+  hipLaunchKernelGGL(k_fe_scan_rows, dim3(1), dim3(256), 0, e->stream, (const int32_t*)cp.row_count, cp.row_offset, rows);
+  hipLaunchKernelGGL(k_fe_cand_write, dim3(rows), dim3(256), 0, e->stream, cp);
+  HIP_TRY(e, hipGetLastError());
+  int32_t* h_n = reinterpret_cast<int32_t*>(e->h_fe_io);
+  HIP_TRY(e, hipMemcpyAsync(h_n, cp.row_offset + rows, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  e->fe_n_cand = *h_n;
+  *n_out = e->fe_n_cand;
+  return PBA_OK;
+}
+
+int pba_frontend_get_candidates(pba_engine* e, pba_candidate* out, int32_t n) {
+  if (!e || n < 0 || (n > 0 && !out)) return PBA_ERR_INVALID;
+  if (n > e->fe_n_cand) return fail(e, PBA_ERR_STATE, "pba_frontend_get_candidates: %d requested, the last scan found %d", n, e->fe_n_cand);
+  if (n == 0) return PBA_OK;
+  PBA_NOT_POISONED(e);
+  HIP_TRY(e, hipSetDevice(e->cfg.device));
+  { const int rcode = fe_stage(e, (size_t)n * sizeof(pba_candidate)); if (rcode) return rcode; }
+  HIP_TRY(e, hipMemcpyAsync(e->h_fe_io, e->d_fe_cand, (size_t)n * sizeof(pba_candidate), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  std::memcpy(out, e->h_fe_io, (size_t)n * sizeof(pba_candidate));
+  return PBA_OK;
+}
+
+int pba_frontend_descriptors(pba_engine* e, int32_t slot, int32_t n, const int32_t* xy, float* desc) {
+  if (!e || n < 0 || slot < 0 || slot >= e->cfg.max_frames || (n > 0 && (!xy || !desc))) return PBA_ERR_INVALID;
+  if (!e->frame_set[slot]) return fail(e, PBA_ERR_STATE, "pba_frontend_descriptors: slot %d holds no frame", slot);
+  if (n == 0) return PBA_OK;
+  PBA_NOT_POISONED(e);
+  HIP_TRY(e, hipSetDevice(e->cfg.device));
+  const int rows = e->cfg.rows, cols = e->cfg.cols, R = e->cfg.radius, P = (2 * R + 1) * (2 * R + 1);
+  const size_t npix = (size_t)rows * cols;
+  const size_t b_xy = (size_t)n * 8, b_out = (size_t)n * e->channels * P * sizeof(float);
+  int rcode;
+  if ((rcode = fe_stage(e, b_xy + b_out))) return rcode;
+  if ((rcode = dev_alloc(e, &e->d_fe_io, b_xy + b_out + (b_xy + b_out) / 4))) return rcode;
+  std::memcpy(e->h_fe_io, xy, b_xy);
+  HIP_TRY(e, hipMemcpyAsync(e->d_fe_io, e->h_fe_io, b_xy, hipMemcpyHostToDevice, e->stream));
+  const bool mc = e->channels > 1;
+  const size_t total = (size_t)n * e->channels * P;
+  hipLaunchKernelGGL(k_fe_descriptors, dim3((unsigned)std::min<size_t>((total + 255) / 256, 4096)), dim3(256), 0, e->stream,
+                     (const uint32_t*)(e->d_frames + npix * slot), mc ? (const float*)(e->d_frames_mc + (size_t)slot * e->channels * npix) : (const float*)nullptr,
+                     e->channels, rows, cols, R, n, reinterpret_cast<const int2*>(e->d_fe_io), reinterpret_cast<float*>(e->d_fe_io + b_xy));
+  HIP_TRY(e, hipGetLastError());
+  HIP_TRY(e, hipMemcpyAsync(e->h_fe_io + b_xy, e->d_fe_io + b_xy, b_out, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  std::memcpy(desc, e->h_fe_io + b_xy, b_out);
   return PBA_OK;
 }
 

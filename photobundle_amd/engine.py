@@ -104,6 +104,46 @@ class Engine:
                     "pba_set_frame_pyr_down")
         return out
 
+    # ---- device front-end (pba_frontend_*: reference photobundle.cc:505-603 on the frame in the ring) --------------------------
+    def frontend_visibility(self, uv, rc, patches26, min_score, mask_radius):
+        """ZNCC test of tracked points on the most recently uploaded u8 frame; returns the hit flags [n] (and stamps the mask)."""
+        uv = np.ascontiguousarray(uv, dtype=np.float64).reshape(-1, 2)
+        rc = np.ascontiguousarray(rc, dtype=np.int32).reshape(-1, 2)
+        pt = np.ascontiguousarray(patches26, dtype=np.float32).reshape(-1, 26)
+        n = len(uv)
+        assert len(rc) == n and len(pt) == n
+        hit = np.zeros(n, np.uint8)
+        self._check(self._L.pba_frontend_visibility(self._h, n, _ptr(uv), _ptr(rc), _ptr(pt), float(min_score), int(mask_radius), _ptr(hit)),
+                    "pba_frontend_visibility")
+        return hit
+
+    def frontend_zncc_probe(self, uv, patches26):
+        """Test hook: [n, 27] = the new frame's zero-mean 5x5 patch at uv, its norm, the score against patches26."""
+        uv = np.ascontiguousarray(uv, dtype=np.float64).reshape(-1, 2)
+        pt = np.ascontiguousarray(patches26, dtype=np.float32).reshape(-1, 26)
+        out = np.zeros((len(uv), 27), np.float32)
+        self._check(self._L.pba_frontend_zncc_probe(self._h, len(uv), _ptr(uv), _ptr(pt), _ptr(out)), "pba_frontend_zncc_probe")
+        return out
+
+    def frontend_candidates(self, slot, depth, min_depth, max_depth, nms_radius, border):
+        """Candidate scan of the frame in `slot`; returns a structured array (saliency f4, x i4, y i4) in row-major order."""
+        depth = np.ascontiguousarray(depth, dtype=np.float32)
+        assert depth.shape == (self.cfg.rows, self.cfg.cols)
+        n = C.c_int32(0)
+        self._check(self._L.pba_frontend_candidates(self._h, int(slot), _ptr(depth), float(min_depth), float(max_depth), int(nms_radius),
+                                                    int(border), C.byref(n)), "pba_frontend_candidates")
+        out = np.zeros(n.value, dtype=np.dtype([("saliency", np.float32), ("x", np.int32), ("y", np.int32)]))
+        self._check(self._L.pba_frontend_get_candidates(self._h, _ptr(out) if n.value else None, n.value), "pba_frontend_get_candidates")
+        return out
+
+    def frontend_descriptors(self, slot, xy):
+        """Integer-pixel patches at xy [n][2] = (x, y) of the frame in `slot`: [n, C, (2R+1)^2] f32."""
+        xy = np.ascontiguousarray(xy, dtype=np.int32).reshape(-1, 2)
+        P = (2 * self.cfg.radius + 1) ** 2
+        out = np.zeros((len(xy), max(1, self.cfg.channels), P), np.float32)
+        self._check(self._L.pba_frontend_descriptors(self._h, int(slot), len(xy), _ptr(xy), _ptr(out)), "pba_frontend_descriptors")
+        return out
+
     def get_frame_channel(self, slot, channel):
         out = np.empty((3, self.cfg.rows, self.cfg.cols), np.float32)
         self._check(self._L.pba_get_frame_channel(self._h, int(slot), int(channel), _ptr(out[0]), _ptr(out[1]), _ptr(out[2])),

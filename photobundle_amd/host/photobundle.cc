@@ -219,6 +219,8 @@ struct PhotometricBundleAdjustment::DescriptorFrame {
       : id(frame_id), channels(MakeChannels(img, rows, cols, type, nt)), I(channels[0]) {}
   // channel images produced elsewhere (the engine's device-side producer): [C][rows*cols]
   DescriptorFrame(uint32_t frame_id, std::vector<Image_<float>>&& ch) : id(frame_id), channels(std::move(ch)), I(channels[0]) {}
+  // device front-end: the channel images never reach the host, only their number is known here
+  DescriptorFrame(uint32_t frame_id, int n_channels) : id(frame_id), channels((size_t)n_channels), I(channels[0]) {}
   size_t numChannels() const { return channels.size(); }
   void computeSaliencyMap(Image_<float>& smap, int nt) const {
     const int rows = I.rows(), cols = I.cols();
@@ -302,9 +304,24 @@ void PhotometricBundleAdjustment::addFrame(const uint8_t* I_ptr, const float* Z_
   const int slot = (int)(_frame_id % window);
   const Options::DescriptorType dtype = _options_ptr->descriptorType;
   static const bool host_channels = std::getenv("PBA_HOST_CHANNELS") != nullptr;    // test hook: the host-side channel producers
+  // r4: visibility, saliency, candidate scan and descriptor patches run on the device, on the frame that sits in the engine anyway
+  // (pba_frontend_*); PBA_HOST_FRONTEND (test hook, implied by PBA_HOST_CHANNELS) keeps the host restatement below -- byte-identical
+  static const bool host_frontend = std::getenv("PBA_HOST_FRONTEND") != nullptr || host_channels;
+  const int n_desc_channels = dtype == Options::DescriptorType::BitPlanes ? 8 : (dtype == Options::DescriptorType::IntensityAndGradient ? 3 : 1);
   UniquePointer<DescriptorFrame> frame;
-  if (dtype != Options::DescriptorType::Intensity && !host_channels) {
-    // Multi-channel descriptors: the engine builds the channel images on the device from the u8 frame (0.47 MB up instead of
+  if (!host_frontend) {
+    if (dtype != Options::DescriptorType::Intensity) {
+      const int32_t kind = dtype == Options::DescriptorType::BitPlanes ? PBA_DESCRIPTOR_BITPLANES : PBA_DESCRIPTOR_INTENSITY_AND_GRADIENT;
+      check(_engine, pba_set_frame_descriptor_u8(_engine, slot, I_ptr, kind, 1.0f, 1.5f), "pba_set_frame_descriptor_u8");
+    } else if (_frame_resident) {
+      _frame_resident = false;                 // the pyramid class produced this level's frame on the device
+    } else {
+      check(_engine, pba_set_frame_u8(_engine, slot, I_ptr), "pba_set_frame_u8");
+    }
+    frame.reset(new DescriptorFrame(_frame_id, n_desc_channels));
+    lap(5);
+  } else if (dtype != Options::DescriptorType::Intensity && !host_channels) {
+    // (host front-end) Multi-channel descriptors: the engine builds the channel images on the device from the u8 frame (0.47 MB up instead of
     // 5.6 / 15 MB) and the front-end reads them back (saliency, descriptor patches) instead of running DescriptorFrame::Create
     // on the CPU as well -- bit-identical images (tests/test_gpu_producers.py), ~190 ms less per KITTI frame for BitPlanes.
     const int32_t kind = dtype == Options::DescriptorType::BitPlanes ? PBA_DESCRIPTOR_BITPLANES : PBA_DESCRIPTOR_INTENSITY_AND_GRADIENT;
@@ -343,9 +360,40 @@ void PhotometricBundleAdjustment::addFrame(const uint8_t* I_ptr, const float* Z_
 
   lap(0);
   // ---- visibility list update (reference :505-542) ------------------------------------------------------------
-  std::fill(_mask.d.begin(), _mask.d.end(), (uint16_t)1);
   int num_updated = 0, max_num_to_update = 0;
   double t_vis_par = 0.0; int n_vis = 0;
+  if (!host_frontend) {
+    // device: the host only projects the tracked points (double arithmetic of :519-523) and ships the ones inside the border
+    // with their stored patches; the ZNCC test and the mask live on the device (pba_frontend_visibility)
+    const int n_sp = (int)_scene_points.size();
+    std::vector<int> idx;
+    std::vector<double> uvs;
+    std::vector<int32_t> rcs;
+    std::vector<float> pats;
+    for (int k = 0; k < n_sp; ++k) {
+      const ScenePoint& pt = *_scene_points[k];
+      const int f_dist = (int)_frame_id - (int)pt.lastFrameId();
+      if (f_dist > _options_ptr->maxFrameDistance) continue;
+      ++max_num_to_update;
+      const Vec2 uv = _calib.project(TransformPoint(T_c, pt.X));
+      const int r = (int)std::round(uv[1]), c = (int)std::round(uv[0]);
+      if (r >= B && r < max_rows && c >= B && c <= max_cols) {
+        idx.push_back(k);
+        uvs.push_back(uv[0]); uvs.push_back(uv[1]);
+        rcs.push_back(r); rcs.push_back(c);
+        static_assert(sizeof(ZnccPatch) == 26 * sizeof(float), "patch record = 25 values + norm");
+        const float* pd = reinterpret_cast<const float*>(&pt.patch);
+        pats.insert(pats.end(), pd, pd + 26);
+      }
+    }
+    std::vector<uint8_t> hit(idx.size());
+    check(_engine, pba_frontend_visibility(_engine, (int32_t)idx.size(), uvs.data(), rcs.data(), pats.data(), _options_ptr->minScore, mask_radius,
+                                           hit.data()), "pba_frontend_visibility");
+    for (size_t q = 0; q < idx.size(); ++q)
+      if (hit[q]) { ++num_updated; _scene_points[idx[q]]->f.push_back(_frame_id); }
+    n_vis = n_sp;
+  } else {
+  std::fill(_mask.d.begin(), _mask.d.end(), (uint16_t)1);
   {
     // the ZNCC test of every tracked point is independent: evaluated on all host threads, applied in list order
     const int n_sp = (int)_scene_points.size();
@@ -377,10 +425,12 @@ void PhotometricBundleAdjustment::addFrame(const uint8_t* I_ptr, const float* Z_
     }
   }
 
+  }
+
   lap(1);
   // ---- new scene points (reference :545-585): valid depth AND strict local maximum of the saliency under the mask --
   ScenePointPointerList new_points;
-  frame->computeSaliencyMap(_saliency_map, nt);
+  if (host_frontend) frame->computeSaliencyMap(_saliency_map, nt);
   lap(2);
   const int nms = _options_ptr->nonMaxSuppRadius;
   auto is_local_max = [&](int row, int col) {
@@ -399,7 +449,15 @@ void PhotometricBundleAdjustment::addFrame(const uint8_t* I_ptr, const float* Z_
   // get their scene point, ZNCC patch and descriptor built.
   struct Candidate { float saliency; int x, y; };
   std::vector<Candidate> cands;
-  {
+  if (!host_frontend) {
+    // device: saliency, depth test, mask, strict local maximum; the list comes back in the row-major order of the scan below
+    static_assert(sizeof(Candidate) == sizeof(pba_candidate), "candidate record");
+    int32_t n_c = 0;
+    check(_engine, pba_frontend_candidates(_engine, slot, Z_ptr, _options_ptr->minValidDepth, _options_ptr->maxValidDepth, nms, B, &n_c),
+          "pba_frontend_candidates");
+    cands.resize((size_t)n_c);
+    check(_engine, pba_frontend_get_candidates(_engine, reinterpret_cast<pba_candidate*>(cands.data()), n_c), "pba_frontend_get_candidates");
+  } else {
     std::vector<std::vector<Candidate>> per_row(max_rows > B ? max_rows - B : 0);
 #pragma omp parallel for schedule(dynamic, 8) num_threads(nt)
     for (int y = B; y < max_rows; ++y) {
@@ -439,7 +497,16 @@ void PhotometricBundleAdjustment::addFrame(const uint8_t* I_ptr, const float* Z_
                _scene_points.empty() ? 0.0 : 100.0 * num_updated / _scene_points.size(), max_num_to_update, (int)new_points.size());
 
   // ---- descriptors (reference :466-479, :597-603): integer-pixel patch, indices clamped ------------------------
-  {
+  if (!host_frontend) {
+    const int n_new = (int)new_points.size();
+    std::vector<int32_t> xy((size_t)2 * n_new);
+    for (int k = 0; k < n_new; ++k) { xy[2 * k] = new_points[k]->x0; xy[2 * k + 1] = new_points[k]->y0; }
+    std::vector<float> dv((size_t)n_new * num_channels * patch_length);
+    check(_engine, pba_frontend_descriptors(_engine, slot, n_new, xy.data(), dv.data()), "pba_frontend_descriptors");
+    const size_t per = (size_t)num_channels * patch_length;
+    for (int k = 0; k < n_new; ++k)
+      for (size_t i = 0; i < per; ++i) new_points[k]->descriptor[i] = (double)dv[(size_t)k * per + i];
+  } else {
     const int mc = cols - radius - 1, mr = rows - radius - 1;
     for (int k = 0; k < num_channels; ++k) {
       const Image_<float>& channel = frame->channels[k];
