@@ -2452,16 +2452,20 @@ __global__ __launch_bounds__(kTile, 2) void k_schur(SchurParams p_in) {
     }
     if (grad_only) continue;      // (uniform) the barrier above already separates this tile's reads from the next tile's stores
     if (active && fa >= 0) {
+      // r4: the pair blocks are formed from the RANK-2 factors of W_l = Ac^T (M Ap) and Y_l = W_l P instead of from W | Y
+      // themselves:  Y_a W_b^T = Ac_a^T (Q_a (M Ap)_b^T) Ac_b  with  Q = (M Ap) P  (2 x 3).  Per observation 22 doubles go to
+      // LDS (Ac without the structural zeros of its translation part: rotation 2 x 3 | ju0 ju2 jv1 jv2; M Ap; Q) for 18 FMAs --
+      // it was 36 values and 90 FMAs -- and a pair block costs 92 FMAs + 32 LDS reads instead of 108 + 36 (below).
       double* so = s_obs + tid * kObsStride;
 #pragma unroll
-      for (int j = 0; j < 6; ++j) {
-        const double w0 = Ac[0][j] * MAp[0][0] + Ac[1][j] * MAp[1][0];
-        const double w1 = Ac[0][j] * MAp[0][1] + Ac[1][j] * MAp[1][1];
-        const double w2 = Ac[0][j] * MAp[0][2] + Ac[1][j] * MAp[1][2];
-        so[3 * j] = w0; so[3 * j + 1] = w1; so[3 * j + 2] = w2;
-        so[18 + 3 * j] = w0 * Pm[0] + w1 * Pm[1] + w2 * Pm[2];
-        so[18 + 3 * j + 1] = w0 * Pm[1] + w1 * Pm[3] + w2 * Pm[4];
-        so[18 + 3 * j + 2] = w0 * Pm[2] + w1 * Pm[4] + w2 * Pm[5];
+      for (int k = 0; k < 3; ++k) { so[k] = Ac[0][k]; so[3 + k] = Ac[1][k]; }
+      so[6] = Ac[0][3]; so[7] = Ac[0][5]; so[8] = Ac[1][4]; so[9] = Ac[1][5];
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        so[10 + 3 * r] = MAp[r][0]; so[11 + 3 * r] = MAp[r][1]; so[12 + 3 * r] = MAp[r][2];
+        so[16 + 3 * r] = MAp[r][0] * Pm[0] + MAp[r][1] * Pm[1] + MAp[r][2] * Pm[2];
+        so[17 + 3 * r] = MAp[r][0] * Pm[1] + MAp[r][1] * Pm[3] + MAp[r][2] * Pm[4];
+        so[18 + 3 * r] = MAp[r][0] * Pm[2] + MAp[r][1] * Pm[4] + MAp[r][2] * Pm[5];
       }
     }
     lds_barrier();
@@ -2474,16 +2478,37 @@ __global__ __launch_bounds__(kTile, 2) void k_schur(SchurParams p_in) {
       for (int q = grp; q < n_pts; q += n_groups) {
         const int la = la_row[q], lb = lb_row[q];
         if (la < 0 || lb < 0) continue;
-        const double* Y = s_obs + la * kObsStride + 18;
-        const double* Wb = s_obs + lb * kObsStride;
-        double wb[18], yy[18];
+        const double* Fa = s_obs + la * kObsStride;
+        const double* Fb = s_obs + lb * kObsStride;
+        double aa[10], qa[6], ab[10], mb[6];
 #pragma unroll
-        for (int k = 0; k < 18; ++k) { wb[k] = Wb[k]; yy[k] = Y[k]; }
+        for (int k = 0; k < 10; ++k) { aa[k] = Fa[k]; ab[k] = Fb[k]; }
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
+        for (int k = 0; k < 6; ++k) { qa[k] = Fa[16 + k]; mb[k] = Fb[10 + k]; }
+        // N = Q_a (M Ap)_b^T (2 x 2)
+        double N[2][2];
 #pragma unroll
-          for (int j = 0; j < 6; ++j)     // three chained FMAs per entry (the sum-then-subtract form costs a fourth operation)
-            acc[6 * i + j] = fma(-yy[3 * i + 2], wb[3 * j + 2], fma(-yy[3 * i + 1], wb[3 * j + 1], fma(-yy[3 * i], wb[3 * j], acc[6 * i + j])));
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) N[r][t] = fma(qa[3 * r + 2], mb[3 * t + 2], fma(qa[3 * r + 1], mb[3 * t + 1], qa[3 * r] * mb[3 * t]));
+        // Z = N Ac_b (2 x 6); Ac = [rotation (2 x 3) | ju0 0 ju2 ; 0 jv1 jv2]
+        double Z[2][6];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+#pragma unroll
+          for (int j = 0; j < 3; ++j) Z[r][j] = fma(N[r][1], ab[3 + j], N[r][0] * ab[j]);
+          Z[r][3] = N[r][0] * ab[6];
+          Z[r][4] = N[r][1] * ab[8];
+          Z[r][5] = fma(N[r][1], ab[9], N[r][0] * ab[7]);
+        }
+        // T(a, b) -= Ac_a^T Z
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+#pragma unroll
+          for (int i = 0; i < 3; ++i) acc[6 * i + j] = fma(-aa[3 + i], Z[1][j], fma(-aa[i], Z[0][j], acc[6 * i + j]));
+          acc[18 + j] = fma(-aa[6], Z[0][j], acc[18 + j]);
+          acc[24 + j] = fma(-aa[8], Z[1][j], acc[24 + j]);
+          acc[30 + j] = fma(-aa[9], Z[1][j], fma(-aa[7], Z[0][j], acc[30 + j]));
         }
       }
     }
