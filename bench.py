@@ -242,9 +242,9 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if dist is not None:
+        if dist is not None:      # (one rank: a second synchronize behind the first is 10-20 us of host API time inside the bracket)
             dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
 
     if args.warmup > 0:
         eng.solve(opts(args.warmup))

@@ -253,6 +253,12 @@ bool fused_capable(const pba_engine* e) { return e->fuse && ((e->cfg.flags >> 1)
 int sample_waves_for_radius(int) { return kSampleWaves; }
 
 __global__ void k_noop() {}
+// initial trust-region state of a solve, passed by value (a device-to-device hipMemcpyAsync of the host-mapped mirror goes through
+// the copy engine: its hand-over sat in front of the first kernel of every solve)
+#ifndef PBA_LM_INIT_KERNEL
+#define PBA_LM_INIT_KERNEL 1
+#endif
+__global__ void k_lm_init(LmState* dst, LmState st) { if (threadIdx.x == 0) *dst = st; }
 // device -> host-mapped pinned memory (8-byte words, grid-stride); visible to the host once the stream has drained
 __global__ void k_to_host(const double* __restrict__ src, double* __restrict__ dst, size_t n) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
@@ -1549,7 +1555,12 @@ int pba_internal_async_begin(pba_engine* e, const pba_solver_options* o) {
   st.max_num_iterations = o->max_num_iterations; st.max_invalid = o->max_num_consecutive_invalid_steps;
   *e->h_lm = st;
   // device copy of the initial state straight from the host-mapped mirror (stream ordered, no host sync)
-  HIP_TRY(e, hipMemcpyAsync(e->d_lm, e->h_lm_dev, sizeof(st), hipMemcpyDeviceToDevice, e->stream));
+  if (PBA_LM_INIT_KERNEL) {
+    hipLaunchKernelGGL(k_lm_init, dim3(1), dim3(64), 0, e->stream, e->d_lm, st);
+    HIP_TRY(e, hipGetLastError());
+  } else {
+    HIP_TRY(e, hipMemcpyAsync(e->d_lm, e->h_lm_dev, sizeof(st), hipMemcpyDeviceToDevice, e->stream));
+  }
   e->async_cur = e->cur;
   return PBA_OK;
 }

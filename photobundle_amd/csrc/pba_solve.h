@@ -546,6 +546,7 @@ __device__ __forceinline__ void solve_blocked(SolveParams& p, double* smem, int 
     double v = sc[c] * val[u] * sc[r];          // (rounds 1-3 scaled the mirrored entry: column scale first)
     if (r == c) v = (r < n) ? v + D2[r] : 0.0;
     A[(size_t)r * ld + c] = v;
+    if (r != c) A[(size_t)c * ld + r] = 0.0;      // strict upper triangle: zeros (the back-substitution reads whole rows unmasked)
   }
   __syncthreads();
   if (p.S_dbg) {
@@ -708,25 +709,31 @@ __device__ __forceinline__ void solve_blocked(SolveParams& p, double* smem, int 
         }
       }
     }
+    // the panel wave stored its six-column rows whole: inside a diagonal block the entries on and right of the diagonal (l_jj = 1
+    // and unused values) become zeros, so that row j of A is L[j][i] for i < j and 0 beyond -- the masks of the substitution's loads
+    // (a compare and two selects per value on the one wave everybody waits for) are paid here, once, by all threads
+    for (int t = tid; t < n; t += T) {
+      const int c0 = 6 * (t / 6);
+#pragma unroll
+      for (int m = 0; m < 6; ++m) if (c0 + m >= t) A[(size_t)t * ld + c0 + m] = 0.0;
+    }
+    __syncthreads();
     PBA_TS(3);
     // ---- backward substitution L^T x = z (z = row n = D^-1 L^-1 y, L unit lower): the panel wave alone ----------------
     // Solution vector in registers (lane i <-> unknown i, two per lane beyond 64); column j: x_j = z_j of lane j (one
-    // v_readlane pair), z_i -= L[j][i] x_j for i < j.  The rows of L come in chunks of six, masked at load time (zero for i >= j:
-    // no select on the dependency chain) and double-buffered in two register sets (no copies, so the wait for a chunk sits
-    // one chunk after its loads).
+    // v_readlane pair), z_i -= L[j][i] x_j for i < j.  The rows of L come in chunks of six straight out of A (zero for i >= j, see
+    // above: nothing but the FMA on the dependency chain) and are double-buffered in two register sets (no copies, so the wait
+    // for a chunk sits one chunk after its loads).
     if (wave == 0) {
       double z[ROWS];
 #pragma unroll
       for (int q = 0; q < ROWS; ++q) { const int i = lane + 64 * q; z[q] = (i < n) ? A[(size_t)n * ld + i] : 0.0; }
+      const double* Arow = A + (lane < n ? lane : 0);      // (lanes beyond the system -- and 64 + lane > n -- read in-bounds junk into unknowns nobody uses)
       auto load_chunk = [&](int jb, double (&L6)[6][ROWS]) {
 #pragma unroll
         for (int u = 0; u < 6; ++u)
 #pragma unroll
-          for (int q = 0; q < ROWS; ++q) {
-            const int i = lane + 64 * q, j = jb + u;
-            const double v = A[(size_t)j * ld + (i < n ? i : 0)];
-            L6[u][q] = (i < j) ? v : 0.0;
-          }
+          for (int q = 0; q < ROWS; ++q) L6[u][q] = Arow[(size_t)(jb + u) * ld + 64 * q];      // (zero on and right of the diagonal)
       };
       auto apply_chunk = [&](int jb, const double (&L6)[6][ROWS]) {
 #pragma unroll
