@@ -1109,8 +1109,16 @@ void k_sample(SampleParams p_in) {
   constexpr size_t kPreBytes = sizeof(double) * 3 * WAVES * 64 + 2 * kMaxFrames * sizeof(CamGeom);
   __shared__ __attribute__((aligned(16))) char s_raw[kTexBytes > kPreBytes ? kTexBytes : kPreBytes];
   uint32_t (*s_tex)[FF * LSTRIDE] = reinterpret_cast<uint32_t (*)[FF * LSTRIDE]>(s_raw);
-  __shared__ int32_t s_base[WAVES][64];
-  __shared__ int32_t s_irr[WAVES][64];   // (by0 << 16) | bx0: window anchor of the observations staged with clamped coordinates
+  __shared__ __attribute__((aligned(8))) int32_t s_bi[2][WAVES][64];
+  int32_t (*s_base)[64] = s_bi[0];
+  int32_t (*s_irr)[64] = s_bi[1];        // (by0 << 16) | bx0: window anchor of the observations staged with clamped coordinates
+  // r4: the windowed irregular observations of the WHOLE workgroup go through one queue and are dealt round robin to its four
+  // waves (the wave that owned three border patches used to hold the other three -- and their LDS -- for its per-tap passes)
+  struct IrrRec { double u, v; int32_t wyx, pt, src, pad; };
+  constexpr int kIrrCap = 32;
+  __shared__ IrrRec s_q[(sample_rows_per_batch(R) == 2 * R + 2) ? kIrrCap : 1];
+  __shared__ int32_t s_icnt[WAVES];
+  static_assert(sizeof(double) * 6 * kIrrCap <= sizeof(int32_t) * 2 * WAVES * 64, "the six sums of every queued patch fit s_base | s_irr");
   __shared__ uint32_t s_win[(sample_rows_per_batch(R) == 2 * R + 2) ? 1 : WAVES][(sample_rows_per_batch(R) == 2 * R + 2) ? 1 : (2 * R + 2) * (2 * R + 2)];   // large radii: the clamped window of ONE irregular observation per wave
   __shared__ double s_red[4 * WAVES];
   __shared__ int32_t s_fail;
@@ -1226,7 +1234,22 @@ void k_sample(SampleParams p_in) {
   // >= 0: regular, linear texel index of the footprint origin;  -1: nothing to stage;  <= -2: windowed irregular, slot
   s_base[wave][lane] = (active && regular) ? (int32_t)(slot * (p.rows * p.cols) + by * p.cols + bx) : (((kWindow && win_irr) || reg_clamped) ? -2 - slot : -1);
   s_irr[wave][lane] = (by0 << 16) | bx0;
+  const unsigned long long im_all = kWindow ? __ballot(win_irr) : 0ull;
+  if (kWindow && lane == 0) s_icnt[wave] = __popcll(im_all);
   lds_barrier();
+  // workgroup-uniform: how many windowed irregular observations the four waves hold together, and where this wave's start in the queue
+  int q_off = 0, q_total = 0;
+  if (kWindow) {
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) { const int c = s_icnt[w]; q_off += (w < wave) ? c : 0; q_total += c; }
+  }
+  const bool share_irr = kWindow && q_total > 1 && q_total <= kIrrCap;
+  int my_q = -1;
+  if (share_irr && win_irr) {
+    my_q = q_off + __popcll(im_all & ((1ull << lane) - 1ull));
+    IrrRec rcd; rcd.u = u; rcd.v = v; rcd.wyx = (by0 << 16) | bx0; rcd.pt = pt; rcd.src = (wave << 8) | lane; rcd.pad = 0;
+    s_q[my_q] = rcd;
+  }
   PBA_STK(2);
 
   // ---- phases 2 + 3, per batch of RB footprint rows: cooperative staging global -> LDS, then the per-lane walk -----
@@ -1487,10 +1510,66 @@ void k_sample(SampleParams p_in) {
   if constexpr (kWindow) {
     // Windowed irregular observations, one at a time with the WAVE on one patch: lane = pixel (W^2 <= 25 lanes busy), the
     // reference's per-tap rule (sample_eigen.h:38-51, :82-101) with the four texels of the pixel taken from the staged
-    // window of lane `src`, then six fixed-order wave reductions.  A lane-serial walk of the per-tap rule costs ~3x the
-    // regular walk and every lane of the wave waits for it; this costs ~200 instructions per irregular observation.
+    // window `tw` (texel-major, stride LSTRIDE) of the observation, then six fixed-order wave reductions.  A lane-serial walk of
+    // the per-tap rule costs ~3x the regular walk and every lane of the wave waits for it; this costs ~200 instructions per
+    // irregular observation.
     static_assert(W * W <= 64, "one lane per pixel");
-    unsigned long long im = __ballot(win_irr);
+    auto patch_sums = [&](double us, double vs, int wy, int wx, const uint32_t* tw, float dsc_px, double (&q6)[6]) {
+      double q_cc = 0.0, q11 = 0.0, q12 = 0.0, q22 = 0.0, q1 = 0.0, q2 = 0.0;
+      if (lane < W * W) {
+        const int i = lane / W, j = lane - i * W;
+        const float yfi = (float)(vs + (double)(i - R)), xfj = (float)(us + (double)(j - R));
+        int y1, y2, x1, x2; float dy, dx;
+        linear_init_axis(yfi, p.rows, y1, y2, dy);
+        linear_init_axis(xfj, p.cols, x1, x2, dx);
+        const float omdy = __fsub_rn(1.0f, dy);
+        const double omdxj = __dsub_rn(1.0, (double)dx);
+        const int o1 = (y1 - wy) * F - wx, o2 = (y2 - wy) * F - wx;
+        const uint32_t t11 = tw[(o1 + x1) * LSTRIDE], t12 = tw[(o1 + x2) * LSTRIDE];
+        const uint32_t t21 = tw[(o2 + x1) * LSTRIDE], t22 = tw[(o2 + x2) * LSTRIDE];
+        const float sI = vlerp_exact(dy, omdy, hlerp_exact(dx, omdxj, tex_I(t11), tex_I(t12)), hlerp_exact(dx, omdxj, tex_I(t21), tex_I(t22)));
+        const double e = (double)dsc_px - (double)sI;
+        const double w2 = UNITW ? 1.0 : p.w2[lane];
+        q_cc = w2 * e * e;
+        if (JAC) {
+          const double gx = (double)(0.5f * vlerp_exact(dy, omdy, hlerp_exact(dx, omdxj, tex_gx2(t11), tex_gx2(t12)), hlerp_exact(dx, omdxj, tex_gx2(t21), tex_gx2(t22))));
+          const double gy = (double)(0.5f * vlerp_exact(dy, omdy, hlerp_exact(dx, omdxj, tex_gy2(t11), tex_gy2(t12)), hlerp_exact(dx, omdxj, tex_gy2(t21), tex_gy2(t22))));
+          const double wgx = w2 * gx, wgy = w2 * gy;
+          q11 = wgx * gx; q12 = wgx * gy; q22 = wgy * gy; q1 = wgx * e; q2 = wgy * e;
+        }
+      }
+      q6[0] = q_cc; q6[1] = q11; q6[2] = q12; q6[3] = q22; q6[4] = q1; q6[5] = q2;
+      if (JAC) wave_sum_n<6>(q6);
+      else q6[0] = wave_sum(q6[0]);
+    };
+    if (share_irr) {
+      // ---- the workgroup's queue, dealt round robin: wave w takes entries w, w + WAVES, ... (same sums, same order inside a patch:
+      // the result does not depend on who computes it).  Two workgroup barriers, paid only by workgroups that hold such patches.
+      lds_barrier();                                   // every wave's windows are staged, every record is written, s_base | s_irr are dead
+      double* s_res = reinterpret_cast<double*>(&s_bi[0][0][0]);
+      for (int q0 = wave; q0 < q_total; q0 += 4 * WAVES) {
+        // up to four patches per trip: their descriptor values (lane = pixel) are requested together
+        float dsc[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int q = q0 + k * WAVES;
+          dsc[k] = (q < q_total && lane < W * W) ? p.desc[(size_t)s_q[q < q_total ? q : 0].pt * (W * W) + lane] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int q = q0 + k * WAVES;
+          if (q >= q_total) break;
+          const IrrRec rcd = s_q[q];
+          const int sw = rcd.src >> 8, sl = rcd.src & 0xff;
+          double q6[6];
+          patch_sums(rcd.u, rcd.v, rcd.wyx >> 16, rcd.wyx & 0xffff, &s_tex[sw][sl], dsc[k], q6);
+          if (lane < 6) s_res[6 * q + lane] = (lane == 0) ? q6[0] : (lane == 1 ? q6[1] : (lane == 2 ? q6[2] : (lane == 3 ? q6[3] : (lane == 4 ? q6[4] : q6[5]))));
+        }
+      }
+      lds_barrier();
+      if (my_q >= 0) { cc = s_res[6 * my_q]; m11 = s_res[6 * my_q + 1]; m12 = s_res[6 * my_q + 2]; m22 = s_res[6 * my_q + 3]; b1 = s_res[6 * my_q + 4]; b2 = s_res[6 * my_q + 5]; }
+    } else {
+    unsigned long long im = im_all;
     while (im) {
       // up to four irregular observations per trip: their descriptor values (lane = pixel) are requested together, so
       // that one global round trip serves four patches
@@ -1504,43 +1583,15 @@ void k_sample(SampleParams p_in) {
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-      const int src = srcs[k];
-      if (src < 0) break;
-      const double us = readlane_f64(u, src), vs = readlane_f64(v, src);
-      const int wy = __builtin_amdgcn_readlane(by0, src), wx = __builtin_amdgcn_readlane(bx0, src);
-      double q_cc = 0.0, q11 = 0.0, q12 = 0.0, q22 = 0.0, q1 = 0.0, q2 = 0.0;
-      if (lane < W * W) {
-        const int i = lane / W, j = lane - i * W;
-        const float yfi = (float)(vs + (double)(i - R)), xfj = (float)(us + (double)(j - R));
-        int y1, y2, x1, x2; float dy, dx;
-        linear_init_axis(yfi, p.rows, y1, y2, dy);
-        linear_init_axis(xfj, p.cols, x1, x2, dx);
-        const float omdy = __fsub_rn(1.0f, dy);
-        const double omdxj = __dsub_rn(1.0, (double)dx);
-        const uint32_t* tw = &s_tex[wave][src];
-        const int o1 = (y1 - wy) * F - wx, o2 = (y2 - wy) * F - wx;
-        const uint32_t t11 = tw[(o1 + x1) * LSTRIDE], t12 = tw[(o1 + x2) * LSTRIDE];
-        const uint32_t t21 = tw[(o2 + x1) * LSTRIDE], t22 = tw[(o2 + x2) * LSTRIDE];
-        const float sI = vlerp_exact(dy, omdy, hlerp_exact(dx, omdxj, tex_I(t11), tex_I(t12)), hlerp_exact(dx, omdxj, tex_I(t21), tex_I(t22)));
-        const double e = (double)dsc[k] - (double)sI;
-        const double w2 = UNITW ? 1.0 : p.w2[lane];
-        q_cc = w2 * e * e;
-        if (JAC) {
-          const double gx = (double)(0.5f * vlerp_exact(dy, omdy, hlerp_exact(dx, omdxj, tex_gx2(t11), tex_gx2(t12)), hlerp_exact(dx, omdxj, tex_gx2(t21), tex_gx2(t22))));
-          const double gy = (double)(0.5f * vlerp_exact(dy, omdy, hlerp_exact(dx, omdxj, tex_gy2(t11), tex_gy2(t12)), hlerp_exact(dx, omdxj, tex_gy2(t21), tex_gy2(t22))));
-          const double wgx = w2 * gx, wgy = w2 * gy;
-          q11 = wgx * gx; q12 = wgx * gy; q22 = wgy * gy; q1 = wgx * e; q2 = wgy * e;
-        }
+        const int src = srcs[k];
+        if (src < 0) break;
+        const double us = readlane_f64(u, src), vs = readlane_f64(v, src);
+        const int wy = __builtin_amdgcn_readlane(by0, src), wx = __builtin_amdgcn_readlane(bx0, src);
+        double q6[6];
+        patch_sums(us, vs, wy, wx, &s_tex[wave][src], dsc[k], q6);
+        if (lane == src) { cc = q6[0]; m11 = q6[1]; m12 = q6[2]; m22 = q6[3]; b1 = q6[4]; b2 = q6[5]; }
       }
-      if (JAC) {
-        double q6[6] = {q_cc, q11, q12, q22, q1, q2};
-        wave_sum_n<6>(q6);
-        q_cc = q6[0]; q11 = q6[1]; q12 = q6[2]; q22 = q6[3]; q1 = q6[4]; q2 = q6[5];
-      } else {
-        q_cc = wave_sum(q_cc);
-      }
-      if (lane == src) { cc = q_cc; m11 = q11; m12 = q12; m22 = q22; b1 = q1; b2 = q2; }
-      }
+    }
     }
   }
   if constexpr (!kWindow) {
