@@ -1068,6 +1068,16 @@ int pba_set_cameras(pba_engine* e, const double* cams6, int32_t n_frames, int32_
   e->n_pairs = e->n_free * (e->n_free + 1) / 2;
   e->part_stride = 36 * e->n_pairs + 3 * 6 * e->n_free + 3;
   if (e->n_pairs > kTile) return fail(e, PBA_ERR_INVALID, "too many free cameras for the Schur tile (%d pairs)", e->n_pairs);
+  {
+    // the reduced solve keeps the whole augmented matrix in LDS (dynamic) next to ~21 KB of static LDS: fits the 160 KB of a
+    // gfx950 CU at every supported window; a device with less (gfx90a / gfx942: 64 KB) gets a clear error instead of a failed launch
+    int lds_max = 0;
+    if (hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, e->cfg.device) == hipSuccess && lds_max > 0) {
+      const size_t need = solve_blocked_smem_bytes(6 * e->n_free) + 22 * 1024;
+      if (need > (size_t)lds_max)
+        return fail(e, PBA_ERR_INVALID, "%d free cameras need %zu bytes of LDS for the reduced solve, the device offers %d per workgroup", e->n_free, need, lds_max);
+    }
+  }
   int rc;
   if ((rc = dev_alloc(e, &e->d_partial, (size_t)(256 * 4) * (((size_t)e->part_stride + 15) / 16 * 16)))) return rc;      // [entry / 16][workgroup][16]
   if ((rc = dev_alloc(e, &e->d_red, (size_t)pba_engine::kChunks * e->part_stride))) return rc;

@@ -237,3 +237,96 @@ def trajectory_consistency(p, engine, ks, options_fn, rtol=1e-12):
         assert d <= rtol, (k, res["final_cost"], c_ref, d)
         worst = max(worst, d)
     return worst
+
+
+# ---- extended-precision arbiter of one LM step ---------------------------------------------------------------------
+def _inv3(A):
+    a, b, c, d, e, f, g, h, i = [A[:, r, s] for r in range(3) for s in range(3)]
+    det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g)
+    out = np.stack([e * i - f * h, c * h - b * i, b * f - c * e, f * g - d * i, a * i - c * g, c * d - a * f,
+                    d * h - e * g, b * g - a * h, a * e - b * d], 1).reshape(-1, 3, 3)
+    return out / det[:, None, None]
+
+
+def _chol_solve(S, r):
+    n = len(r)
+    L = np.zeros_like(S)
+    for j in range(n):
+        L[j, j] = np.sqrt(S[j, j] - (L[j, :j] * L[j, :j]).sum())
+        L[j + 1:, j] = (S[j + 1:, j] - L[j + 1:, :j] @ L[j, :j]) / L[j, j]
+    y = np.zeros_like(r)
+    for j in range(n):
+        y[j] = (r[j] - (L[j, :j] * y[:j]).sum()) / L[j, j]
+    x = np.zeros_like(r)
+    for j in range(n - 1, -1, -1):
+        x[j] = (y[j] - (L[j + 1:, j] * x[j + 1:]).sum()) / L[j, j]
+    return x
+
+
+def block_step(p, bp, radius, scale, dt):
+    """One Ceres LM camera step from per-block products `bp` (oracle.block_products) in numpy dtype `dt` (np.longdouble = x87
+    extended precision on the x86 hosts used here; numpy.linalg has no longdouble, hence the hand-written 3x3 inverses and
+    Cholesky): Jacobi scaling 1 / (1 + sqrt(diag)) (fixed from the first call: pass the returned `scale` back in), damping
+    clip(diag, 1e-6, 1e32) / radius, point elimination, dense solve.  Returns (camera step [n_free, 6], scale, S)."""
+    free = [c for c in range(p.n_frames) if c != p.fixed_slot]
+    col = -np.ones(p.n_frames, int)
+    col[free] = np.arange(len(free))
+    nf, npt = len(free), p.n_points
+    oc, op = col[p.obs_slot], p.obs_point
+    m = oc >= 0
+    Hcc, gc = np.zeros((nf, 6, 6), dt), np.zeros((nf, 6), dt)
+    Hpp, gp = np.zeros((npt, 3, 3), dt), np.zeros((npt, 3), dt)
+    np.add.at(Hcc, oc[m], bp["JcJc"][m].astype(dt))
+    np.add.at(gc, oc[m], bp["Jcr"][m].astype(dt))
+    np.add.at(Hpp, op, bp["JpJp"].astype(dt))
+    np.add.at(gp, op, bp["Jpr"].astype(dt))
+    if scale is None:
+        scale = (1 / (1 + np.sqrt(np.einsum("nii->ni", Hcc))), 1 / (1 + np.sqrt(np.einsum("nii->ni", Hpp))))
+    sc, sp = scale
+    Hcc, gc = Hcc * sc[:, :, None] * sc[:, None, :], gc * sc
+    Hpp, gp = Hpp * sp[:, :, None] * sp[:, None, :], gp * sp
+    for H in (Hcc, Hpp):
+        k = H.shape[1]
+        H[:, np.arange(k), np.arange(k)] += np.clip(np.einsum("nii->ni", H), dt(1e-6), dt(1e32)) / dt(radius)
+    E = bp["JcJp"].astype(dt) * sc[np.maximum(oc, 0)][:, :, None] * sp[op][:, None, :]
+    Ci = _inv3(Hpp)
+    n = 6 * nf
+    S, rhs = np.zeros((n, n), dt), gc.reshape(-1).copy()
+    for a in range(nf):
+        S[6 * a:6 * a + 6, 6 * a:6 * a + 6] = Hcc[a]
+    begin = np.searchsorted(op, np.arange(npt + 1))
+    for pt in range(npt):
+        o = np.arange(begin[pt], begin[pt + 1])
+        o = o[m[o]]
+        if not len(o):
+            continue
+        W = E[o] @ Ci[pt]                                      # [k, 6, 3]
+        idx = (6 * oc[o][:, None] + np.arange(6)[None]).reshape(-1)
+        S[np.ix_(idx, idx)] -= np.einsum("aij,bkj->aibk", W, E[o]).reshape(len(idx), len(idx))
+        rhs[idx] -= (W @ gp[pt]).reshape(-1)
+    return -(_chol_solve(S, rhs).reshape(nf, 6) * sc), scale, S
+
+
+def step_accuracy(p, iterations):
+    """Accuracy of the engine's LM camera step, iteration by iteration along its own path (radius 1e4 x 3^i, every step accepted =
+    the path of the first iterations of a solve): at the engine's state the oracle's per-block products (double) are turned into
+    the camera step in x87 extended precision ("exact for these blocks") and, by the same code, in float64 ("what double
+    arithmetic gives").  Returns [(iteration, cond(S), |engine - exact|, |float64 - exact|)] relative to the largest step entry."""
+    free = [c for c in range(p.n_frames) if c != p.fixed_slot]
+    rows = []
+    with make_engine(p) as e:
+        e.linearize()
+        scale_x = scale_d = None
+        for it in range(iterations):
+            c0, x0 = [a.copy() for a in e.get_state()]
+            bp = oracle.block_products(p, autodiff=True, threads=8, cams=c0, xyz=x0)
+            radius = 1e4 * 3.0 ** it
+            e.step(radius, init_scale=(it == 0))
+            e.accept()
+            e.linearize()
+            d_e = (e.get_state()[0] - c0)[free]
+            d_x, scale_x, S = block_step(p, bp, radius, scale_x, np.longdouble)
+            d_d, scale_d, _ = block_step(p, bp, radius, scale_d, np.float64)
+            nrm = np.abs(d_x).max()
+            rows.append((it, float(np.linalg.cond(S.astype(np.float64))), float(np.abs(d_e - d_x).max() / nrm), float(np.abs(d_d - d_x).max() / nrm)))
+    return rows

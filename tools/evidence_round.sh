@@ -1,9 +1,10 @@
 #!/bin/bash
-# GPU box: profile data of the final build + the whole suite + bench matrix (round 3 final evidence)
+# GPU box: profile data of the final build + the whole suite + bench matrix (final evidence of a round: tools/evidence_round.sh <tag, e.g. r04final>)
 set -u
+TAG=${1:-r04final}
 mkdir -p gpurun_out/g     # bench matrix + rocprof + whole GPU suite of one round (copy what you keep into profiles/rNN/)
-bash tools/profile_round.sh r03final > gpurun_out/g/profile.log 2>&1
-find gpurun_out/prof_r03final -name "*.rocpd" -delete; find gpurun_out/prof_r03final -name "*.db" -delete
+bash tools/profile_round.sh $TAG > gpurun_out/g/profile.log 2>&1
+find gpurun_out/prof_$TAG -name "*.rocpd" -delete; find gpurun_out/prof_$TAG -name "*.db" -delete
 python bench.py --steps 20 --warmup 5 > gpurun_out/g/bench_driver_args.json 2> /dev/null
 python bench.py --no-cpu-baseline --steps 20 --repeats 9 --config 3 > gpurun_out/g/bench_config3.json 2> /dev/null
 python bench.py --no-cpu-baseline --steps 20 --repeats 9 --config 4 > gpurun_out/g/bench_config4.json 2> /dev/null
@@ -12,6 +13,8 @@ python bench.py --no-cpu-baseline --steps 20 --repeats 9 --channels 8 > gpurun_o
 python bench.py --no-cpu-baseline --steps 20 --repeats 9 --inverse-depth > gpurun_out/g/bench_inverse_depth.json 2> /dev/null
 PBA_BENCH_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 20 --warmup 3 --repeats 9 --points 25000 > gpurun_out/g/bench_2ranks_1gpu_peer.json 2> /dev/null
 PBA_PEER=0 PBA_BENCH_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29534 bench.py --gpus 2 --steps 20 --warmup 3 --repeats 9 --points 25000 > gpurun_out/g/bench_2ranks_1gpu_hoststaged.json 2> /dev/null
+python bench.py --config 3 --emulate-rank-of 8 --steps 20 --repeats 9 > gpurun_out/g/config3_rank_of_8.json 2> /dev/null
+PBA_RANDOM_CASES=160 timeout 1500 python -m pytest tests/test_gpu_random_shapes.py -q -m gpu 2>&1 | grep -E "passed|failed" > gpurun_out/g/random_sweep_160.txt
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/g/stats3" -o s -- python $OLDPWD/bench.py --no-cpu-baseline --repeats 3 --steps 20 --config 3 > /dev/null 2>&1
 cd "$OLDPWD"
