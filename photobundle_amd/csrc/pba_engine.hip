@@ -119,6 +119,7 @@ struct pba_engine {
   int async_cur = 0;                // parity assumed at enqueue time
   bool use_async = true;            // PBA_ASYNC=0 disables
   double wait_timeout_s = 120.0;    // PBA_WAIT_TIMEOUT_S: watchdog of the publication waits
+  double tick_hz = 1e8;             // rate of s_memrealtime (hipDeviceAttributeWallClockRate; 100 MHz on gfx950): device-side time-outs
   bool poisoned = false;            // a publication wait timed out: the stream still holds the stalled work, every later
                                     // call fails fast and pba_destroy neither waits for the stream nor for the collective
   unsigned long long* d_dbg = nullptr;   // PBA_SCHUR_TIMING diagnostics
@@ -318,7 +319,7 @@ double* peer_slot(pba_engine* e, int kind) {
 int peer_allreduce(pba_engine* e, int kind, int n, double* out) {
   const unsigned long long x = ++(kind == 0 ? e->comm.seq_a : e->comm.seq_b);
   // device-side wait: half the host watchdog (100 MHz s_memrealtime), so that the recoverable PBA_ERR_COMM wins the race
-  const unsigned long long ticks = (unsigned long long)(0.5 * e->wait_timeout_s * 1e8);
+  const unsigned long long ticks = (unsigned long long)(0.5 * e->wait_timeout_s * e->tick_hz);
   const int grid = std::max(1, std::min(32, (n + 255) / 256));
   hipLaunchKernelGGL(k_peer_allreduce, dim3(grid), dim3(256), 0, e->stream, peer_params(e), (int)Comm::flag_index(kind, x),
                      (unsigned long long)Comm::data_offset(kind, x), n, x, out, ticks, e->h_comm_err_dev);
@@ -362,7 +363,7 @@ int launch_reduce_and_solve(pba_engine* e, SolveParams so, int n, int cur, int c
     fp.peer_own = e->comm.mb_own; fp.peer_flag = (int)Comm::flag_index(0, x); fp.peer_seq = x;
     so.peer = peer_params(e); so.peer_world = e->comm.world; so.peer_flag = (int)Comm::flag_index(0, x);
     so.peer_off = (unsigned long long)Comm::data_offset(0, x); so.peer_seq = x;
-    so.peer_timeout = (unsigned long long)(0.5 * e->wait_timeout_s * 1e8);      // device-side wait: half the host watchdog, so that the recoverable error wins
+    so.peer_timeout = (unsigned long long)(0.5 * e->wait_timeout_s * e->tick_hz);      // device-side wait: half the host watchdog, so that the recoverable error wins
     so.peer_err = e->h_comm_err_dev;
   }
   ev_begin(e, 3);
@@ -535,6 +536,7 @@ int pba_create(const pba_config* cfg, pba_engine** out) {
   if (const char* sv = getenv("PBA_FUSE")) e->fuse = atoi(sv) != 0;
   if (const char* sv = getenv("PBA_ASYNC")) e->use_async = atoi(sv) != 0;
   if (const char* sv = getenv("PBA_WAIT_TIMEOUT_S")) { const double v = atof(sv); if (v > 0.0) e->wait_timeout_s = v; }
+  { int khz = 0; if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, cfg->device) == hipSuccess && khz > 0) e->tick_hz = 1e3 * khz; }
   if ((rc = dev_alloc(e, &e->d_lm, (size_t)1))) return bail(rc);
   if (hipHostMalloc(reinterpret_cast<void**>(&e->h_lm), sizeof(LmState), hipHostMallocMapped) != hipSuccess) return bail(PBA_ERR_HIP);
   if (hipHostGetDevicePointer(reinterpret_cast<void**>(&e->h_lm_dev), e->h_lm, 0) != hipSuccess) return bail(PBA_ERR_HIP);
@@ -1673,7 +1675,7 @@ int pba_internal_async_enqueue(pba_engine* e, int kind, int init_scale, const pb
     if (fused_x) {
       dp.peer = peer_params(e); dp.peer_world = e->comm.world; dp.peer_flag = (int)Comm::flag_index(1, fused_x);
       dp.peer_off = (unsigned long long)Comm::data_offset(1, fused_x); dp.peer_seq = fused_x;
-      dp.peer_timeout = (unsigned long long)(0.5 * e->wait_timeout_s * 1e8); dp.peer_err = e->h_comm_err_dev;
+      dp.peer_timeout = (unsigned long long)(0.5 * e->wait_timeout_s * e->tick_hz); dp.peer_err = e->h_comm_err_dev;
     }
     dp.lm = e->d_lm; dp.host_state = e->h_lm_dev; dp.scal = e->d_scal; dp.host_scal = e->h_scal_dev; dp.log = e->d_log;
     dp.xchg = (multi && !fused_x) ? e->d_xchg : nullptr; dp.world = e->comm.world;
