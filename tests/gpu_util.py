@@ -263,11 +263,10 @@ def _chol_solve(S, r):
     return x
 
 
-def block_step(p, bp, radius, scale, dt):
-    """One Ceres LM camera step from per-block products `bp` (oracle.block_products) in numpy dtype `dt` (np.longdouble = x87
-    extended precision on the x86 hosts used here; numpy.linalg has no longdouble, hence the hand-written 3x3 inverses and
-    Cholesky): Jacobi scaling 1 / (1 + sqrt(diag)) (fixed from the first call: pass the returned `scale` back in), damping
-    clip(diag, 1e-6, 1e32) / radius, point elimination, dense solve.  Returns (camera step [n_free, 6], scale, S)."""
+def block_system(p, bp, radius, scale, dt):
+    """The Jacobi-scaled, damped normal equations of one Ceres LM step from per-block products `bp` in numpy dtype `dt`: scaling
+    1 / (1 + sqrt(diag)) (fixed from the first call: pass the returned `scale` back in), damping clip(diag, 1e-6, 1e32) / radius.
+    Returns (dict(Hcc [n_free, 6, 6], Hpp [n_points, 3, 3], E [n_obs, 6, 3], gc, gp, oc, op, m, sc, sp), scale)."""
     free = [c for c in range(p.n_frames) if c != p.fixed_slot]
     col = -np.ones(p.n_frames, int)
     col[free] = np.arange(len(free))
@@ -289,11 +288,22 @@ def block_step(p, bp, radius, scale, dt):
         k = H.shape[1]
         H[:, np.arange(k), np.arange(k)] += np.clip(np.einsum("nii->ni", H), dt(1e-6), dt(1e32)) / dt(radius)
     E = bp["JcJp"].astype(dt) * sc[np.maximum(oc, 0)][:, :, None] * sp[op][:, None, :]
-    Ci = _inv3(Hpp)
+    E[~m] = 0
+    return dict(Hcc=Hcc, Hpp=Hpp, E=E, gc=gc, gp=gp, oc=oc, op=op, m=m, sc=sc, sp=sp), scale
+
+
+def block_step(p, bp, radius, scale, dt):
+    """One Ceres LM step from per-block products `bp` (oracle.block_products or record_blocks) in numpy dtype `dt` (np.longdouble = x87
+    extended precision on the x86 hosts used here; numpy.linalg has no longdouble, hence the hand-written 3x3 inverses and Cholesky):
+    block_system, point elimination, dense solve, back-substitution.  Returns (camera step [n_free, 6], scale, S, point step [n_points, 3])."""
+    y, scale = block_system(p, bp, radius, scale, dt)
+    nf, npt = len(y["Hcc"]), p.n_points
+    oc, op, m, E = y["oc"], y["op"], y["m"], y["E"]
+    Ci = _inv3(y["Hpp"])
     n = 6 * nf
-    S, rhs = np.zeros((n, n), dt), gc.reshape(-1).copy()
+    S, rhs = np.zeros((n, n), dt), y["gc"].reshape(-1).copy()
     for a in range(nf):
-        S[6 * a:6 * a + 6, 6 * a:6 * a + 6] = Hcc[a]
+        S[6 * a:6 * a + 6, 6 * a:6 * a + 6] = y["Hcc"][a]
     begin = np.searchsorted(op, np.arange(npt + 1))
     for pt in range(npt):
         o = np.arange(begin[pt], begin[pt + 1])
@@ -303,30 +313,80 @@ def block_step(p, bp, radius, scale, dt):
         W = E[o] @ Ci[pt]                                      # [k, 6, 3]
         idx = (6 * oc[o][:, None] + np.arange(6)[None]).reshape(-1)
         S[np.ix_(idx, idx)] -= np.einsum("aij,bkj->aibk", W, E[o]).reshape(len(idx), len(idx))
-        rhs[idx] -= (W @ gp[pt]).reshape(-1)
-    return -(_chol_solve(S, rhs).reshape(nf, 6) * sc), scale, S
+        rhs[idx] -= (W @ y["gp"][pt]).reshape(-1)
+    yc = _chol_solve(S, rhs).reshape(nf, 6)
+    t = y["gp"].copy()                                         # y_p = C^-1 (g_p - E^T y_c)
+    np.subtract.at(t, op[m], np.einsum("nij,ni->nj", E[m], yc[oc[m]]))
+    yp = np.einsum("nij,nj->ni", Ci, t)
+    return -(yc * y["sc"]), scale, S, -(yp * y["sp"])
+
+
+def backward_error(p, bp, radius, scale, d_c, d_p):
+    """Backward error of a step (d_c [n_free, 6], d_p [n_points, 3], unscaled) as a solution of the FULL scaled, damped normal equations
+    H y = g built from `bp`, residual in x87 extended precision, normwise within the camera rows and within the point rows:
+    max(max_i |H y - g|_i / max_i (|H| |y| + |g|)_i) over the two groups (a purely componentwise measure is not bounded for an
+    elimination-based solver: it reaches 1e-9 for the float64 restatement on some windows; one norm over all rows lets the point rows
+    swamp the camera rows).  A stable solver sits at 1e-16 .. 1e-13 whatever the conditioning; a wrong damping, scale or block shows
+    at its own size."""
+    dt = np.longdouble
+    y, _ = block_system(p, bp, radius, scale, dt)
+    oc, op, m, E = y["oc"], y["op"], y["m"], y["E"]
+    yc, yp = -(d_c.astype(dt) / y["sc"]), -(d_p.astype(dt) / y["sp"])
+    rc = np.einsum("nij,nj->ni", y["Hcc"], yc) - y["gc"]
+    np.add.at(rc, oc[m], np.einsum("nij,nj->ni", E[m], yp[op[m]]))
+    rp = np.einsum("nij,nj->ni", y["Hpp"], yp) - y["gp"]
+    np.add.at(rp, op[m], np.einsum("nij,ni->nj", E[m], yc[oc[m]]))
+    ac = np.einsum("nij,nj->ni", np.abs(y["Hcc"]), np.abs(yc)) + np.abs(y["gc"])
+    np.add.at(ac, oc[m], np.einsum("nij,nj->ni", np.abs(E[m]), np.abs(yp[op[m]])))
+    ap = np.einsum("nij,nj->ni", np.abs(y["Hpp"]), np.abs(yp)) + np.abs(y["gp"])
+    np.add.at(ap, op[m], np.einsum("nij,ni->nj", np.abs(E[m]), np.abs(yc[oc[m]])))
+    return float(max(np.abs(rc).max() / ac.max(), np.abs(rp).max() / ap.max()))
+
+
+def record_blocks(p, rec, cams, xyz, dt):
+    """The per-block products the ENGINE's Jacobian-pass records stand for (rho' M, rho' b per observation; check_obs_records pins them to
+    the oracle's rows at 1e-12), formed in dtype `dt` with the independent numpy projection Jacobians."""
+    Ac, Ap = [a.astype(dt) for a in projection_jacobians_numpy(p, cams, xyz)]
+    M = np.zeros((p.n_obs, 2, 2), dt)
+    M[:, 0, 0], M[:, 0, 1], M[:, 1, 0], M[:, 1, 1] = rec[:, 0], rec[:, 1], rec[:, 1], rec[:, 2]
+    b = rec[:, 3:5].astype(dt)
+    AcT, ApT = Ac.transpose(0, 2, 1), Ap.transpose(0, 2, 1)
+    return dict(JcJc=AcT @ M @ Ac, JcJp=AcT @ M @ Ap, JpJp=ApT @ M @ Ap, Jcr=-np.einsum("nij,nj->ni", AcT, b), Jpr=-np.einsum("nij,nj->ni", ApT, b))
 
 
 def step_accuracy(p, iterations):
-    """Accuracy of the engine's LM camera step, iteration by iteration along its own path (radius 1e4 x 3^i, every step accepted =
-    the path of the first iterations of a solve): at the engine's state the oracle's per-block products (double) are turned into
-    the camera step in x87 extended precision ("exact for these blocks") and, by the same code, in float64 ("what double
-    arithmetic gives").  Returns [(iteration, cond(S), |engine - exact|, |float64 - exact|)] relative to the largest step entry."""
+    """Accuracy of the engine's LM step, iteration by iteration along its own path (radius 1e4 x 3^i, every step accepted = the path
+    of the first iterations of a solve).  Everything downstream of the Jacobian-pass records (point elimination, reduced system,
+    scaling, damping, L D L^T, both substitutions) is judged on the ENGINE's OWN records at that state, formed in x87 extended precision:
+      * backward error of the engine's (camera, point) step in the full normal equations, next to that of a float64 restatement
+        (block_step) of the same elimination -- the conditioning-free measure;
+      * forward error of the camera step against the extended-precision step, again next to the float64 restatement's (on these
+        windows the 3x3 point blocks at 0.01 m baselines amplify rounding to 1e-10 .. 1e-5 of the step for ANY double algorithm).
+    Returns per iteration dict(it, cond, bwd_engine, bwd_f64, fwd_engine, fwd_f64, data_shift); data_shift = how far the 1e-15
+    differences between the engine's and the oracle's evaluation of the blocks move the extended-precision step."""
     free = [c for c in range(p.n_frames) if c != p.fixed_slot]
     rows = []
     with make_engine(p) as e:
         e.linearize()
-        scale_x = scale_d = None
+        scale_x = scale_d = scale_o = None
         for it in range(iterations):
             c0, x0 = [a.copy() for a in e.get_state()]
+            rec = e.obs_records()
             bp = oracle.block_products(p, autodiff=True, threads=8, cams=c0, xyz=x0)
             radius = 1e4 * 3.0 ** it
             e.step(radius, init_scale=(it == 0))
             e.accept()
             e.linearize()
-            d_e = (e.get_state()[0] - c0)[free]
-            d_x, scale_x, S = block_step(p, bp, radius, scale_x, np.longdouble)
-            d_d, scale_d, _ = block_step(p, bp, radius, scale_d, np.float64)
+            c1, x1 = e.get_state()
+            d_e, dp_e = (c1 - c0)[free], x1 - x0
+            bx = record_blocks(p, rec, c0, x0, np.longdouble)
+            d_x, scale_x1, S, _ = block_step(p, bx, radius, scale_x, np.longdouble)
+            d_d, scale_d, _, dp_d = block_step(p, record_blocks(p, rec, c0, x0, np.float64), radius, scale_d, np.float64)
+            d_o, scale_o, _, _ = block_step(p, bp, radius, scale_o, np.longdouble)
             nrm = np.abs(d_x).max()
-            rows.append((it, float(np.linalg.cond(S.astype(np.float64))), float(np.abs(d_e - d_x).max() / nrm), float(np.abs(d_d - d_x).max() / nrm)))
+            rows.append(dict(it=it, cond=float(np.linalg.cond(S.astype(np.float64))),
+                             bwd_engine=backward_error(p, bx, radius, scale_x, d_e, dp_e), bwd_f64=backward_error(p, bx, radius, scale_x, d_d, dp_d),
+                             fwd_engine=float(np.abs(d_e - d_x).max() / nrm), fwd_f64=float(np.abs(d_d - d_x).max() / nrm),
+                             data_shift=float(np.abs(d_o - d_x).max() / nrm)))
+            scale_x = scale_x1
     return rows

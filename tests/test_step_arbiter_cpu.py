@@ -7,7 +7,7 @@ import numpy as np
 from oracle import oracle
 from photobundle_amd import synthetic
 
-from gpu_util import block_step
+from gpu_util import block_step, backward_error
 
 
 def _window(**kw):
@@ -23,9 +23,16 @@ def test_block_step_is_the_first_step_of_the_oracle_loop():
         free = [c for c in range(p.n_frames) if c != p.fixed_slot]
         want = (ref["cams"] - p.cams)[free]
         for dt, tol in ((np.float64, 1e-9), (np.longdouble, 1e-9)):
-            got, scale, S = block_step(p, bp, 1e4, None, dt)
+            got, scale, S, got_p = block_step(p, bp, 1e4, None, dt)
             assert got.dtype == dt and S.shape == (6 * len(free), 6 * len(free))
             assert np.abs(got.astype(np.float64) - want).max() <= tol * np.abs(want).max(), (kw, dt)
+            assert np.abs(got_p.astype(np.float64) - (ref["xyz"] - p.xyz)).max() <= 1e-8 * np.abs(ref["xyz"] - p.xyz).max(), (kw, dt)
+            # the restatement is backward stable in its own precision, and the conditioning-free measure sees a 1e-6 slip of the damping
+            assert backward_error(p, bp, 1e4, scale, got, got_p) <= (5e-13 if dt is np.float64 else 5e-16)
+        scale = block_step(p, bp, 1e4, None, np.longdouble)[1]
+        own = backward_error(p, bp, 1e4, scale, want, ref["xyz"] - p.xyz)                                # the oracle's own loop
+        assert own <= 5e-13
+        assert backward_error(p, bp, 1e4 * (1 + 1e-6), scale, want, ref["xyz"] - p.xyz) >= 1e-11 > 2 * own
 
 
 def test_extended_precision_is_wider_than_double_here():
