@@ -483,7 +483,9 @@ def main():
             sh3 = whole3.shard(rank, world)
             del whole3
             e3 = plain_engine(sh3)
-            if backend == "nccl":
+            # the transport the headline engine ended up with (RCCL or host-staged, with or without the peer mailboxes) is the one
+            # this engine uses: what failed its set-up or self-test there is not tried again inside a record
+            if transport.startswith("RCCL"):
                 uid3 = torch.zeros(128, dtype=torch.uint8, device=ctl)
                 if rank == 0:
                     uid3.copy_(torch.frombuffer(bytearray(Engine.comm_unique_id()), dtype=torch.uint8))
@@ -491,7 +493,7 @@ def main():
                 e3.comm_init_rccl(bytes(uid3.cpu().numpy().tobytes()), rank, world)
             else:
                 e3.comm_init_callback(_allreduce, rank, world)
-            if os.environ.get("PBA_PEER", "1") != "0":
+            if eng.comm_transport().endswith("+peer"):
                 e3.comm_enable_peer_exchange()
             tn = measure(e3, sh3, 20, 5, collective=True)
             tr3 = e3.comm_transport()
