@@ -105,7 +105,13 @@ __device__ __forceinline__ void stage_geom(const CamGeom* __restrict__ src, CamG
   const unsigned long long* s = reinterpret_cast<const unsigned long long*>(src);
   unsigned long long* d = reinterpret_cast<unsigned long long*>(dst);
   const int n = n_frames * (int)(sizeof(CamGeom) / 8);
-  for (int k = tid; k < n; k += NT) d[k] = s[k];
+  // all loads of the thread in flight together (the rolled loop paid one L2 round trip per trip: 2 at 8 frames, 4 at 16)
+  constexpr int IT = (kMaxFrames * (int)(sizeof(CamGeom) / 8) + NT - 1) / NT;
+  unsigned long long v[IT];
+#pragma unroll
+  for (int u = 0; u < IT; ++u) { const int k = tid + u * NT; v[u] = (k < n) ? s[k] : 0ull; }
+#pragma unroll
+  for (int u = 0; u < IT; ++u) { const int k = tid + u * NT; if (k < n) d[k] = v[u]; }
 }
 
 // XCD-aware workgroup order (MI355X: 8 XCDs with private 4 MiB L2s; the dispatcher places workgroup b on XCD b % 8).
@@ -845,17 +851,34 @@ __device__ __forceinline__ FusedIdx fused_prefetch_indices(const SampleParams& p
 template <int NT>
 __device__ __forceinline__ void fused_stage_step_table(const SampleParams& p, double* s_bk) {
   if (!p.skip_backsub) {
-    for (int e = threadIdx.x; e < kBk * p.n_frames; e += NT) {
+    // Branch-free: every entry issues the same seven loads (three table words, the rotation part of the camera step, one translation
+    // component, the free index) and selects afterwards.  The five-way branch on the entry kind this replaces was divergent inside
+    // every wave, so its global loads went out one kind after the other: four dependent L2 round trips per trip of this loop, 6.7 k
+    // (8 frames) / 13 k (16 frames) cycles of every workgroup's start (in-kernel stamps).
+    constexpr int GW = (int)(sizeof(CamGeom) / 8);
+    constexpr int oT = (int)(offsetof(CamGeom, t) / 8), oR = (int)(offsetof(CamGeom, R) / 8), oD = (int)(offsetof(CamGeom, dR) / 8);
+    constexpr int oF = (int)(offsetof(CamGeom, free_index) / 4);
+    static_assert(offsetof(CamGeom, t) % 8 == 0 && offsetof(CamGeom, R) % 8 == 0 && offsetof(CamGeom, dR) % 8 == 0, "double words");
+    const double* G = reinterpret_cast<const double*>(p.geom_prev);
+    constexpr int IT = (kBk * kMaxFrames + NT - 1) / NT;
+    const int n_e = kBk * p.n_frames;
+#pragma unroll
+    for (int u = 0; u < IT; ++u) {
+      const int e_raw = threadIdx.x + u * NT;
+      const int e = e_raw < n_e ? e_raw : 0;        // (idle lanes recompute entry 0: no exec-mask branch around the loads)
       const int a = e / kBk, k = e - a * kBk;
-      const CamGeom& gp = p.geom_prev[a];
+      const double* g = G + (size_t)a * GW;
       const double* dc = p.delta_c + 6 * a;
-      double val;
-      if (k < 9) val = gp.R[k];
-      else if (k < 12) val = gp.t[k - 9];
-      else if (k < 21) val = dc[0] * gp.dR[k - 12] + dc[1] * gp.dR[9 + k - 12] + dc[2] * gp.dR[18 + k - 12];
-      else if (k < 24) val = dc[3 + k - 21];
-      else val = (double)gp.free_index;
-      s_bk[e] = val;
+      const bool rot = (k >= 12) && (k < 21);
+      const int j = rot ? k - 12 : 0;
+      const int o0 = (k < 9) ? oR + k : ((k < 12) ? oT + (k - 9) : oD + j);
+      const double w0 = g[o0], w1 = g[oD + 9 + j], w2 = g[oD + 18 + j];
+      const double d0 = dc[0], d1 = dc[1], d2 = dc[2];
+      const double dt = dc[(k >= 21 && k < 24) ? 3 + (k - 21) : 3];
+      const int32_t fidx = reinterpret_cast<const int32_t*>(g)[oF];
+      double val = rot ? d0 * w0 + d1 * w1 + d2 * w2 : w0;
+      if (k >= 21) val = (k < 24) ? dt : (double)fidx;
+      if (e_raw < n_e) s_bk[e] = val;
     }
   }
 }
@@ -2289,8 +2312,21 @@ __global__ __launch_bounds__(kTile, 2) void k_schur(SchurParams p_in) {
       const int k = tid + u * kTile;
       if (k < n_geom_words) reinterpret_cast<unsigned long long*>(s_geom)[k] = greg[u];
     }
-    for (int k = tid + kGeomRegs * kTile; k < n_geom_words; k += kTile)
-      reinterpret_cast<unsigned long long*>(s_geom)[k] = reinterpret_cast<const unsigned long long*>(p.geom)[k];
+    {
+      // the words beyond the register copy (windows of 11+ frames), all in flight together
+      constexpr int kTail = (kMaxFrames * (int)(sizeof(CamGeom) / 8) + kTile - 1) / kTile - kGeomRegs;
+      unsigned long long gt[kTail];
+#pragma unroll
+      for (int u = 0; u < kTail; ++u) {
+        const int k = tid + (kGeomRegs + u) * kTile;
+        gt[u] = (k < n_geom_words) ? reinterpret_cast<const unsigned long long*>(p.geom)[k] : 0ull;
+      }
+#pragma unroll
+      for (int u = 0; u < kTail; ++u) {
+        const int k = tid + (kGeomRegs + u) * kTile;
+        if (k < n_geom_words) reinterpret_cast<unsigned long long*>(s_geom)[k] = gt[u];
+      }
+    }
     lds_barrier();
     PBA_TICK(0);
 
