@@ -1,6 +1,20 @@
-"""numpy restatement of PhotometricBundleAdjustment::addFrame / optimize (reference src/photobundle.cc:482-615,
-:764-876) used ONLY to check the C++ drop-in class (photobundle_amd/host) end to end: it rebuilds, frame by frame, the
-window problems the class must assemble, solves each with the CPU oracle and returns the refined trajectory."""
+"""TEST INFRASTRUCTURE (oracle of SURVEY.md 8 row f1) -- numpy restatement of the reference FRONT-END, never imported by the product.
+
+PhotometricBundleAdjustment::addFrame / optimize (reference src/photobundle.cc:482-615, :764-876), statement by statement:
+  * `_interp2`            src/photobundle.cc:262-294   (float arithmetic, the four border cases)
+  * `Zncc`                src/photobundle.cc:296-361   (interpolateFixedPatch :299-312, ZnccPatch_<2, float>: mean, norm, score)
+  * `Emulator.add_frame`  src/photobundle.cc:482-615   (trajectory push :485-487, visibility update :505-542 with std::round and the
+                                                        mask block :536-538, saliency map :550 -> :213-221, candidate selection :555-573
+                                                        with IsLocalMax_ src/imgproc.h:176-212, top-N :578-585, ExtractPatch :466-479,
+                                                        :597-603, ring buffer :605-612)
+  * `Emulator._optimize`  src/photobundle.cc:764-876   (window assembly :774-816 -> WindowProblem, solved by the C++ oracle
+                                                        oracle/pba_oracle.cpp, write-back :841-875, eviction :851, :888-905)
+  * `PyramidEmulator`     src/photobundle_pyramid.cc:37-69 as intended (see photobundle_amd/host/photobundle_pyramid.h), levels from
+                                                        oracle.pyr_down_u8 / resize_bilinear_f32
+It rebuilds, frame by frame, the window problems the C++ drop-in class (photobundle_amd/host) must assemble, solves each with the
+CPU oracle and returns the refined trajectory; tests/test_gpu_frontend.py also holds the device front-end kernels to `Zncc` bit for
+bit.  Like the rest of oracle/: parity unpinned (the reference cannot be built here and ships no vectors).  (Until round 4 this file
+was tests/frontend_emulation.py.)"""
 import numpy as np
 
 from oracle import oracle

@@ -47,6 +47,12 @@ static void dumpResult(const std::string& fn, int frame, const PhotometricBundle
   for (const auto& it : r.iterationSummary)
     std::fprintf(f, "it %d %d %d %.17g %.17g %.17g %.17g %.17g %.17g\n", it.iteration, (int)it.step_is_valid, (int)it.step_is_successful, it.cost,
                  it.cost_change, it.gradient_max_norm, it.step_norm, it.relative_decrease, it.trust_region_radius);
+  // every pose of the trajectory so far, round-trip precision (photobundle.cc:858: Result::poses covers all frames)
+  for (size_t i = 0; i < r.poses.size(); ++i) {
+    std::fprintf(f, "pose %zu", i);
+    for (int a = 0; a < 3; ++a) for (int b = 0; b < 4; ++b) std::fprintf(f, " %.17g", r.poses[i](a, b));
+    std::fprintf(f, "\n");
+  }
   for (size_t i = 0; i < r.refinedPoints.size(); ++i)
     std::fprintf(f, "pt %.17g %.17g %.17g %.17g %.17g %.17g\n", r.refinedPoints[i][0], r.refinedPoints[i][1], r.refinedPoints[i][2],
                  r.originalPoints[i][0], r.originalPoints[i][1], r.originalPoints[i][2]);

@@ -3,6 +3,8 @@
 size that tests/test_gpu_fullsize.py compares the engine with (see tests/referee_cache.py; ~15 min on 8 cores).
 
     python tests/golden/make_referee_traces.py [key-prefix ...]
+    python tests/golden/make_referee_traces.py --rehash     # r5: entries of the window-only hash scheme get the window + oracle
+                                                            # sources + options hash, ONLY where the old window hash still matches
 """
 import json
 import os
@@ -16,7 +18,26 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import referee_cache as rc  # noqa: E402
 
 
+def rehash():
+    out = json.load(open(rc.FIXTURE))
+    wins = rc.windows()
+    built = {}
+    for key, (wname, _, xv) in rc.RUNS.items():
+        if wname not in built:
+            built = {wname: wins[wname]()}
+        p = built[wname]
+        old = rc.problem_hash(p, rc._variant(p, xv))
+        if out[key]["hash"] == old:
+            out[key]["hash"] = rc.entry_hash(p, key)
+            print("%-28s rehashed" % key, flush=True)
+        else:
+            print("%-28s NOT rehashed (window hash %s)" % (key, "already new scheme" if out[key]["hash"] == rc.entry_hash(p, key) else "differs"), flush=True)
+    json.dump(out, open(rc.FIXTURE, "w"), indent=0, sort_keys=True)
+
+
 def main():
+    if sys.argv[1:] == ["--rehash"]:
+        return rehash()
     only = sys.argv[1:]
     out = json.load(open(rc.FIXTURE)) if os.path.exists(rc.FIXTURE) else {}
     wins = rc.windows()

@@ -5,9 +5,10 @@ GPU box (the GPU side is a fraction of a second), which put the suite at 660 s o
 only on the seeded synthetic window and the oracle, so they are generated ONCE by tests/golden/make_referee_traces.py
 (same window builders, same oracle options: the table RUNS below is shared) and committed as
 tests/golden/referee_traces.json: per run the iteration trace, the final cameras, cost and termination.  Every entry
-carries a SHA-1 of the window it was computed for; a test whose freshly built window hashes differently (another numpy,
-a changed generator) ignores the entry and runs the oracle live, so a stale fixture can slow a test down but never
-decide it.  PBA_REFEREE_LIVE=1 forces the live path.  Test infrastructure: never imported by the product.
+carries a SHA-1 of the window it was computed for, of the ORACLE'S SOURCES (oracle/pba_oracle.cpp, pba_oracle.h, oracle.py) and
+of the resolved solver options of the run; a test whose freshly built window hashes differently (another numpy, a changed
+generator), or that runs against an edited oracle or other options, ignores the entry and runs the oracle live, so a stale
+fixture can slow a test down but never decide it.  PBA_REFEREE_LIVE=1 forces the live path.  Test infrastructure: never imported by the product.
 """
 import hashlib
 import json
@@ -54,6 +55,35 @@ def _runs():
 RUNS = _runs()
 
 
+_ROOT = os.path.dirname(_HERE)
+_ORACLE_SOURCES = ("oracle/pba_oracle.cpp", "oracle/pba_oracle.h", "oracle/oracle.py")
+
+
+def oracle_fingerprint():
+    """SHA-1 over the oracle's sources: an entry computed by another oracle never decides a test."""
+    h = hashlib.sha1()
+    for name in _ORACLE_SOURCES:
+        h.update(open(os.path.join(_ROOT, name), "rb").read())
+    return h.hexdigest()
+
+
+def options_fingerprint(key):
+    """The RESOLVED options struct of run `key` (defaults of the oracle library + the overrides of RUNS), field by field."""
+    from oracle import oracle
+    _, opts, _ = RUNS[key]
+    o = oracle.default_options(num_threads=8, **opts)
+    return json.dumps({f[0]: getattr(o, f[0]) for f in o._fields_ if f[0] != "num_threads"}, sort_keys=True)
+
+
+def entry_hash(p, key):
+    _, _, xv = RUNS[key]
+    h = hashlib.sha1()
+    h.update(problem_hash(p, _variant(p, xv)).encode())
+    h.update(oracle_fingerprint().encode())
+    h.update(options_fingerprint(key).encode())
+    return h.hexdigest()
+
+
 def problem_hash(p, xyz=None):
     h = hashlib.sha1()
     for a in (p.images, p.cams, p.xyz if xyz is None else xyz, p.desc, p.obs_point, p.obs_slot, p.weights,
@@ -76,7 +106,7 @@ def run_live(p, key):
 
 def pack(p, key, res):
     _, _, xv = RUNS[key]
-    return dict(hash=problem_hash(p, _variant(p, xv)), cams=[[float(v) for v in row] for row in res["cams"]],
+    return dict(hash=entry_hash(p, key), cams=[[float(v) for v in row] for row in res["cams"]],
                 iterations=[{k: it[k] for k in ITER_KEYS} for it in res["iterations"]], **{k: res[k] for k in RESULT_KEYS})
 
 
@@ -91,11 +121,11 @@ def solve(p, key):
         _CACHE = json.load(open(FIXTURE)) if os.path.exists(FIXTURE) else {}
     _, _, xv = RUNS[key]
     ent = _CACHE.get(key)
-    if ent is not None and os.environ.get("PBA_REFEREE_LIVE") != "1" and ent["hash"] == problem_hash(p, _variant(p, xv)):
+    if ent is not None and os.environ.get("PBA_REFEREE_LIVE") != "1" and ent["hash"] == entry_hash(p, key):
         res = {k: ent[k] for k in RESULT_KEYS}
         res["cams"] = np.array(ent["cams"], dtype=np.float64)
         res["iterations"] = ent["iterations"]
         res["from_fixture"] = True
         return res
-    print("referee_cache: %s runs live (%s)" % (key, "no fixture entry" if ent is None else "forced / the window hashes differently"))
+    print("referee_cache: %s runs live (%s)" % (key, "no fixture entry" if ent is None else "forced / window, oracle sources or options hash differently"))
     return run_live(p, key)

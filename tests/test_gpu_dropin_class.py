@@ -60,7 +60,7 @@ def _read_results(path):
 
 @pytest.mark.timeout(900)
 def test_run_kitti_matches_emulated_reference_pipeline(tmp_path):
-    from frontend_emulation import Emulator
+    from oracle.frontend import Emulator
     assert os.path.exists(RUN), "build photobundle_amd/bin/run_kitti first (__graft_entry__.build())"
     size, K = (120, 160), (200.0, 200.0, 80.0, 60.0)
     n_frames, window, radius, max_points = 6, 4, 1, 4096  # no top-N cut: nth_element is unspecified among saliency ties
@@ -120,7 +120,7 @@ def test_run_kitti_matches_emulated_reference_pipeline(tmp_path):
 @pytest.mark.timeout(1500)
 def test_pyramid_path_matches_emulation(tmp_path):
     """configs[2] (photobundle_pyramid path): 2-level coarse-to-fine through run_kitti (numLevels = 2)."""
-    from frontend_emulation import PyramidEmulator
+    from oracle.frontend import PyramidEmulator
     size, K = (160, 224), (280.0, 280.0, 112.0, 80.0)
     n_frames, window, radius, max_points = 5, 3, 1, 100000
     tmp = str(tmp_path)
@@ -146,7 +146,7 @@ def test_pyramid_path_matches_emulation(tmp_path):
 @pytest.mark.timeout(1500)
 def test_pyramid_three_levels_matches_emulation(tmp_path):
     """configs[2] path with numLevels = 3 (192x256 -> 96x128 -> 48x64) against the numpy emulation + oracle solves."""
-    from frontend_emulation import PyramidEmulator
+    from oracle.frontend import PyramidEmulator
     size, K = (192, 256), (320.0, 320.0, 128.0, 96.0)
     n_frames, window, radius, max_points = 5, 3, 1, 100000
     tmp = str(tmp_path)
@@ -235,7 +235,7 @@ def test_configs2_full_size_three_level_pyramid(tmp_path):
 def test_multichannel_descriptor_types_match_emulation(tmp_path, descriptor):
     """Options::descriptorType = IntensityAndGradient / BitPlanes (reference photobundle.cc:225-248) through the class and
     run_kitti: channel images, saliency over all channels, C patches per descriptor, C (2R+1)^2 residuals per block."""
-    from frontend_emulation import Emulator
+    from oracle.frontend import Emulator
     size, K = (120, 160), (200.0, 200.0, 80.0, 60.0)
     n_frames, window, radius, max_points = 6, 4, 1, 4096
     tmp = str(tmp_path)

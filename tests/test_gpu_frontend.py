@@ -1,5 +1,5 @@
 """-m gpu: the device front-end (pba_frontend_visibility / _candidates / _descriptors; reference src/photobundle.cc:505-603) against
-the numpy restatement of the same reference lines (tests/frontend_emulation.py: interp2 / ZnccPatch_ in float arithmetic, the
+the numpy restatement of the same reference lines (oracle/frontend.py: interp2 / ZnccPatch_ in float arithmetic, the
 oracle's channel planes for the saliency, ExtractPatch) -- bit for bit -- and through the drop-in class: run_kitti with the device
 front-end (default) and with the host one (PBA_HOST_FRONTEND=1) write byte-identical trajectories and Result dumps."""
 import os
@@ -29,7 +29,7 @@ def _engine(size, kind, radius=1):
 
 @pytest.mark.parametrize("size", [(96, 131), (376, 1241)])
 def test_zncc_visibility_matches_the_float_restatement(size):
-    from frontend_emulation import Zncc
+    from oracle.frontend import Zncc
     rng = np.random.default_rng(size[0])
     img = _image(rng, size)
     n = 600 if size[0] > 200 else 300

@@ -63,6 +63,9 @@ def _make(c):
     return p
 
 
+ARBITRATED = []      # seed offsets of the cases of this session that needed the step arbiter
+
+
 @pytest.mark.timeout(600)
 @pytest.mark.parametrize("case", CASES, ids=["%02d-f%d-r%d-c%d-%s%s" % (i, c["n_frames"], c["radius"], c["channels"], c["visibility"], "-ragged" if c["ragged"] else "")
                                              for i, c in enumerate(CASES)])
@@ -122,6 +125,10 @@ def test_random_shape(case):
             # 1e-17 .. 4.7e-11, ratio <= 4.2 (profiles/r04/random_sweep_r3_vs_r4.txt); a 1e-6 slip of the damping shows as 5e-11 where
             # the restatement sits at 1e-15 (tests/test_step_arbiter_cpu.py)
             assert r["bwd_engine"] <= 10.0 * r["bwd_f64"] + 1e-14, r
+            # ... and its FORWARD error (camera step against the extended-precision step of the same records) stays within a stated
+            # factor of the float64 restatement's at every arbitrated iteration: the pose bar that remains when the oracle-twin bars
+            # are left (VERDICT r4 #4b) -- a step that is farther from the exact one than any double algorithm would be is a defect
+            assert r["fwd_engine"] <= 10.0 * r["fwd_f64"] + 1e-13, r
         return acc
 
     if bad:
@@ -136,6 +143,10 @@ def test_random_shape(case):
         # position now and then: what separates such a trajectory from the oracle's is amplification, not a wrong step.  The objective
         # itself is pinned by the consistency check above (oracle cost at the engine's own states, 1e-11).  Every use is reported.
         assert consistency <= 1e-11
+        ARBITRATED.append(case["seed_offset"])
+        # hard ceilings that no arbitration lifts: costs within 1e-4 of the oracle's after five iterations (the largest
+        # separation seen in 240 windows is 2.9e-5, a one-ulp twin that flips first shows the same sizes)
+        assert max(dg for _, dg, _ in bad) <= 1e-4, bad
         print("STEP ARBITER used by case %s: violations of the oracle-twin bars %s; per iteration: %s" % (case, bad, arbiter(iterations)))
         explained = True
     elif case["seed_offset"] % 8 == 3:
@@ -146,9 +157,19 @@ def test_random_shape(case):
     # amplify rounding to 1e-5 .. 1e-4 in the poses there (the one-ulp twin shows the same), so the bar follows the twin
     hard = case["rot_deg"] >= 2.0 or case["trans"] >= 0.4
     cam_dist = np.abs(res["cams"] - ref["cams"]).max()
+    bar = (50.0 * cam_floor + 3e-4) if hard else (3.0 * cam_floor + 1e-5)
     if explained:
-        # costs that have separated by 1e-8 .. 1e-3 put the cameras on different branches of the amplification: reported, not barred
-        print("camera distance to the oracle after %d iterations: %.2e (one-ulp twin of the oracle: %.2e)" % (iterations, cam_dist, cam_floor))
+        # costs that have separated by 1e-8 .. 1e-5 put the cameras on different branches of the amplification: the twin envelope no
+        # longer applies, a ceiling of 10x the plain bar does (the per-iteration forward-error bar of the arbiter is the sharp one)
+        print("camera distance to the oracle after %d iterations: %.2e (one-ulp twin of the oracle: %.2e, ceiling %.2e)" % (iterations, cam_dist, cam_floor, 10.0 * bar))
+        assert cam_dist <= 10.0 * bar
     else:
-        assert cam_dist <= ((50.0 * cam_floor + 3e-4) if hard else (3.0 * cam_floor + 1e-5))
+        assert cam_dist <= bar
     print("worst record error:", worst)
+
+
+def test_arbitrated_cases_stay_rare():
+    """The arbiter is for the odd window whose one-ulp twin under-states the rounding band (3 of 240 on the round-4 build): a build
+    that needs it for more than 1 case in 40 (and more than one case at all) has a precision problem, whatever the arbiter says."""
+    print("cases that needed the step arbiter: %s of %d" % (ARBITRATED, len(CASES)))
+    assert len(ARBITRATED) <= max(1, len(CASES) // 40), ARBITRATED

@@ -5,7 +5,7 @@ import os
 
 import numpy as np
 
-from frontend_emulation import pyr_down_u8, resize_bilinear_f32
+from oracle.frontend import pyr_down_u8, resize_bilinear_f32
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 

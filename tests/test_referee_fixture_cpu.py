@@ -18,6 +18,16 @@ def test_fixture_covers_every_run():
         if "max_num_iterations" in opts and not key.endswith("referee") and "twin" not in key:
             assert len(its) == opts["max_num_iterations"] + 1, key        # fixed-length runs
         assert ent["final_cost"] <= ent["initial_cost"]
-    # runs of one window on unperturbed points share its hash
-    assert fx["configs1/referee"]["hash"] == fx["configs1/twin_autodiff"]["hash"] != fx["configs1/twin_ulp_up"]["hash"]
+    # the hash covers the window, the oracle's sources AND the run's options: no two runs share one
+    assert len({fx[k]["hash"] for k in rc.RUNS}) == len(rc.RUNS)
     assert fx["configs1/referee"]["termination_type"] == 0
+
+
+def test_entry_hash_follows_options_and_oracle_sources(monkeypatch):
+    """ an edited oracle or other solver options must not leave a fixture entry valid."""
+    a = rc.options_fingerprint("configs1/referee")
+    assert a != rc.options_fingerprint("configs1/twin_analytic") and a != rc.options_fingerprint("configs1/referee_2")
+    assert "extended_precision" in a and "function_tolerance" in a
+    before = rc.oracle_fingerprint()
+    monkeypatch.setattr(rc, "_ORACLE_SOURCES", rc._ORACLE_SOURCES[:2])
+    assert rc.oracle_fingerprint() != before
