@@ -32,6 +32,8 @@ struct pba_engine {
   float* d_frames_mc = nullptr;     // channels > 1: [max_frames][channels][rows*cols] channel VALUES (gradients are formed at use)
   int channels = 1;
   uint8_t* d_img_stage = nullptr;   // [rows*cols]
+  bool img_stage_valid = false;     // d_img_stage holds the u8 image of the frame uploaded last (set by the u8 / descriptor / pyr_down
+                                    // setters, cleared by the float setters): what the device front-end's ZNCC reads
   uint8_t* h_img_stage = nullptr;   // pinned host copy of the frame being uploaded
   double* h_state_stage = nullptr;  // pinned, host-mapped landing buffer of pba_get_state (grown on demand)
   double* h_state_dev = nullptr;    // its device address
@@ -621,6 +623,7 @@ int pba_set_frame_channels_f32(pba_engine* e, int slot, int32_t n_channels, cons
   HIP_TRY(e, hipMemcpyAsync(e->d_frames_mc + (size_t)slot * n_channels * npix, channels, (size_t)n_channels * npix * sizeof(float),
                             hipMemcpyHostToDevice, e->stream));
   HIP_TRY(e, hipStreamSynchronize(e->stream));
+  e->img_stage_valid = false;       // no u8 image behind this frame: the device front-end's ZNCC has nothing to read
   e->frame_set[slot] = 1;
   return PBA_OK;
 }
@@ -643,6 +646,7 @@ int pba_set_frame_u8(pba_engine* e, int slot, const uint8_t* image) {
   HIP_TRY(e, hipGetLastError());
   HIP_TRY(e, hipEventRecord(e->ev_img_stage, e->stream));
   e->img_stage_busy = true;
+  e->img_stage_valid = true;
   e->frame_set[slot] = 1;
   return PBA_OK;
 }
@@ -811,6 +815,7 @@ int pba_set_frame_pyr_down(pba_engine* e, int slot, pba_engine* finer, int finer
     HIP_TRY(e, hipMemcpyAsync(image_out, e->d_img_stage, (size_t)drows * dcols, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
   }
+  e->img_stage_valid = true;
   e->frame_set[slot] = 1;
   return PBA_OK;
 }
@@ -829,6 +834,8 @@ int pba_frontend_visibility(pba_engine* e, int32_t n, const double* uv, const in
                             int32_t mask_radius, uint8_t* hit) {
   if (!e || n < 0 || mask_radius < 0 || (n > 0 && (!uv || !rc || !patches26 || !hit))) return PBA_ERR_INVALID;
   PBA_NOT_POISONED(e);
+  if (n > 0 && !e->img_stage_valid)
+    return fail(e, PBA_ERR_STATE, "pba_frontend_visibility: no u8 frame behind the ZNCC (upload one with pba_set_frame_u8 / _descriptor_u8 / _pyr_down first)");
   HIP_TRY(e, hipSetDevice(e->cfg.device));
   const int rows = e->cfg.rows, cols = e->cfg.cols;
   const size_t npix = (size_t)rows * cols;
@@ -863,6 +870,8 @@ int pba_frontend_visibility(pba_engine* e, int32_t n, const double* uv, const in
 int pba_frontend_zncc_probe(pba_engine* e, int32_t n, const double* uv, const float* patches26, float* out27) {
   if (!e || n <= 0 || !uv || !patches26 || !out27) return PBA_ERR_INVALID;
   PBA_NOT_POISONED(e);
+  if (!e->img_stage_valid)
+    return fail(e, PBA_ERR_STATE, "pba_frontend_zncc_probe: no u8 frame behind the ZNCC (upload one with pba_set_frame_u8 / _descriptor_u8 / _pyr_down first)");
   HIP_TRY(e, hipSetDevice(e->cfg.device));
   const size_t o_pt = (size_t)n * 16, o_out = o_pt + (size_t)n * 104, total = o_out + (size_t)n * 108;
   int rcode;
@@ -886,6 +895,8 @@ int pba_frontend_candidates(pba_engine* e, int32_t slot, const float* depth, dou
   if (!e || !depth || !n_out || slot < 0 || slot >= e->cfg.max_frames || border < 0) return PBA_ERR_INVALID;
   if (!e->frame_set[slot]) return fail(e, PBA_ERR_STATE, "pba_frontend_candidates: slot %d holds no frame", slot);
   if (nms_radius > border) return fail(e, PBA_ERR_INVALID, "pba_frontend_candidates: nms radius %d reaches over the border %d", nms_radius, border);
+  if (2 * border >= e->cfg.rows || 2 * border >= e->cfg.cols)
+    return fail(e, PBA_ERR_INVALID, "pba_frontend_candidates: border %d leaves no interior in a %d x %d image", border, e->cfg.rows, e->cfg.cols);
   PBA_NOT_POISONED(e);
   HIP_TRY(e, hipSetDevice(e->cfg.device));
   const int rows = e->cfg.rows, cols = e->cfg.cols;
@@ -1290,22 +1301,23 @@ int pba_internal_step(pba_engine* e, double radius, int32_t init_scale, const pb
     e->cost_blocks[cand] = e->fused_grid;
     e->lin_valid[cand] = e->speculate;
     if (sp.dbg) {
-      std::vector<unsigned long long> h(8 * (size_t)e->fused_grid + 8);
+      const int fl = e->fused_grid;
+      std::vector<unsigned long long> h(8 * (size_t)fl + 8);
       (void)hipMemcpyAsync(h.data(), sp.dbg, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost, e->stream);
       (void)hipStreamSynchronize(e->stream);
       double avg[8] = {0};
-      for (int b = 0; b < e->fused_grid; ++b) for (int k = 0; k < 6; ++k) avg[k] += (double)(h[8 * b + k] & 0xffffffffffffffull) / e->fused_grid;
+      for (int b = 0; b < fl; ++b) for (int k = 0; k < 6; ++k) avg[k] += (double)(h[8 * b + k] & 0xffffffffffffffull) / fl;
       // per-XCD timeline (the counters of different XCDs are not assumed to be synchronised)
       {
         unsigned long long g0 = ~0ull, g1 = 0;
-        for (int b = 0; b < e->fused_grid; ++b) { g0 = std::min(g0, h[8 * b + 6]); g1 = std::max(g1, h[8 * b + 7]); }
+        for (int b = 0; b < fl; ++b) { g0 = std::min(g0, h[8 * b + 6]); g1 = std::max(g1, h[8 * b + 7]); }
         double mean_dur = 0.0;
-        for (int b = 0; b < e->fused_grid; ++b) mean_dur += 0.01 * (double)(h[8 * b + 7] - h[8 * b + 6]) / e->fused_grid;
+        for (int b = 0; b < fl; ++b) mean_dur += 0.01 * (double)(h[8 * b + 7] - h[8 * b + 6]) / fl;
         std::fprintf(stderr, "k_sample(fused) timeline: first start -> last end %.2f us, mean block duration %.2f us\n",
                      0.01 * (double)(g1 - g0), mean_dur);
         int hist[16] = {0};
-        for (int b = 0; b < e->fused_grid; ++b) { int k = (int)((h[8 * b + 6] - g0) / 400); hist[k > 15 ? 15 : k]++; }
-        const unsigned long long* hf = &h[8 * (size_t)e->fused_grid];
+        for (int b = 0; b < fl; ++b) { int k = (int)((h[8 * b + 6] - g0) / 400); hist[k > 15 ? 15 : k]++; }
+        const unsigned long long* hf = &h[8 * (size_t)fl];
         std::fprintf(stderr, "  last workgroup: own work %.2f us, finalisation %.2f us (loads %.2f, reduce %.2f, decide %.2f)\n",
                      0.01 * (double)hf[1], 0.01 * (double)hf[0], 0.01 * (double)hf[2], 0.01 * (double)hf[3], 0.01 * (double)hf[4]);
         std::fprintf(stderr, "  block starts per 4 us bin:");
@@ -1315,14 +1327,14 @@ int pba_internal_step(pba_engine* e, double radius, int32_t init_scale, const pb
       for (int x = 0; x < 8; ++x) {
         unsigned long long t0 = ~0ull, t1 = 0; int n = 0; int late = 0;
         int mism = 0;
-        for (int b = 0; b < e->fused_grid; ++b) {
+        for (int b = 0; b < fl; ++b) {
           if ((int)(h[8 * b] >> 56) != x) continue;
           t0 = std::min(t0, h[8 * b + 6]); t1 = std::max(t1, h[8 * b + 7]); ++n;
           if ((b & 7) != x) ++mism;
         }
         unsigned long long first_end = ~0ull;
-        for (int b = 0; b < e->fused_grid; ++b) if ((int)(h[8 * b] >> 56) == x) first_end = std::min(first_end, h[8 * b + 7]);
-        for (int b = 0; b < e->fused_grid; ++b) if ((int)(h[8 * b] >> 56) == x && h[8 * b + 6] >= first_end) ++late;
+        for (int b = 0; b < fl; ++b) if ((int)(h[8 * b] >> 56) == x) first_end = std::min(first_end, h[8 * b + 7]);
+        for (int b = 0; b < fl; ++b) if ((int)(h[8 * b] >> 56) == x && h[8 * b + 6] >= first_end) ++late;
         (void)mism;
         std::fprintf(stderr, "  xcd %d: %d blocks, span %.2f us, first block done after %.2f us, %d blocks started later than that\n",
                      x, n, 0.01 * (double)(t1 - t0), 0.01 * (double)(first_end - t0), late);

@@ -864,7 +864,10 @@ __global__ __launch_bounds__(kReduceThreads) void k_reduce_final(ReduceFinalPara
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-      const unsigned t = __hip_atomic_fetch_add(fp.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // the other workgroups' mailbox-slot stores are ordered before the flag by the ticket itself (release on the way in, acquire
+      // in the workgroup that raises the flag with a system-scope release), not only by the system-scope write-through stores +
+      // s_waitcnt above: the consumer may be another device
+      const unsigned t = __hip_atomic_fetch_add(fp.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
       if (t == gridDim.x - 1) {
         *fp.ticket = 0;
         __hip_atomic_store(reinterpret_cast<unsigned long long*>(fp.peer_own) + fp.peer_flag, fp.peer_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
