@@ -90,6 +90,7 @@ def main():
                     help="--emulate-rank-of: latency ASSUMED per cross-device exchange on top of the measured single-device path "
                          "(flag write -> remote poll -> R mailbox reads of <= 35 KB over xGMI); no multi-GPU box was available to measure it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-all-cores", action="store_true", help="skip the second CPU-baseline leg (all host cores)")
     ap.add_argument("--cpu-points", type=int, default=50000, help="points of the bounded CPU-baseline sample")
     ap.add_argument("--cpu-steps", type=int, default=20)
     args = ap.parse_args()
@@ -570,6 +571,29 @@ def main():
             "residuals_per_sec": hi * P * (cres["num_jacobian_passes"] + cres["num_cost_passes"]) / cpu_s,
         }
         out["speedup_vs_cpu_baseline"] = iters_per_sec / cpu_iters_per_sec_full
+        # the same path at ALL host cores beside the reference's 4-thread cap (core count and CPU model stated)
+        all_cores = os.cpu_count() or 1
+        cpu_model = "unknown"
+        try:
+            with open("/proc/cpuinfo") as f:
+                for line in f:
+                    if line.startswith("model name"):
+                        cpu_model = line.split(":", 1)[1].strip()
+                        break
+        except OSError:
+            pass
+        out["cpu_baseline"]["cpu_model"] = cpu_model
+        out["cpu_baseline"]["host_cores"] = all_cores
+        if all_cores > threads and not args.no_cpu_all_cores:
+            o.num_threads = all_cores
+            tc = time.perf_counter()
+            cres2 = oracle.solve(sub, o)
+            cpu_s2 = time.perf_counter() - tc
+            it2 = len(cres2["iterations"]) - 1
+            out["cpu_baseline_all_cores"] = {
+                "value": (it2 / cpu_s2) * frac, "unit": out["cpu_baseline"]["unit"], "cores": all_cores, "kind": "port", "cpu_model": cpu_model,
+                "sample": "the same sample, %d OpenMP threads, %.1f s wall" % (all_cores, cpu_s2), "sample_iters_per_sec": it2 / cpu_s2,
+            }
 
     if rank == 0:
         print(json.dumps(out))

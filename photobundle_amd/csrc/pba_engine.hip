@@ -259,7 +259,7 @@ __global__ void k_noop() {}
 // initial trust-region state of a solve, passed by value (a device-to-device hipMemcpyAsync of the host-mapped mirror goes through
 // the copy engine: its hand-over sat in front of the first kernel of every solve)
 #ifndef PBA_LM_INIT_KERNEL
-#define PBA_LM_INIT_KERNEL 1
+#define PBA_LM_INIT_KERNEL 0
 #endif
 __global__ void k_lm_init(LmState* dst, LmState st) { if (threadIdx.x == 0) *dst = st; }
 // device -> host-mapped pinned memory (8-byte words, grid-stride); visible to the host once the stream has drained
@@ -333,7 +333,8 @@ int peer_allreduce(pba_engine* e, int kind, int n, double* out) {
 // exchange of the packed sums sits between the two, so they stay separate kernels.  With the peer exchange there is no
 // exchange kernel: the reduction's last workgroup raises this rank's mailbox flag, the solve's prologue waits for every
 // rank's flag and sums the mailbox slots in rank order (pba_solve.h).
-int launch_reduce_and_solve(pba_engine* e, SolveParams so, int n, int cur, int cand, const LmState* lm, int final_pass, int n_cost_blocks) {
+int launch_reduce_and_solve(pba_engine* e, SolveParams so, int n, int cur, int cand, const LmState* lm, int final_pass, int n_cost_blocks,
+                            const ReduceSolveParams::Fin* fin = nullptr) {
   const bool multi = e->comm.multi();
   const int grid = (e->part_stride + kReduceEntries - 1) / kReduceEntries + 1;
   const int pstride = packed_stride(n);
@@ -346,6 +347,11 @@ int launch_reduce_and_solve(pba_engine* e, SolveParams so, int n, int cur, int c
     rsp.rp = rp;
     rsp.block_cost_alt = e->d_block_cost[cand]; rsp.block_fail_alt = e->d_block_fail[cand];
     rsp.ticket = e->d_ticket_solve; rsp.so = so;
+    if (fin) {
+      rsp.fin = *fin;
+      // gradient-only: the pair blocks and the right-hand side of the partials are not consumed
+      if (final_pass && !so.init_scale) rsp.rp.first_entry = 36 * e->n_pairs + n;
+    }
     rsp.stamp = (lm && !final_pass) ? stamp_record(e) : nullptr;
     ev_begin(e, 3);
     hipLaunchKernelGGL(k_reduce_solve, dim3(grid), dim3(kReduceThreads), solve_blocked_smem_bytes(n), e->stream, rsp);
@@ -784,6 +790,7 @@ int pba_set_frame_descriptor_u8(pba_engine* e, int slot, const uint8_t* image, i
   HIP_TRY(e, hipGetLastError());
   HIP_TRY(e, hipEventRecord(e->ev_img_stage, e->stream));
   e->img_stage_busy = true;
+  e->img_stage_valid = true;
   e->frame_set[slot] = 1;
   return PBA_OK;
 }
@@ -1050,6 +1057,8 @@ int pba_set_problem(pba_engine* e, int32_t n_points, const double* xyz, const do
   e->backsub_grid = (n_points + 255) / 256;
   if ((rc = dev_alloc(e, &e->d_bs_out, (size_t)3 * std::max(e->backsub_grid, e->fused_grid)))) return rc;
   e->schur_grid = std::min(e->n_tiles, 256 * 4);
+  // (experiment switch: workgroups of the persistent k_schur launch; the partial buffers are sized for <= 1024)
+  if (const char* sv = getenv("PBA_SCHUR_GRID")) { const int g = atoi(sv); if (g >= 1 && g <= 1024) e->schur_grid = std::min(e->n_tiles, g); }
 
   // the points go to the CURRENT parity: the cameras of an earlier pba_set_cameras live there too, so the two calls may
   // come in either order
@@ -1565,6 +1574,13 @@ int pba_internal_async_capable(const pba_engine* e, const pba_solver_options* o)
 
 int pba_internal_ready(pba_engine* e) { return check_ready(e, "pba_solve"); }
 
+// 1: the final (gradient-only) enqueue, kind 2, also flushes to the host mirror -- no kind-3 enqueue behind it (single rank, the
+// reduction + solve as one launch)
+int pba_internal_final_flushes(const pba_engine* e) {
+  static const bool off = [] { const char* sv = getenv("PBA_FUSE_FINAL"); return sv && atoi(sv) == 0; }();
+  return (!off && !e->comm.multi() && e->solve_kind == 0 && !PBA_PHASE_TIMING) ? 1 : 0;
+}
+
 int pba_internal_async_begin(pba_engine* e, const pba_solver_options* o) {
   { const int rc0 = check_ready(e, "pba_solve"); if (rc0) return rc0; }
   PBA_NOT_POISONED(e);
@@ -1578,12 +1594,11 @@ int pba_internal_async_begin(pba_engine* e, const pba_solver_options* o) {
   st.min_radius = o->min_trust_region_radius; st.min_relative_decrease = o->min_relative_decrease;
   st.max_num_iterations = o->max_num_iterations; st.max_invalid = o->max_num_consecutive_invalid_steps;
   *e->h_lm = st;
-  // device copy of the initial state straight from the host-mapped mirror (stream ordered, no host sync)
+  // The device copy of the initial state is made by the first kernel of the solve (workgroup 0 of the kind-0 sampling pass reads the
+  // host-mapped mirror: SampleParams::lm_init_*); PBA_LM_INIT_KERNEL=1 keeps the separate launch of rounds 3-4.
   if (PBA_LM_INIT_KERNEL) {
     hipLaunchKernelGGL(k_lm_init, dim3(1), dim3(64), 0, e->stream, e->d_lm, st);
     HIP_TRY(e, hipGetLastError());
-  } else {
-    HIP_TRY(e, hipMemcpyAsync(e->d_lm, e->h_lm_dev, sizeof(st), hipMemcpyDeviceToDevice, e->stream));
   }
   e->async_cur = e->cur;
   return PBA_OK;
@@ -1612,6 +1627,7 @@ int pba_internal_async_enqueue(pba_engine* e, int kind, int init_scale, const pb
     // plain Jacobian pass at the current point, on the fused (tile) grid so that both parities share one block count
     SampleParams sp = sample_params(true);
     sp.lm = nullptr; sp.host_scal = nullptr; sp.host_seq = h_seq_dev; sp.seq = 0; sp.decide = 0; sp.enq_cur = cur;
+    if (!PBA_LM_INIT_KERNEL) { sp.lm_init_dst = e->d_lm; sp.lm_init_src = e->h_lm_dev; }
     e->stamp_iter = 0;
     sp.stamp = stamp_record(e);
     launch_sample<true, true>(e, sp);
@@ -1651,8 +1667,16 @@ int pba_internal_async_enqueue(pba_engine* e, int kind, int init_scale, const pb
   so.init_scale = init_scale; so.jacobi = o->jacobi_scaling; so.radius = 1.0; so.min_diag = o->min_lm_diagonal; so.max_diag = o->max_lm_diagonal;
   so.lm = e->d_lm; so.enq_cur = cur; so.final_pass = (kind == 2) ? 1 : 0; so.cams_alt = e->d_cams[cand]; so.cams_cand_alt = e->d_cams[cur]; so.geom_alt = e->d_geom[cand];
   so.geom_cand_alt = e->d_geom[cur];
-  { const int rcs = launch_reduce_and_solve(e, so, n, cur, cand, e->d_lm, kind == 2 ? 1 : 0, e->fused_grid); if (rcs) return rcs; }
+  // single rank: the final pass decides and flushes in its own last workgroup (no k_decide, no k_flush behind it)
+  const bool fin_fused = kind == 2 && pba_internal_final_flushes(e);
   const unsigned long long seq = ++e->seq;
+  ReduceSolveParams::Fin fin{};
+  if (fin_fused) {
+    fin.lm = e->d_lm; fin.log = e->d_log; fin.host_log = e->h_log_dev; fin.max_log = (int)pba_engine::kMaxLog; fin.host_state = e->h_lm_dev;
+    fin.host_scal = e->h_scal_dev; fin.host_seq = h_seq_dev; fin.seq = seq;
+  }
+  { const int rcs = launch_reduce_and_solve(e, so, n, cur, cand, e->d_lm, kind == 2 ? 1 : 0, e->fused_grid, fin_fused ? &fin : nullptr); if (rcs) return rcs; }
+  if (fin_fused) { HIP_TRY(e, hipGetLastError()); *seq_out = seq; return PBA_OK; }
   unsigned long long fused_x = 0;      // exchange number of the step scalars when k_decide does the exchange itself
   if (kind == 1) {
     SampleParams sp = sample_params(false);

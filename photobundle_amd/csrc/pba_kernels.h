@@ -808,6 +808,9 @@ struct SampleParams {
   unsigned long long* xchg_flag;   // null, or this rank's mailbox flag of the exchange: raised (xchg_seq) by the last workgroup
   unsigned long long xchg_seq;     // once its contribution has left, for the consumer kernel (k_decide) of every rank
   unsigned long long* dbg;    // optional [gridDim.x][8] per-phase cycle stamps of thread 0 (diagnostics)
+  // first linearisation of an asynchronous solve: workgroup 0 copies the initial trust-region state from the host-mapped mirror
+  // to the device (it was a launch of its own, k_lm_init, in front of every solve); null otherwise
+  LmState* lm_init_dst; const LmState* lm_init_src;
 };
 
 // ---- pieces of the FUSED sampling kernels (k_sample, k_sample_mc): the step that leads to the point being sampled -------
@@ -1119,6 +1122,8 @@ void k_sample(SampleParams p_in) {
   // inverse-depth variant (point_world): null for the reference's free world points
   const double* rays = p.rays;
   if (FUSED && !fused_resolve_parity(p)) return;
+  if (FUSED && p.lm_init_dst && blockIdx.x == 0 && threadIdx.x < sizeof(LmState) / 4)      // (consumed by the NEXT kernel of the stream)
+    reinterpret_cast<unsigned*>(p.lm_init_dst)[threadIdx.x] = __hip_atomic_load(reinterpret_cast<const unsigned*>(p.lm_init_src) + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   constexpr int W = 2 * R + 1;      // patch side
   constexpr int F = 2 * R + 2;      // footprint side
   constexpr int RB = sample_rows_per_batch(R);   // footprint rows staged per batch
@@ -1941,6 +1946,8 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(PBA_
   SampleParams p = p_in;
   p.dbg = nullptr;
   if (FUSED && !fused_resolve_parity(p)) return;
+  if (FUSED && p.lm_init_dst && blockIdx.x == 0 && threadIdx.x < sizeof(LmState) / 4)      // (as in k_sample)
+    reinterpret_cast<unsigned*>(p.lm_init_dst)[threadIdx.x] = __hip_atomic_load(reinterpret_cast<const unsigned*>(p.lm_init_src) + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   constexpr int W = 2 * R + 1, F = 2 * R + 2;
   constexpr int H = JAC ? 1 : 0;                    // halo: the gradients of a footprint texel need its four neighbours
   constexpr int FW = F + 2 * H;                     // staged columns
@@ -2794,11 +2801,7 @@ __global__ __launch_bounds__(256) void k_finalize_step(const double* __restrict_
 __global__ void k_flush(const LmState* lm, LmState* host_state, const double* scal, double* host_scal,
                         const pba_iteration_summary* log, pba_iteration_summary* host_log, int max_log,
                         unsigned long long* host_seq, unsigned long long seq) {
-  const int n_words = (lm->n_log < max_log ? lm->n_log : max_log) * (int)(sizeof(pba_iteration_summary) / 4);
-  static_assert(sizeof(pba_iteration_summary) % 4 == 0, "word copy");
-  const unsigned* src = reinterpret_cast<const unsigned*>(log);
-  for (int k = threadIdx.x; k < n_words; k += blockDim.x) store_system_u32(reinterpret_cast<unsigned*>(host_log) + k, src[k]);
-  lm_publish(lm, host_state, scal, host_scal, host_seq, seq, threadIdx.x, blockDim.x);
+  flush_to_host(lm, host_state, scal, host_scal, log, host_log, max_log, host_seq, seq, threadIdx.x, blockDim.x);
 }
 
 // Publishes the (already reduced) scalar block to host-mapped memory: used after the multi-rank all-reduces and

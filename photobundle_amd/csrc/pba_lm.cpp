@@ -63,10 +63,12 @@ static int solve_async(pba_engine* e, const pba_solver_options* o, pba_solver_su
   // that computes them is enqueued unconditionally and gates itself on the device state (lm_final_pass_needed), which
   // saves a host round trip; then ONE flush brings the last outcome and the iteration log to the host mirror.
   tt[3] = now();
+  bool flushed = false;
   if (enq >= o->max_num_iterations) {
     if ((rc = pba_internal_async_enqueue(e, 2, o->max_num_iterations <= 0 ? 1 : 0, o, &seq))) return rc;
+    flushed = pba_internal_final_flushes(e) != 0;      // single rank: the final pass flushes in its own last workgroup
   }
-  if ((rc = pba_internal_async_enqueue(e, 3, 0, o, &seq))) return rc;
+  if (!flushed && (rc = pba_internal_async_enqueue(e, 3, 0, o, &seq))) return rc;
   tt[4] = now();
   if ((rc = pba_internal_async_wait(e, seq))) return rc;
   tt[5] = now();

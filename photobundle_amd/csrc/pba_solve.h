@@ -71,6 +71,7 @@ struct ReduceParams {
   int32_t n_free, n_pairs;
   const double* block_cost; const int32_t* block_fail; int32_t n_cost_blocks;
   double* packed; double* scal;
+  int32_t first_entry;      // entries below it are neither read nor stored (gradient-only final pass: the pair blocks and the rhs)
 };
 
 template <int STORE>
@@ -82,7 +83,7 @@ __device__ __forceinline__ void reduce_partials(const ReduceParams& rp, double (
   const int n = 6 * rp.n_free, TRI = tri_index(n + 1);
   if ((int)blockIdx.x < (int)gridDim.x - 1) {
     const int e = blockIdx.x * EX + ex;
-    const bool valid = e < stride;
+    const bool valid = e < stride && e >= rp.first_entry;
     const bool is_max = (e == stride - 3) || (e == stride - 1);
     double acc = 0.0;
     double v[NF];
@@ -121,9 +122,9 @@ __device__ __forceinline__ void reduce_partials(const ReduceParams& rp, double (
 #pragma unroll
       for (int w = 1; w < kReduceThreads / 64; ++w) s = is_max ? fmax(s, s_red[w][ex]) : s + s_red[w][ex];
       if (dest >= 0) packed_store<STORE>(rp.packed + dest, s);
-      else if (e == stride - 3) rp.scal[kGmaxPts] = s;
+      else if (e == stride - 3) packed_store<STORE>(rp.scal + kGmaxPts, s);      // (STORE 1: read by the last workgroup of this launch when it decides)
       else if (e == stride - 2) packed_store<STORE>(rp.packed + TRI + 2 * n + 1, s);
-      else if (e == stride - 1) rp.scal[kSchurFail] = s;
+      else if (e == stride - 1) packed_store<STORE>(rp.scal + kSchurFail, s);
     }
   } else {
     // last workgroup: cost of the linearisation point = fixed-order sum of the Jacobian-pass block partials (strided per
@@ -886,14 +887,37 @@ struct ReduceSolveParams {
   unsigned int* ticket;          // zero between launches
   unsigned long long* stamp;     // null, or the device time-stamp block (kStamp*)
   SolveParams so;                // lm / enq_cur / final_pass of the step live here
+  // End of a single-rank solve folded into the final (gradient-only) pass: host_seq != null makes the last workgroup take the
+  // gradient-only decision (k_decide) and flush log, state, scalars and sequence number to the host mirror (k_flush) itself --
+  // two launches less at the end of every solve.  A pass that turns out not to be needed (lm_final_pass_needed) only flushes.
+  struct Fin {
+    LmState* lm; pba_iteration_summary* log; pba_iteration_summary* host_log; int32_t max_log;
+    LmState* host_state; double* host_scal; unsigned long long* host_seq; unsigned long long seq;
+  } fin;
 };
+
+// log -> host log, then state, scalars and the sequence number (k_flush's body; nthreads threads of one workgroup)
+__device__ inline void flush_to_host(const LmState* lm, LmState* host_state, const double* scal, double* host_scal, const pba_iteration_summary* log,
+                                     pba_iteration_summary* host_log, int max_log, unsigned long long* host_seq, unsigned long long seq, int tid, int nthreads) {
+  const int n_words = (lm->n_log < max_log ? lm->n_log : max_log) * (int)(sizeof(pba_iteration_summary) / 4);
+  static_assert(sizeof(pba_iteration_summary) % 4 == 0, "word copy");
+  const unsigned* src = reinterpret_cast<const unsigned*>(log);
+  for (int k = tid; k < n_words; k += nthreads) store_system_u32(reinterpret_cast<unsigned*>(host_log) + k, src[k]);
+  lm_publish(lm, host_state, scal, host_scal, host_seq, seq, tid, nthreads);
+}
 
 __global__ __launch_bounds__(kReduceThreads) void k_reduce_solve(ReduceSolveParams rsp) {
   const LmState* lm = rsp.so.lm;
   ReduceParams rp = rsp.rp;
+  const bool fin_mode = rsp.fin.host_seq != nullptr;
   if (lm) {
     if (lm->done && !rsp.so.final_pass) return;
-    if (rsp.so.final_pass && !lm_final_pass_needed(lm)) return;
+    if (rsp.so.final_pass && !lm_final_pass_needed(lm)) {
+      if (fin_mode && blockIdx.x == 0)
+        flush_to_host(lm, rsp.fin.host_state, rsp.so.scal, rsp.fin.host_scal, rsp.fin.log, rsp.fin.host_log, rsp.fin.max_log, rsp.fin.host_seq,
+                      rsp.fin.seq, threadIdx.x, kReduceThreads);
+      return;
+    }
     if (lm->cur != rsp.so.enq_cur) { rp.block_cost = rsp.block_cost_alt; rp.block_fail = rsp.block_fail_alt; }
   }
   extern __shared__ __attribute__((aligned(16))) char dyn_smem[];      // the solve's matrix (last workgroup only)
@@ -929,6 +953,21 @@ __global__ __launch_bounds__(kReduceThreads) void k_reduce_solve(ReduceSolvePara
   so.packed = rp.packed;
   if (wide) solve_blocked<true, kSolveWideThreads>(so, reinterpret_cast<double*>(dyn_smem), tid);
   else solve_blocked<true, kSolveBlockedThreads>(so, reinterpret_cast<double*>(dyn_smem), tid);
+  if (fin_mode) {
+    // gradient-only decision + flush by this (last) workgroup: what k_decide and k_flush did as two more launches
+    const int nth = wide ? kSolveWideThreads : kSolveBlockedThreads;
+    __syncthreads();                                  // the epilogue's scalars have left (the barrier drains the stores)
+    if (tid == 0) {
+      double sl[kNumScal];
+      for (int k = 0; k < kNumScal; ++k) sl[k] = load_agent(so.scal + k);     // (max |g_p| came from another workgroup of this launch)
+      lm_decide(rsp.fin.lm, sl, rsp.fin.log, rsp.fin.max_log, 1);
+      if (rsp.fin.lm->done && rsp.fin.lm->done_seq == 0) rsp.fin.lm->done_seq = rsp.fin.seq;
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // thread 0's state / log stores (write-through) are read by the whole workgroup
+    flush_to_host(rsp.fin.lm, rsp.fin.host_state, so.scal, rsp.fin.host_scal, rsp.fin.log, rsp.fin.host_log, rsp.fin.max_log, rsp.fin.host_seq,
+                  rsp.fin.seq, tid, nth);
+  }
   if (rsp.stamp && tid == 0) rsp.stamp[kStampEndSolve] = __builtin_amdgcn_s_memrealtime();
   if (PBA_PHASE_TIMING && rsp.so.dbg && tid == 0)
     printf("k_reduce_solve: last workgroup %d of %d reached the solve %.2f us after its own start, finished it %.2f us later\n", (int)blockIdx.x,

@@ -6,6 +6,10 @@ small yaw / lateral noise (matches the regime of reference data/kitti_init_poor/
 local poses perturbed (the "poor VO" regime).  Points are drawn from gradient-weighted pixel sites, back-projected
 with noisy depth; descriptors are integer-pixel patches of the birth frame (reference src/photobundle.cc:466-479).
 """
+import hashlib
+import os
+import pickle
+
 import numpy as np
 
 from . import imgproc, se3
@@ -125,6 +129,29 @@ def make_window(n_frames=8, n_points=50000, radius=2, size=KITTI_SIZE, K=KITTI_K
                   frames.  One frame does not hold 200k sites that stay inside a 16-frame window (BASELINE configs[3]):
                   that shape uses (0, 8).
     """
+    # PBA_WINDOW_CACHE=<dir> (dev tool: A/B timing loops on the GPU box spend 20-40 s per process generating the same window):
+    # the finished problem is pickled there, keyed by every argument; windows with a caller-supplied channel_fn are not cached
+    cache_file = None
+    if os.environ.get("PBA_WINDOW_CACHE") and channel_fn is None:
+        key = repr((n_frames, n_points, radius, tuple(size), tuple(K), visibility, huber, gaussian, depth_noise, rot_deg, trans,
+                    seed_offset, point_seed_offset, tuple(dense_births)))
+        cache_file = os.path.join(os.environ["PBA_WINDOW_CACHE"], "window_%s.pkl" % hashlib.sha1(key.encode()).hexdigest()[:16])
+        if os.path.exists(cache_file):
+            with open(cache_file, "rb") as f:
+                return pickle.load(f)
+    prob = _make_window(n_frames, n_points, radius, size, K, visibility, huber, gaussian, depth_noise, rot_deg, trans, seed_offset,
+                        point_seed_offset, dense_births, channel_fn)
+    if cache_file is not None:
+        os.makedirs(os.path.dirname(cache_file), exist_ok=True)
+        tmp = cache_file + ".%d.tmp" % os.getpid()
+        with open(tmp, "wb") as f:
+            pickle.dump(prob, f, protocol=4)
+        os.replace(tmp, cache_file)
+    return prob
+
+
+def _make_window(n_frames, n_points, radius, size, K, visibility, huber, gaussian, depth_noise, rot_deg, trans, seed_offset,
+                 point_seed_offset, dense_births, channel_fn):
     rows, cols = size
     tex = Texture(seed=SEED_TEXTURE + seed_offset)
     T_gt = make_trajectory(n_frames, SEED_TRAJ + seed_offset)
