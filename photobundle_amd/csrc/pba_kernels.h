@@ -984,11 +984,22 @@ __device__ __forceinline__ void fused_backsub(const SampleParams& p, const doubl
 
 // Per-workgroup partials of the fused kernels: cost of the block and the point part of the step statistics, fixed-order
 // sums (butterfly inside each wave, then the waves in order), write-through stores for the last workgroup of the launch.
+// The three step statistics of a wave's points, reduced (same butterfly as the block cost) as soon as the back-substitution
+// has produced them and kept in SCALAR registers from there on: as per-lane doubles they were six vector registers live across
+// the whole walk.  PBA_STEP_SUMS_EARLY=0: reduced with the block cost at the end (rounds 2-4).
+#ifndef PBA_STEP_SUMS_EARLY
+#define PBA_STEP_SUMS_EARLY 1
+#endif
+__device__ __forceinline__ void fused_wave_step_sums(double& bs_mcc, double& bs_st2, double& bs_x2) {
+  double q3[3] = {bs_mcc, bs_st2, bs_x2};
+  wave_sum_n<3>(q3);
+  bs_mcc = readlane_f64(q3[0], 0); bs_st2 = readlane_f64(q3[1], 0); bs_x2 = readlane_f64(q3[2], 0);
+}
+// bs_*: already summed over the wave (fused_wave_step_sums)
 template <int WAVES>
 __device__ __forceinline__ void fused_block_partials(const SampleParams& p, int bid, int lane, int wave, double cost_obs,
                                                      double bs_mcc, double bs_st2, double bs_x2, double* s_red, const int32_t& s_fail) {
-  double q4[4] = {cost_obs, bs_mcc, bs_st2, bs_x2};
-  wave_sum_n<4>(q4);
+  double q4[4] = {wave_sum(cost_obs), bs_mcc, bs_st2, bs_x2};
   if (lane == 0) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) s_red[q * WAVES + wave] = q4[q];
@@ -1180,6 +1191,7 @@ void k_sample(SampleParams p_in) {
   if (FUSED) {
     // ---- phase 0: back-substitution for this workgroup's points (fused_backsub) ------------------------------
     fused_backsub<WAVES * 64>(p, rays, fi, s_bk, reinterpret_cast<double*>(&s_tex[0][0]), pt, slot, obs, active, X, bs_mcc, bs_st2, bs_x2);
+    if (PBA_STEP_SUMS_EARLY) fused_wave_step_sums(bs_mcc, bs_st2, bs_x2);
   } else if (active) {
     pt = p.obs_point[obs];
     slot = p.obs_slot[obs];
@@ -1703,6 +1715,7 @@ void k_sample(SampleParams p_in) {
   }
   // deterministic block reductions: butterfly inside each wave, then the waves in order
   if (FUSED) {
+    if (!PBA_STEP_SUMS_EARLY) fused_wave_step_sums(bs_mcc, bs_st2, bs_x2);
     fused_block_partials<WAVES>(p, bid, lane, wave, cost_obs, bs_mcc, bs_st2, bs_x2, s_red, s_fail);
   } else {
     const double v = wave_sum(cost_obs);
@@ -2152,6 +2165,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(PBA_
   }
   if (FUSED) {
     lds_barrier();        // every wave is done with the texel region / s_base before the finalisation reuses them
+    fused_wave_step_sums(bs_mcc, bs_st2, bs_x2);
     fused_block_partials<WAVES>(p, bid, lane, wave, cost_obs, bs_mcc, bs_st2, bs_x2, s_red, s_fail);
     fused_finalize<WAVES>(p, lane, wave, &s_base[0][0], reinterpret_cast<double*>(s_raw), 0ull);
   } else {

@@ -30,6 +30,11 @@ def test_single_gpu_line():
     assert KEYS <= set(d) and d["n_gpus"] == 1 and d["steps"] == 10 and d["value"] > 0 and d["scaling"] == "weak"
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_source_id", "traffic_matches_build"} <= set(d["roofline"])
     assert {"value", "unit", "cores", "kind", "sample"} <= set(d["cpu_baseline"]) and d["cpu_baseline"]["kind"] == "port"
+    # core count and CPU model stated; the all-cores leg beside the reference's 4-thread cap wherever the host has more
+    assert d["cpu_baseline"]["host_cores"] >= d["cpu_baseline"]["cores"] and d["cpu_baseline"]["cpu_model"]
+    if d["cpu_baseline"]["host_cores"] > d["cpu_baseline"]["cores"]:
+        a = d["cpu_baseline_all_cores"]
+        assert a["cores"] == d["cpu_baseline"]["host_cores"] and a["value"] > 0 and a["kind"] == "port"
 
 
 @pytest.mark.timeout(900)

@@ -162,3 +162,31 @@ def test_class_output_is_identical_with_the_host_front_end(tmp_path):
         # same front-end statistics line by line ("updated %d ... new %d": photobundle.cc:593-595)
         upd = lambda s: [l for l in s.splitlines() if l.startswith("updated ")]
         assert upd(dev[2]) == upd(host[2]) and len(upd(dev[2])) == 6 * (3 if name == "pyr" else 1), name
+
+
+def test_frontend_refuses_a_stale_u8_stage_and_a_border_without_interior():
+    """the ZNCC reads the u8 image of the frame uploaded last; a frame that arrived as float channels (or none at all)
+    leaves nothing to read -> PBA_ERR_STATE instead of scores of a stale image.  And the candidate scan checks its border."""
+    from photobundle_amd.engine import EngineError
+    size = (96, 131)
+    rng = np.random.default_rng(5)
+    img = _image(rng, size)
+    uv = np.array([[40.0, 40.0]]); rc = np.array([[40, 40]], np.int32); pats = np.zeros((1, 26), np.float32)
+    e = _engine(size, "Intensity")
+    with pytest.raises(EngineError):                       # nothing uploaded yet
+        e.frontend_visibility(uv, rc, pats, 0.5, 1)
+    with pytest.raises(EngineError):
+        e.frontend_zncc_probe(uv, pats)
+    e.set_frame(0, img)
+    e.frontend_visibility(uv, rc, pats, 0.5, 1)            # fine after a u8 upload
+    with pytest.raises(EngineError):                       # border 48 leaves no interior in 96 rows
+        e.frontend_candidates(0, np.ones(size, np.float32), 0.1, 100.0, 1, 48)
+    e.close()
+    e3 = _engine(size, "IntensityAndGradient")
+    e3.set_frame_descriptor(0, img, "IntensityAndGradient")
+    e3.frontend_visibility(uv, rc, pats, 0.5, 1)           # the descriptor producer keeps the u8 stage
+    ch = np.zeros((3,) + size, np.float32)
+    e3.set_frame_channels(1, ch)                            # float channels: no u8 image behind this frame
+    with pytest.raises(EngineError):
+        e3.frontend_visibility(uv, rc, pats, 0.5, 1)
+    e3.close()

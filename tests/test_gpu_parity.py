@@ -6,6 +6,8 @@ Tolerances (fp64 path; the image samples themselves are bit-exact by constructio
   per-iteration LM cost                           1e-9  relative, identical accept/reject sequence
   refined poses                                   1e-5  absolute (north_star bar), typically ~1e-9
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -14,6 +16,8 @@ from photobundle_amd import synthetic
 from photobundle_amd.engine import default_solver_options
 
 from gpu_util import check_obs_records, dense_system, make_engine, reference_step
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -180,3 +184,32 @@ def test_error_paths(small_window):
     with pytest.raises(EngineError):
         e.set_problem(p.xyz, p.desc, p.obs_point[::-1].copy(), p.obs_slot, p.weights)   # not grouped by point
     e.close()
+
+
+def test_final_pass_that_decides_and_flushes_matches_the_separate_kernels(small_window):
+    """r5: at the iteration limit the gradient-only pass of a single-rank solve decides and flushes in its own last workgroup
+    (k_reduce_solve with a Fin block) instead of k_decide + k_flush behind it, and the trust-region state is initialised by the first
+    kernel of the solve: same log, same state, bit for bit, as the round-4 launch sequence (PBA_FUSE_FINAL=0 in a fresh process)."""
+    import json, subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import json, sys
+        sys.path.insert(0, %r)
+        from photobundle_amd import synthetic
+        from photobundle_amd.engine import Engine, default_solver_options
+        out = []
+        for n_it in (0, 1, 4, 7):
+            p = synthetic.make_window(n_frames=4, n_points=300, radius=2, size=(120, 160), K=(200.0, 200.0, 80.0, 60.0))
+            with Engine(120, 160, p.K, p.radius, p.n_frames, huber=p.huber) as e:
+                e.load(p)
+                r = e.solve(default_solver_options(max_num_iterations=n_it, function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0))
+            out.append([[i["cost"].hex(), i["gradient_max_norm"].hex(), i["gradient_norm"].hex(), i["trust_region_radius"].hex(), i["step_is_successful"]]
+                        for i in r["iterations"]] + [r["cams"].tobytes().hex(), r["final_cost"].hex(), r["message"]])
+        print("RESULT" + json.dumps(out))
+    """ % ROOT)
+    runs = []
+    for fuse in ("1", "0"):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, PBA_FUSE_FINAL=fuse))
+        assert r.returncode == 0, r.stderr[-2000:]
+        runs.append(json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT")][0][6:]))
+    assert runs[0] == runs[1]
+    assert len(runs[0][3]) == 8 + 3          # iteration 0 + 7 logged steps (+ cameras, final cost, message)
