@@ -212,12 +212,15 @@ int pba_set_frame_pyr_down(pba_engine* e, int slot, pba_engine* finer, int finer
  *                             inside the border (:519-523), rc [n][2]: their rounded (row, column), patches [n][26]: the stored
  *                             zero-mean 5x5 patch and its norm.  hit[i] = score > min_score; the (2 mask_radius + 1)^2 block around
  *                             every hit leaves the engine's selection mask (:536-538), which the call first resets.  n may be 0.
+ *                             PBA_ERR_STATE when the frame uploaded last left no u8 image behind (pba_set_frame_channels_f32, or no
+ *                             upload at all): the ZNCC would otherwise score a stale image.
  *   pba_frontend_candidates   saliency map of the frame in `slot` (sum over the channels of |Ix| + |Iy|, :213-221), then every pixel
  *                             of [border, rows - border - 1) x [border, cols - border - 1) with min_depth <= depth <= max_depth
  *                             that is unmasked and a STRICT local maximum of the saliency over (2 nms_radius + 1)^2 (:555-573,
  *                             src/imgproc.h:176-212; nms_radius <= 0: every valid-depth pixel).  depth: rows * cols floats of the
  *                             caller (borrowed for the call).  *n_out = number of candidates, kept on the device in the row-major
- *                             order of the reference's scan;
+ *                             order of the reference's scan; PBA_ERR_INVALID for nms_radius > border or a border that leaves no
+ *                             interior (2 border >= rows or cols);
  *   pba_frontend_get_candidates   copies the first n of them out (the caller selects the maxNumPoints most salient, :578-585);
  *   pba_frontend_descriptors  ExtractPatch (:466-479, :597-603) at n integer pixels xy [n][2] = (x, y): desc [n][C][(2 R + 1)^2]
  *                             channel values as float (exact: the reference stores the same floats widened to double).
