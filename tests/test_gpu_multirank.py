@@ -279,3 +279,78 @@ def test_two_ranks_peer_exchange_async_driver(tmp_path):
     rc = np.array([i["cost"] for i in ref_conv["iterations"]])
     n = min(len(rc), len(r0["conv_costs"]))
     assert abs(len(rc) - len(r0["conv_costs"])) <= 1 and np.allclose(r0["conv_costs"][:n], rc[:n], rtol=1e-8)
+
+
+# ---- EIGHT ranks, sixteen frames (the sharding of BASELINE configs[3]) on ONE device ------------------------------------------
+def _make16():
+    from photobundle_amd import synthetic
+    return synthetic.make_window(n_frames=16, n_points=960, radius=2, size=(120, 200), K=(250.0, 250.0, 100.0, 60.0),
+                                 visibility="causal", seed_offset=6)
+
+
+def _worker_peer8(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["PBA_WAIT_TIMEOUT_S"] = "60"
+    import torch
+    import torch.distributed as dist
+    from photobundle_amd.engine import default_solver_options
+    from gpu_util import make_engine
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    p = _make16()
+    sh = p.shard(rank, world)
+    e = make_engine(sh, keep_reduced_system=True)
+
+    def allreduce(a, op):
+        t = torch.from_numpy(a)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM if op == 0 else dist.ReduceOp.MAX)
+
+    e.comm_init_callback(allreduce, rank, world)
+    transport = e.comm_enable_peer_exchange()
+    res = e.solve(default_solver_options(max_num_iterations=5))
+    S, rhs = e.reduced_system()
+    np.savez(os.path.join(out_dir, "p8_rank%d.npz" % rank), transport=np.array(transport), cams=res["cams"], xyz=res["xyz"],
+             costs=np.array([i["cost"] for i in res["iterations"]]), ok=np.array([i["step_is_successful"] for i in res["iterations"]]),
+             S=S, rhs=rhs, nres=res["num_residuals"], n_points=sh.n_points)
+    dist.barrier()           # nobody frees its mailbox while a peer may still read it
+    e.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_eight_ranks_sixteen_frames_on_one_device(tmp_path):
+    """The partitioning of BASELINE configs[3] -- a 16-frame window point-sharded over EIGHT ranks, the 90 x 90 reduced system summed
+    in rank order and solved redundantly on every rank (k_reduce_final -> mailbox -> k_solve_blocked<512> with its peer wait; host-
+    staged all-reduce where IPC mapping is unavailable) -- with real kernels and the asynchronous driver, all eight processes on the
+    one GPU of the box.  What is NOT covered here is the xGMI hop between devices (no multi-GPU box): everything else of the 8-way
+    path is.  Replicas must be bit-identical, the solve must match one rank up to the summation order of the shards."""
+    import torch.multiprocessing as mp
+    from photobundle_amd.engine import default_solver_options
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from gpu_util import make_engine
+    world = 8
+    port = 29500 + ((os.getpid() + 131) % 2000)
+    mp.spawn(_worker_peer8, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r = [np.load(tmp_path / ("p8_rank%d.npz" % k)) for k in range(world)]
+    assert len({str(x["transport"]) for x in r}) == 1
+    print("transport of the eight ranks:", str(r[0]["transport"]))
+    p = _make16()
+    assert sum(int(x["n_points"]) for x in r) == p.n_points and all(int(x["n_points"]) > 0 for x in r)
+    with make_engine(p) as e:
+        ref = e.solve(default_solver_options(max_num_iterations=5))
+    assert r[0]["S"].shape == (90, 90)
+    for x in r[1:]:
+        assert np.array_equal(x["cams"], r[0]["cams"]) and np.array_equal(x["S"], r[0]["S"]) and np.array_equal(x["rhs"], r[0]["rhs"])
+        assert np.array_equal(x["costs"], r[0]["costs"]) and np.array_equal(x["ok"], r[0]["ok"])
+    ref_costs = np.array([i["cost"] for i in ref["iterations"]])
+    # (five iterations: eight shards sum in another order than one rank, and on this poorly initialised 16-frame window the first
+    # float-rounded sample position flips at the sixth -- 1.6e-10 of the cost there, 2e-9 one iteration later; first run of the test)
+    print("costs, eight ranks vs one:", np.abs(r[0]["costs"] / ref_costs - 1.0))
+    assert len(ref_costs) == len(r[0]["costs"]) and np.allclose(r[0]["costs"], ref_costs, rtol=1e-9)
+    assert np.array_equal(r[0]["ok"], np.array([i["step_is_successful"] for i in ref["iterations"]]))
+    assert np.abs(r[0]["cams"] - ref["cams"]).max() <= 1e-7
+    assert np.abs(np.concatenate([x["xyz"] for x in r]) - ref["xyz"]).max() <= 1e-5
+    assert int(r[0]["nres"]) == ref["num_residuals"]
