@@ -168,7 +168,7 @@ def test_configs0_reference_config_and_trajectory(tmp_path):
         ref = twins[0]
         assert np.isclose(g["initial"], ref["initial_cost"], rtol=1e-12), (g["initial"], ref["initial_cost"])
         assert np.isclose(g["initial"], ref_q["initial_cost"], rtol=1e-12)
-        # Rounding differences grow along the LM path (DESIGN.md 7: piecewise-bilinear objective, Huber kinks, free scale
+        # Rounding differences grow along the LM path (DESIGN.md 6: piecewise-bilinear objective, Huber kinks, free scale
         # gauge): the engine is held to the extended-precision referee within 2x the distance the DOUBLE oracle runs keep
         # from it, with identical decisions while those agree with the referee's (gpu_util.referee_parity)
         # the ENGINE's refined cameras of this window: Result::poses as the class wrote them back (photobundle.cc:841-844, :858),
