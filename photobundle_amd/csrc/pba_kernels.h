@@ -857,7 +857,7 @@ __device__ __forceinline__ void fused_stage_step_table(const SampleParams& p, do
     // Branch-free: every entry issues the same seven loads (three table words, the rotation part of the camera step, one translation
     // component, the free index) and selects afterwards.  The five-way branch on the entry kind this replaces was divergent inside
     // every wave, so its global loads went out one kind after the other: four dependent L2 round trips per trip of this loop, 6.7 k
-    // (8 frames) / 13 k (16 frames) cycles of every workgroup's start (in-kernel stamps, DESIGN_HISTORY 4).
+    // (8 frames) / 13 k (16 frames) cycles of every workgroup's start (in-kernel stamps).
     constexpr int GW = (int)(sizeof(CamGeom) / 8);
     constexpr int oT = (int)(offsetof(CamGeom, t) / 8), oR = (int)(offsetof(CamGeom, R) / 8), oD = (int)(offsetof(CamGeom, dR) / 8);
     constexpr int oF = (int)(offsetof(CamGeom, free_index) / 4);
