@@ -58,6 +58,26 @@ def kernel_source_id():
     return h.hexdigest()[:12]
 
 
+def usable_cores():
+    """Cores this process may actually run on: the affinity mask capped by the cgroup CPU quota (the GPU boxes of the pool show 256
+    hardware threads and a quota of 16: OpenMP teams beyond the quota only time-slice)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                q, per = int(f.read()), int(g.read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -553,7 +573,7 @@ def main():
         hi = int(np.searchsorted(prob.obs_point, n_cpu, side="left"))
         sub.xyz, sub.desc = prob.xyz[:n_cpu].copy(), prob.desc[:n_cpu]
         sub.obs_point, sub.obs_slot = prob.obs_point[:hi], prob.obs_slot[:hi]
-        threads = min(os.cpu_count() or 1, 4)            # reference default: min(omp_get_max_threads(), 4)
+        threads = min(usable_cores(), 4)                 # reference default: min(omp_get_max_threads(), 4)
         o = oracle.default_options(max_num_iterations=args.cpu_steps, function_tolerance=0.0, gradient_tolerance=0.0,
                                    parameter_tolerance=0.0, num_threads=threads, use_autodiff=1)
         tc = time.perf_counter()
@@ -572,7 +592,7 @@ def main():
         }
         out["speedup_vs_cpu_baseline"] = iters_per_sec / cpu_iters_per_sec_full
         # the same path at ALL host cores beside the reference's 4-thread cap (core count and CPU model stated)
-        all_cores = os.cpu_count() or 1
+        all_cores = usable_cores()
         cpu_model = "unknown"
         try:
             with open("/proc/cpuinfo") as f:
@@ -583,17 +603,19 @@ def main():
         except OSError:
             pass
         out["cpu_baseline"]["cpu_model"] = cpu_model
-        out["cpu_baseline"]["host_cores"] = all_cores
+        out["cpu_baseline"]["host_cores"] = os.cpu_count() or 1
+        out["cpu_baseline"]["usable_cores"] = all_cores          # affinity mask capped by the cgroup CPU quota
         if all_cores > threads and not args.no_cpu_all_cores:
             o.num_threads = all_cores
-            o.max_num_iterations = max(2, args.cpu_steps // 4)      # (a quarter of the sample's iterations: the leg is there for the record)
+            o.max_num_iterations = args.cpu_steps
             tc = time.perf_counter()
             cres2 = oracle.solve(sub, o)
             cpu_s2 = time.perf_counter() - tc
             it2 = len(cres2["iterations"]) - 1
             out["cpu_baseline_all_cores"] = {
                 "value": (it2 / cpu_s2) * frac, "unit": out["cpu_baseline"]["unit"], "cores": all_cores, "kind": "port", "cpu_model": cpu_model,
-                "sample": "the same sample, %d LM iterations, %d OpenMP threads, %.1f s wall" % (it2, all_cores, cpu_s2), "sample_iters_per_sec": it2 / cpu_s2,
+                "host_cores": os.cpu_count() or 1,
+                "sample": "the same sample, %d LM iterations, %d OpenMP threads (every core the cgroup quota grants), %.1f s wall" % (it2, all_cores, cpu_s2), "sample_iters_per_sec": it2 / cpu_s2,
             }
 
     if rank == 0:

@@ -32,9 +32,11 @@ def test_single_gpu_line():
     assert {"value", "unit", "cores", "kind", "sample"} <= set(d["cpu_baseline"]) and d["cpu_baseline"]["kind"] == "port"
     # core count and CPU model stated; the all-cores leg beside the reference's 4-thread cap wherever the host has more
     assert d["cpu_baseline"]["host_cores"] >= d["cpu_baseline"]["cores"] and d["cpu_baseline"]["cpu_model"]
-    if d["cpu_baseline"]["host_cores"] > d["cpu_baseline"]["cores"]:
+    # "all cores" = every core the process may use (affinity mask capped by the cgroup CPU quota), not every hardware thread of the host
+    assert d["cpu_baseline"]["usable_cores"] <= d["cpu_baseline"]["host_cores"]
+    if d["cpu_baseline"]["usable_cores"] > d["cpu_baseline"]["cores"]:
         a = d["cpu_baseline_all_cores"]
-        assert a["cores"] == d["cpu_baseline"]["host_cores"] and a["value"] > 0 and a["kind"] == "port"
+        assert a["cores"] == d["cpu_baseline"]["usable_cores"] and a["value"] > 0 and a["kind"] == "port"
 
 
 @pytest.mark.timeout(900)
