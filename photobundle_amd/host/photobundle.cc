@@ -687,46 +687,3 @@ PhotometricBundleAdjustment::ScenePointPointerList PhotometricBundleAdjustment::
   _scene_points.swap(keep);
   return remove;
 }
-
-// C hook (tests bind it through ctypes): the channel images DescriptorFrame::Create builds on the host
-// (imgproc.h), [C][rows*cols]; kind 1 = IntensityAndGradient, 2 = BitPlanes; returns C
-// test hook (tests/test_host_api_cpu.py): the small API pieces of the reference headers that nothing else in the library calls
-extern "C" int pb_api_probe(char* text, int cap, double* out8) {
-  PhotometricBundleAdjustment::Options o;
-  o.patchRadius = 3;
-  o.descriptorType = PhotometricBundleAdjustment::Options::DescriptorType::BitPlanes;
-  std::ostringstream ss;
-  ss << o;
-  const std::string t = ss.str();
-  if ((int)t.size() + 1 > cap) return -1;
-  std::memcpy(text, t.c_str(), t.size() + 1);
-  Mat33 K = Mat33::Identity();
-  K(0, 0) = 718.856; K(1, 1) = 718.856; K(0, 2) = 607.1928; K(1, 2) = 185.2157;
-  Calibration c(K, 0.5372);
-  const double uvd[3] = {700.0, 100.0, 12.5};
-  const Vec3 X = c.triangulate(uvd);
-  out8[0] = X[0]; out8[1] = X[1]; out8[2] = X[2];
-  const double Xp[3] = {X[0], X[1], X[2]};
-  double uv[2];
-  c.project(Xp, uv);
-  out8[3] = uv[0]; out8[4] = uv[1];
-  c.scale(2.0);
-  out8[5] = c.fx(); out8[6] = c.cx(); out8[7] = c.b();
-  c.scale(0.5);      // ignored (s <= 1)
-  return (c.fx() == out8[5]) ? 0 : -2;
-}
-
-extern "C" int pb_descriptor_channels(const uint8_t* img, int rows, int cols, int kind, float* out) {
-  std::vector<Image_<float>> ch;
-  const size_t n = (size_t)rows * cols;
-  if (kind == 2) {
-    imgproc::computeBitPlanes(img, rows, cols, ch);
-  } else {
-    ch.resize(3);
-    for (auto& c : ch) c.resize(rows, cols);
-    for (size_t i = 0; i < n; ++i) ch[0].d[i] = (float)img[i];
-    imgproc::imgradient(img, rows, cols, ch[1].data(), ch[2].data());
-  }
-  for (size_t k = 0; k < ch.size(); ++k) std::copy(ch[k].d.begin(), ch[k].d.end(), out + k * n);
-  return (int)ch.size();
-}

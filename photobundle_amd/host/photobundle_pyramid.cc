@@ -146,15 +146,3 @@ void PhotometricBundleAdjustmentPyr::addFrame(const uint8_t* image, const float*
   }
   if (result) *result = last;
 }
-
-// C hooks (tests bind them through ctypes)
-extern "C" void pb_pyr_down_u8(const uint8_t* src, int rows, int cols, uint8_t* dst) {
-  std::vector<uint8_t> d;
-  pyrDownU8(src, rows, cols, d);
-  std::copy(d.begin(), d.end(), dst);
-}
-extern "C" void pb_resize_bilinear_f32(const float* src, int rows, int cols, int drows, int dcols, float* dst) {
-  std::vector<float> d;
-  resizeBilinearF32(src, rows, cols, drows, dcols, d);
-  std::copy(d.begin(), d.end(), dst);
-}

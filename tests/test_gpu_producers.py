@@ -16,7 +16,7 @@ KINDS = {"IntensityAndGradient": (1, 3), "BitPlanes": (2, 8)}
 
 
 def _host():
-    L = C.CDLL(os.path.join(ROOT, "photobundle_amd", "libphotobundle.so"))
+    L = C.CDLL(os.path.join(ROOT, "tests", "native", "libhost_probe.so"))
     L.pb_descriptor_channels.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
     L.pb_descriptor_channels.restype = C.c_int
     L.pb_pyr_down_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]

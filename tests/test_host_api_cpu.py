@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_options_stream_and_calibration_helpers():
-    L = C.CDLL(os.path.join(ROOT, "photobundle_amd", "libphotobundle.so"))
+    L = C.CDLL(os.path.join(ROOT, "tests", "native", "libhost_probe.so"))
     buf = C.create_string_buffer(2048)
     out = np.zeros(8)
     assert L.pb_api_probe(buf, 2048, out.ctypes.data_as(C.c_void_p)) == 0

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _lib():
-    return C.CDLL(os.path.join(ROOT, "photobundle_amd", "libphotobundle.so"))
+    return C.CDLL(os.path.join(ROOT, "tests", "native", "libhost_probe.so"))
 
 
 def test_pyr_down_matches_numpy_and_known_answers():
