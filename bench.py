@@ -617,6 +617,7 @@ def main():
                 "host_cores": os.cpu_count() or 1,
                 "sample": "the same sample, %d LM iterations, %d OpenMP threads (every core the cgroup quota grants), %.1f s wall" % (it2, all_cores, cpu_s2), "sample_iters_per_sec": it2 / cpu_s2,
             }
+            out["speedup_vs_cpu_all_cores"] = iters_per_sec / out["cpu_baseline_all_cores"]["value"]
 
     if rank == 0:
         print(json.dumps(out))

@@ -266,7 +266,8 @@ int pba_linearize(pba_engine* e, double* cost);
 int pba_step(pba_engine* e, double radius, int32_t init_scale, const pba_solver_options* o, pba_step_info* out);
 /* Make the candidate the current point (the caller then calls pba_linearize). */
 int pba_accept(pba_engine* e);
-/* Test hooks: copies of the reduced (global) system of the LAST pba_step: n = 6 * free cameras.
+/* Test hooks: copies of the reduced (global) system of the LAST pba_step (after pba_solve: of the last FULL iteration -- the
+ * gradient-only pass that ends a solve at the iteration limit leaves them alone): n = 6 * free cameras.
  * S[n*n] row-major = s_c (U - sum W P W^T) s_c + D_c^2, rhs[n], both in Jacobi-scaled space. */
 int pba_get_reduced_system(pba_engine* e, double* S, double* rhs, int32_t* n);
 /* Test hook: per-observation record of the last linearisation: [n_obs][6] = rho'*M11, M12, M22, rho'*b1, b2, rho/2. */

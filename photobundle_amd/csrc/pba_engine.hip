@@ -336,6 +336,9 @@ int peer_allreduce(pba_engine* e, int kind, int n, double* out) {
 int launch_reduce_and_solve(pba_engine* e, SolveParams so, int n, int cur, int cand, const LmState* lm, int final_pass, int n_cost_blocks,
                             const ReduceSolveParams::Fin* fin = nullptr) {
   const bool multi = e->comm.multi();
+  // The gradient-only pass neither forms nor reduces the pair blocks and the right-hand side: the reduced-system test hook
+  // (pba_get_reduced_system) keeps the system of the last FULL step instead of being overwritten with entries nobody computed
+  if (final_pass && !so.init_scale) { so.S_dbg = nullptr; so.rhs_dbg = nullptr; }
   const int grid = (e->part_stride + kReduceEntries - 1) / kReduceEntries + 1;
   const int pstride = packed_stride(n);
   ReduceParams rp{};

@@ -142,6 +142,12 @@ extern "C" int pba_solve(pba_engine* e, const pba_solver_options* o, pba_solver_
   std::snprintf(sum->message, sizeof(sum->message), "Maximum number of iterations reached.");
   double blocks = (double)pba_internal_local_blocks(e);
   if (pba_internal_allreduce_host(e, &blocks, 1, 0)) return PBA_ERR_COMM;
+  // ceres::Solver::Summary counts in `int` (the reference's numResiduals too): a window beyond that range is refused up front
+  // instead of reporting a wrapped count (3.2 M blocks x 121 pixels x 8 channels would)
+  if (blocks * pba_internal_patch_len(e) > 2147483647.0) {
+    std::snprintf(sum->message, sizeof(sum->message), "%.0f residual blocks x %d residuals exceed the int32 range of the summary", blocks, pba_internal_patch_len(e));
+    return PBA_ERR_INVALID;
+  }
   sum->num_residual_blocks = (int32_t)blocks;
   sum->num_residuals = (int32_t)(blocks * pba_internal_patch_len(e));
   sum->fixed_cost = 0.0;   // every residual block has a free point

@@ -139,7 +139,7 @@ __device__ __forceinline__ void reduce_partials(const ReduceParams& rp, double (
       double s = s_red[0][0]; int ff = s_f[0];
       for (int w = 1; w < kReduceThreads / 64; ++w) { s += s_red[w][0]; ff |= s_f[w]; }
       packed_store<STORE>(rp.packed + TRI + 2 * n, s);
-      rp.scal[kEvalFailLin] = (double)ff;
+      packed_store<STORE>(rp.scal + kEvalFailLin, (double)ff);      // (read by the LAST workgroup of this launch when it decides: not a plain store)
       if (n >= 0) packed_store<STORE>(rp.packed + tri_index(n) + n, 0.0);      // the unused corner (n, n) of the augmented matrix
     }
   }

@@ -8,7 +8,6 @@ with noisy depth; descriptors are integer-pixel patches of the birth frame (refe
 """
 import hashlib
 import os
-import pickle
 
 import numpy as np
 
@@ -129,25 +128,58 @@ def make_window(n_frames=8, n_points=50000, radius=2, size=KITTI_SIZE, K=KITTI_K
                   frames.  One frame does not hold 200k sites that stay inside a 16-frame window (BASELINE configs[3]):
                   that shape uses (0, 8).
     """
-    # PBA_WINDOW_CACHE=<dir> (dev tool: A/B timing loops on the GPU box spend 20-40 s per process generating the same window):
-    # the finished problem is pickled there, keyed by every argument; windows with a caller-supplied channel_fn are not cached
+    # PBA_WINDOW_CACHE=<dir> (dev tool: A/B timing loops on the GPU box spend 20-40 s per process generating the same window): the
+    # finished problem is kept there as an .npz of plain arrays (np.load with allow_pickle=False: nothing in the file can execute),
+    # keyed by every argument AND by the sources that generate it (an edit to the generator never reuses a stale window); the
+    # directory is created private to the user.  Windows with a caller-supplied channel_fn are not cached.
     cache_file = None
     if os.environ.get("PBA_WINDOW_CACHE") and channel_fn is None:
         key = repr((n_frames, n_points, radius, tuple(size), tuple(K), visibility, huber, gaussian, depth_noise, rot_deg, trans,
-                    seed_offset, point_seed_offset, tuple(dense_births)))
-        cache_file = os.path.join(os.environ["PBA_WINDOW_CACHE"], "window_%s.pkl" % hashlib.sha1(key.encode()).hexdigest()[:16])
+                    seed_offset, point_seed_offset, tuple(dense_births), _generator_fingerprint()))
+        cache_file = os.path.join(os.environ["PBA_WINDOW_CACHE"], "window_%s.npz" % hashlib.sha1(key.encode()).hexdigest()[:16])
         if os.path.exists(cache_file):
-            with open(cache_file, "rb") as f:
-                return pickle.load(f)
+            return _window_from_npz(cache_file)
     prob = _make_window(n_frames, n_points, radius, size, K, visibility, huber, gaussian, depth_noise, rot_deg, trans, seed_offset,
                         point_seed_offset, dense_births, channel_fn)
     if cache_file is not None:
-        os.makedirs(os.path.dirname(cache_file), exist_ok=True)
-        tmp = cache_file + ".%d.tmp" % os.getpid()
-        with open(tmp, "wb") as f:
-            pickle.dump(prob, f, protocol=4)
+        os.makedirs(os.path.dirname(cache_file), mode=0o700, exist_ok=True)
+        tmp = cache_file + ".%d.tmp.npz" % os.getpid()
+        _window_to_npz(prob, tmp)
         os.replace(tmp, cache_file)
     return prob
+
+
+_ARRAYS = ("planes", "cams", "xyz", "desc", "obs_point", "obs_slot", "weights", "images")
+_META_ARRAYS = ("cams_gt", "T_gt", "T_init", "local_init", "depths")
+
+
+def _generator_fingerprint():
+    h = hashlib.sha1()
+    here = os.path.dirname(os.path.abspath(__file__))
+    for name in ("synthetic.py", "imgproc.py", "se3.py", "problem.py"):
+        with open(os.path.join(here, name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _window_to_npz(p, path):
+    d = {k: getattr(p, k) for k in _ARRAYS}
+    d.update({"meta_" + k: np.asarray(p.meta[k]) for k in _META_ARRAYS})
+    d["scalars"] = np.array([p.radius, p.fixed_slot, p.channels], np.int64)
+    d["K"] = np.array(p.K, np.float64)
+    d["huber"] = np.array([p.huber], np.float64)
+    d["visibility"] = np.frombuffer(str(p.meta["visibility"]).encode(), np.uint8)
+    with open(path, "wb") as f:
+        np.savez(f, **d)
+
+
+def _window_from_npz(path):
+    with np.load(path, allow_pickle=False) as z:
+        radius, fixed_slot, channels = (int(v) for v in z["scalars"])
+        meta = {k: z["meta_" + k] for k in _META_ARRAYS}
+        meta["visibility"] = bytes(z["visibility"]).decode()
+        return WindowProblem(K=tuple(float(v) for v in z["K"]), radius=radius, huber=float(z["huber"][0]), fixed_slot=fixed_slot,
+                             channels=channels, meta=meta, **{k: z[k] for k in _ARRAYS})
 
 
 def _make_window(n_frames, n_points, radius, size, K, visibility, huber, gaussian, depth_noise, rot_deg, trans, seed_offset,

@@ -199,3 +199,26 @@ def test_rejected_first_step_is_logged_as_rejected():
             assert np.isclose(a["cost"], b["cost"], rtol=1e-9) and np.isclose(a["relative_decrease"], b["relative_decrease"], rtol=1e-6, atol=1e-12)
         assert res["num_successful_steps"] == ref["num_successful_steps"]
 
+
+
+@pytest.mark.parametrize("n_it", [0, 5])
+def test_non_finite_initial_point_is_an_evaluation_failure_and_leaves_no_stale_flag(n_it):
+    """the zero-iteration solve decides in the last workgroup of the gradient-only pass, which reads the
+    non-finite flag another workgroup of the same launch wrote -- a plain store there is not visible across XCDs.  A NaN descriptor
+    must end the solve as Ceres does ("Initial residual and Jacobian evaluation failed."), and a clean solve on the same engine
+    right after must not inherit the flag."""
+    p = synthetic.make_window(n_frames=4, n_points=400, radius=2, **SMALL)
+    bad = copy.copy(p)
+    bad.desc = p.desc.copy()
+    bad.desc.reshape(p.n_points, -1)[123, 7] = np.nan      # a non-finite residual in every block of point 123
+    opts = default_solver_options(max_num_iterations=n_it)
+    with Engine(SMALL["size"][0], SMALL["size"][1], p.K, p.radius, p.n_frames, huber=p.huber) as e:
+        for rep in range(3):
+            e.load(bad)
+            r = e.solve(opts)
+            assert "evaluation failed" in r["message"], r["message"]
+            assert len(r["iterations"]) == 0
+            e.load(p)
+            r = e.solve(opts)
+            assert "evaluation failed" not in r["message"], r["message"]
+            assert len(r["iterations"]) >= 1 and np.isfinite(r["iterations"][0]["cost"])

@@ -64,6 +64,7 @@ def _make(c):
 
 
 ARBITRATED = []      # seed offsets of the cases of this session that needed the step arbiter
+RAN = []             # seed offsets of the cases that ran to the end in THIS process (the rarity check below needs all of them)
 
 
 @pytest.mark.timeout(600)
@@ -171,10 +172,15 @@ def test_random_shape(case):
     else:
         assert cam_dist <= bar
     print("worst record error:", worst)
+    RAN.append(case["seed_offset"])
 
 
 def test_arbitrated_cases_stay_rare():
     """The arbiter is for the odd window whose one-ulp twin under-states the rounding band (3 of 240 on the round-4 build): a build
     that needs it for more than 1 case in 40 (and more than one case at all) has a precision problem, whatever the arbiter says."""
-    print("cases that needed the step arbiter: %s of %d" % (ARBITRATED, len(CASES)))
+    print("cases that needed the step arbiter: %s of %d (%d ran in this process)" % (ARBITRATED, len(CASES), len(RAN)))
+    # under pytest-xdist, -k selections or reordering this process has seen only some of the cases: a ceiling on a subset would pass
+    # vacuously (ADVICE r5), so the check says so instead
+    if sorted(RAN) != sorted(c["seed_offset"] for c in CASES):
+        pytest.skip("only %d of %d cases ran in this process: the rarity ceiling needs the whole sweep" % (len(RAN), len(CASES)))
     assert len(ARBITRATED) <= max(1, len(CASES) // 40), ARBITRATED

@@ -5,7 +5,7 @@ these tests rule out is a shared mistake in weights, border rule, sampling grid 
 the device producers, which all derive from the same reading of that documentation."""
 import numpy as np
 import pytest
-from scipy import ndimage
+ndimage = pytest.importorskip("scipy.ndimage")      # a box without scipy skips instead of failing collection
 
 from oracle import oracle
 

@@ -9,8 +9,9 @@ both optimisers look for the same fixed point J^T r = 0.  Only camera 0 is const
 gauge freedom, so the minimum is compared through its COST and through gauge-free quantities (the re-projections)."""
 import numpy as np
 import pytest
-from scipy.optimize import least_squares
-from scipy.spatial.transform import Rotation
+pytest.importorskip("scipy")      # a box without scipy skips these cross-checks instead of failing collection
+from scipy.optimize import least_squares      # noqa: E402
+from scipy.spatial.transform import Rotation      # noqa: E402
 
 from oracle import oracle
 from photobundle_amd import synthetic

@@ -4,7 +4,7 @@ Calibration::project (reference src/photobundle.cc:696-706, src/calibration.h:34
 at machine precision (the central-difference check of test_oracle_solver.py stops at 1e-6).  SURVEY.md 8c names this cross-check."""
 import numpy as np
 import pytest
-import sympy as sp
+sp = pytest.importorskip("sympy")      # a box without sympy skips this cross-check instead of failing collection
 
 from oracle import oracle
 from photobundle_amd import synthetic
