@@ -11,6 +11,7 @@
 
 #include <cfloat>
 #include <climits>
+#include <type_traits>
 
 // Per-phase cycle stamps inside the kernels (PBA_SCHUR_TIMING=1|2 at run time) cost registers and a device printf, so
 // they are compiled in only on request: make TIMING=1.
@@ -99,7 +100,8 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane) {
 
 // Cooperative copy of the per-camera geometry table into LDS (8-byte words, coalesced): the per-lane gathers of
 // ~50 doubles per observation then hit LDS instead of going through the vector memory path.
-template <int NT>
+// AG: the table was written by another workgroup of the SAME launch (resident solve): agent-scope loads
+template <int NT, bool AG = false>
 __device__ __forceinline__ void stage_geom(const CamGeom* __restrict__ src, CamGeom* dst, int n_frames, int tid) {
   static_assert(sizeof(CamGeom) % 8 == 0, "CamGeom is copied as 8-byte words");
   const unsigned long long* s = reinterpret_cast<const unsigned long long*>(src);
@@ -109,7 +111,11 @@ __device__ __forceinline__ void stage_geom(const CamGeom* __restrict__ src, CamG
   constexpr int IT = (kMaxFrames * (int)(sizeof(CamGeom) / 8) + NT - 1) / NT;
   unsigned long long v[IT];
 #pragma unroll
-  for (int u = 0; u < IT; ++u) { const int k = tid + u * NT; v[u] = (k < n) ? s[k] : 0ull; }
+  for (int u = 0; u < IT; ++u) {
+    const int k = tid + u * NT;
+    if (AG) v[u] = (k < n) ? __hip_atomic_load(s + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    else v[u] = (k < n) ? s[k] : 0ull;
+  }
 #pragma unroll
   for (int u = 0; u < IT; ++u) { const int k = tid + u * NT; if (k < n) d[k] = v[u]; }
 }
@@ -851,7 +857,7 @@ __device__ __forceinline__ FusedIdx fused_prefetch_indices(const SampleParams& p
   return f;
 }
 
-template <int NT>
+template <int NT, bool AG = false>
 __device__ __forceinline__ void fused_stage_step_table(const SampleParams& p, double* s_bk) {
   if (!p.skip_backsub) {
     // Branch-free: every entry issues the same seven loads (three table words, the rotation part of the camera step, one translation
@@ -875,10 +881,13 @@ __device__ __forceinline__ void fused_stage_step_table(const SampleParams& p, do
       const bool rot = (k >= 12) && (k < 21);
       const int j = rot ? k - 12 : 0;
       const int o0 = (k < 9) ? oR + k : ((k < 12) ? oT + (k - 9) : oD + j);
-      const double w0 = g[o0], w1 = g[oD + 9 + j], w2 = g[oD + 18 + j];
-      const double d0 = dc[0], d1 = dc[1], d2 = dc[2];
-      const double dt = dc[(k >= 21 && k < 24) ? 3 + (k - 21) : 3];
-      const int32_t fidx = reinterpret_cast<const int32_t*>(g)[oF];
+      // (AG: geometry and camera step were written by the solving workgroup of the SAME launch -- agent-scope loads)
+      auto ld = [](const double* q) { return AG ? load_agent(q) : *q; };
+      const double w0 = ld(g + o0), w1 = ld(g + oD + 9 + j), w2 = ld(g + oD + 18 + j);
+      const double d0 = ld(dc), d1 = ld(dc + 1), d2 = ld(dc + 2);
+      const double dt = ld(dc + ((k >= 21 && k < 24) ? 3 + (k - 21) : 3));
+      const int32_t fidx = AG ? __hip_atomic_load(reinterpret_cast<const int32_t*>(g) + oF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                              : reinterpret_cast<const int32_t*>(g)[oF];
       double val = rot ? d0 * w0 + d1 * w1 + d2 * w2 : w0;
       if (k >= 21) val = (k < 24) ? dt : (double)fidx;
       if (e_raw < n_e) s_bk[e] = val;
@@ -888,10 +897,13 @@ __device__ __forceinline__ void fused_stage_step_table(const SampleParams& p, do
 
 // Phase 0 of the fused kernels: back-substitution (SchurEliminator::BackSubstitute) for the workgroup's whole points; on
 // return X is the CANDIDATE point parameters of the lane's observation.  s_bs: [NT][3] doubles of LDS scratch.
-template <int NT>
+// RL = ResLane<R> of the resident solve (point, records, scale and P | g_p | D^2 come from it, the candidate goes back there), or
+// `const void` on the three-kernel path (everything through global memory)
+template <int NT, class RL = const void>
 __device__ __forceinline__ void fused_backsub(const SampleParams& p, const double* rays, const FusedIdx& fi, const double* s_bk,
                                               double* s_bs, int& pt, int& slot, int& obs, bool& active, double (&X)[3],
-                                              double& bs_mcc, double& bs_st2, double& bs_x2) {
+                                              double& bs_mcc, double& bs_st2, double& bs_x2, RL* rl = nullptr) {
+  constexpr bool RES = !std::is_void<RL>::value;
   // delta_p = -P (g_p + sum_l W_l^T delta_c[slot_l]),  W_l^T delta_c = Ap^T M' (Ac delta_c)
   const int half = threadIdx.x >> 7, lt = threadIdx.x & 127;
   const int4 ti = fi.ti;
@@ -906,6 +918,15 @@ __device__ __forceinline__ void fused_backsub(const SampleParams& p, const doubl
     pt = fi.pt;
     slot = fi.slot;
     l0 = fi.l0; cnt = fi.cnt;
+    if constexpr (RES) {
+      X[0] = rl->X[0]; X[1] = rl->X[1]; X[2] = rl->X[2];
+      if (!p.skip_backsub) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) pr[k] = rl->pr[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) spk[k] = rl->sp[k];
+      }
+    } else {
     const double* xsrc = p.skip_backsub ? p.xyz : p.xyz_prev;
     X[0] = xsrc[3 * (size_t)pt]; X[1] = xsrc[3 * (size_t)pt + 1]; X[2] = xsrc[3 * (size_t)pt + 2];
     // issued here (same dependency level as X) so that they are in flight across the barrier below
@@ -914,6 +935,7 @@ __device__ __forceinline__ void fused_backsub(const SampleParams& p, const doubl
     for (int k = 0; k < 12; ++k) pr[k] = p.ptrec[12 * (size_t)pt + k];
 #pragma unroll
     for (int k = 0; k < 3; ++k) spk[k] = p.sp[3 * (size_t)pt + k];
+    }
     }
     const double* bk = s_bk + kBk * slot;
     if (!p.skip_backsub && bk[24] >= 0.0) {
@@ -932,7 +954,9 @@ __device__ __forceinline__ void fused_backsub(const SampleParams& p, const doubl
       const double s1 = bk[15] * Xw[0] + bk[16] * Xw[1] + bk[17] * Xw[2] + bk[22];
       const double s2 = bk[18] * Xw[0] + bk[19] * Xw[1] + bk[20] * Xw[2] + bk[23];
       const double t0 = ju0 * s0 + ju2 * s2, t1 = jv1 * s1 + jv2 * s2;
-      const double m0 = p.rec_prev[0 * p.rec_stride + obs], m1 = p.rec_prev[1 * p.rec_stride + obs], m2 = p.rec_prev[2 * p.rec_stride + obs];
+      double m0, m1, m2;
+      if constexpr (RES) { m0 = rl->rec[0]; m1 = rl->rec[1]; m2 = rl->rec[2]; }
+      else { m0 = p.rec_prev[0 * p.rec_stride + obs]; m1 = p.rec_prev[1 * p.rec_stride + obs]; m2 = p.rec_prev[2 * p.rec_stride + obs]; }
       const double u0 = m0 * t0 + m1 * t1, u1 = m1 * t0 + m2 * t1;
       // W_l^T dc = Ap^T u = R^T (dpi^T u)
       const double w0 = ju0 * u0, w1 = jv1 * u1, w2 = ju2 * u0 + jv2 * u1;
@@ -975,10 +999,13 @@ __device__ __forceinline__ void fused_backsub(const SampleParams& p, const doubl
         bs_mcc += 0.5 * yk * (sk * pr[6 + k]) + 0.5 * pr[9 + k] * yk * yk;
         bs_st2 += d[k] * d[k];
         bs_x2 += X[k] * X[k];
-        const_cast<double*>(p.xyz)[3 * (size_t)pt + k] = X[k] + d[k];
+        if constexpr (!RES) const_cast<double*>(p.xyz)[3 * (size_t)pt + k] = X[k] + d[k];
       }
       X[k] = X[k] + d[k];
     }
+  }
+  if constexpr (RES) {      // (the candidate of the lane's point; a first linearisation samples at the current one)
+    rl->Xc[0] = X[0]; rl->Xc[1] = X[1]; rl->Xc[2] = X[2];
   }
 }
 
@@ -1121,50 +1148,78 @@ constexpr int sample_stage_groups(int ng, int per_group) {
   return best;
 }
 
-// amdgpu_waves_per_eu(N, N): the register allocator / scheduler works for exactly N resident waves per SIMD (with only a
-// lower bound it trades instruction-level parallelism for an occupancy the kernel does not profit from: measured).
-template <int R, bool JAC, int WAVES, bool FUSED, bool UNITW, bool FAST>
-__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu((R <= 2 ? (JAC ? PBA_SAMPLE_WAVES_PER_SIMD : 2) : (R >= 4 ? PBA_SAMPLE_WAVES_LARGE : 2)), (R <= 2 ? (JAC ? PBA_SAMPLE_WAVES_PER_SIMD : 2) : (R >= 4 ? PBA_SAMPLE_WAVES_LARGE : 2)))))
-void k_sample(SampleParams p_in) {
+// LDS of one sampling workgroup (k_sample; the sampling phase of the resident solve, pba_resident.h, aliases it with the other phases')
+// texel-major LDS layout [t][lane]: the walk reads stride-1 across lanes; the odd stride keeps the staging stores of
+// the vector row segments at the 2-way minimum (64 lanes on 32 banks) and four workgroups within 160 KB of LDS.
+constexpr int kSampleLdsStride = 65;
+struct SampleIrrRec { double u, v; int32_t wyx, pt, src, pad; };
+constexpr int kSampleIrrCap = 32;
+template <int R, int WAVES>
+struct SampleSmem {
+  static constexpr int F = 2 * R + 2;
+  static constexpr int RB = sample_rows_per_batch(R);
+  static constexpr int FF = RB * F;                      // texels of one batch
+  static constexpr size_t kTexBytes = sizeof(uint32_t) * WAVES * FF * kSampleLdsStride;
+  static constexpr size_t kPreBytes = sizeof(double) * 3 * WAVES * 64 + 2 * kMaxFrames * sizeof(CamGeom);
+  static_assert(kTexBytes >= sizeof(double) * 4 * WAVES * 64, "the finalisation reuses the texel region");
+  alignas(16) char raw[kTexBytes > kPreBytes ? kTexBytes : kPreBytes];
+  alignas(8) int32_t bi[2][WAVES][64];
+  // r4: the windowed irregular observations of the WHOLE workgroup go through one queue and are dealt round robin to its four
+  // waves (the wave that owned three border patches used to hold the other three -- and their LDS -- for its per-tap passes)
+  SampleIrrRec q[(RB == F) ? kSampleIrrCap : 1];
+  int32_t icnt[WAVES];
+  uint32_t win[(RB == F) ? 1 : WAVES][(RB == F) ? 1 : F * F];   // large radii: the clamped window of ONE irregular observation per wave
+  double red[4 * WAVES];
+  int32_t fail;
+};
+static_assert(sizeof(double) * 6 * kSampleIrrCap <= sizeof(int32_t) * 2 * 4 * 64, "the six sums of every queued patch fit s_base | s_irr");
+
+// Per-lane state of the RESIDENT solve (pba_resident.h: one launch per solve, every workgroup owns a fixed pair of whole-point
+// tiles): what the three-kernel path re-reads from global memory in every kernel of every iteration -- the observation's indices,
+// its point, the Jacobian-pass records, the point's Jacobi scale / damped inverse / gradient, the descriptor -- stays in registers.
+template <int R>
+struct ResLane {
+  int4 ti;                     // tile descriptor {first observation, observations, first point, points}
+  int pt, slot, l0, cnt;       // lane_rec of the lane's observation
+  double X[3], Xc[3];          // parameters of the lane's point: current | candidate
+  double rec[6], recc[6];      // rho' M11, M12, M22, rho' b1, b2, rho / 2 at the current | candidate point
+  double sp[3];                // Jacobi scale of the point's columns
+  double pr[12];               // P (6) | g_p (3) | D_p^2 (3) of the point at the current linearisation
+  float desc[(2 * R + 1) * (2 * R + 1)];
+};
+
+// The body of the sampling kernel for ONE 256-thread workgroup `bid` (see k_sample below for the template switches).
+//   RES: phase of the resident solve -- indices, points, previous records and descriptors come from `rl`, the candidate point and
+//        its records go back there; tables produced by other workgroups of the SAME launch are read with agent-scope loads; the
+//        step finalisation (ticket, fixed-order reduction, decision) is the caller's.
+template <int R, bool JAC, int WAVES, bool FUSED, bool UNITW, bool FAST, bool RES>
+__device__ __forceinline__ void sample_wg(SampleParams& p, SampleSmem<R, WAVES>& sm, ResLane<R>& rl, const int bid, const int n_blocks) {
   static_assert(!FUSED || (WAVES * 64) % 128 == 0, "fused tiles are 128 observations");
   static_assert(!FAST || UNITW, "the reduced-precision walk assumes unit patch weights");
-  SampleParams p = p_in;
-  if (!PBA_PHASE_TIMING) p.dbg = nullptr;
+  static_assert(!RES || (FUSED && !FAST), "the resident phase is the fused exact kernel");
   // inverse-depth variant (point_world): null for the reference's free world points
   const double* rays = p.rays;
-  if (FUSED && !fused_resolve_parity(p)) return;
-  if (FUSED && p.lm_init_dst && blockIdx.x == 0 && threadIdx.x < sizeof(LmState) / 4)      // (consumed by the NEXT kernel of the stream)
-    reinterpret_cast<unsigned*>(p.lm_init_dst)[threadIdx.x] = __hip_atomic_load(reinterpret_cast<const unsigned*>(p.lm_init_src) + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   constexpr int W = 2 * R + 1;      // patch side
   constexpr int F = 2 * R + 2;      // footprint side
   constexpr int RB = sample_rows_per_batch(R);   // footprint rows staged per batch
   constexpr int NB = (F + RB - 1) / RB;
   constexpr int FF = RB * F;                      // texels of one batch
-  // texel-major LDS layout [t][lane]: the walk reads stride-1 across lanes; the odd stride keeps the staging stores of
-  // the vector row segments at the 2-way minimum (64 lanes on 32 banks) and four workgroups within 160 KB of LDS.
-  constexpr int LSTRIDE = 65;
-  constexpr size_t kTexBytes = sizeof(uint32_t) * WAVES * FF * LSTRIDE;
-  static_assert(kTexBytes >= sizeof(double) * 4 * WAVES * 64, "the finalisation reuses the texel region");
-  constexpr size_t kPreBytes = sizeof(double) * 3 * WAVES * 64 + 2 * kMaxFrames * sizeof(CamGeom);
-  __shared__ __attribute__((aligned(16))) char s_raw[kTexBytes > kPreBytes ? kTexBytes : kPreBytes];
+  constexpr int LSTRIDE = kSampleLdsStride;
+  char* s_raw = sm.raw;
   uint32_t (*s_tex)[FF * LSTRIDE] = reinterpret_cast<uint32_t (*)[FF * LSTRIDE]>(s_raw);
-  __shared__ __attribute__((aligned(8))) int32_t s_bi[2][WAVES][64];
+  auto& s_bi = sm.bi;
   int32_t (*s_base)[64] = s_bi[0];
   int32_t (*s_irr)[64] = s_bi[1];        // (by0 << 16) | bx0: window anchor of the observations staged with clamped coordinates
-  // r4: the windowed irregular observations of the WHOLE workgroup go through one queue and are dealt round robin to its four
-  // waves (the wave that owned three border patches used to hold the other three -- and their LDS -- for its per-tap passes)
-  struct IrrRec { double u, v; int32_t wyx, pt, src, pad; };
-  constexpr int kIrrCap = 32;
-  __shared__ IrrRec s_q[(sample_rows_per_batch(R) == 2 * R + 2) ? kIrrCap : 1];
-  __shared__ int32_t s_icnt[WAVES];
-  static_assert(sizeof(double) * 6 * kIrrCap <= sizeof(int32_t) * 2 * WAVES * 64, "the six sums of every queued patch fit s_base | s_irr");
-  __shared__ uint32_t s_win[(sample_rows_per_batch(R) == 2 * R + 2) ? 1 : WAVES][(sample_rows_per_batch(R) == 2 * R + 2) ? 1 : (2 * R + 2) * (2 * R + 2)];   // large radii: the clamped window of ONE irregular observation per wave
-  __shared__ double s_red[4 * WAVES];
-  __shared__ int32_t s_fail;
+  using IrrRec = SampleIrrRec;
+  constexpr int kIrrCap = kSampleIrrCap;
+  auto& s_q = sm.q;
+  auto& s_icnt = sm.icnt;
+  auto& s_win = sm.win;
+  auto& s_red = sm.red;
+  int32_t& s_fail = sm.fail;
 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int bid = xcd_logical_block(blockIdx.x, gridDim.x);
   int obs = bid * (WAVES * 64) + threadIdx.x;
   bool active = obs < p.n_obs;
   if (threadIdx.x == 0) s_fail = 0;
@@ -1179,9 +1234,10 @@ void k_sample(SampleParams p_in) {
   // fused form: the tile descriptor and the observation's indices do not depend on the tables -- requested first so
   // that their two dependent round trips overlap the table loads instead of following the barrier
   FusedIdx fi{make_int4(0, 0, 0, 0), 0, 0, 0, 0};
-  if (FUSED) fi = fused_prefetch_indices<WAVES * 64>(p, bid);
-  stage_geom<WAVES * 64>(p.geom, s_geom, p.n_frames, threadIdx.x);
-  if (FUSED) fused_stage_step_table<WAVES * 64>(p, s_bk);
+  if constexpr (RES) { fi.ti = rl.ti; fi.pt = rl.pt; fi.slot = rl.slot; fi.l0 = rl.l0; fi.cnt = rl.cnt; }
+  else if (FUSED) fi = fused_prefetch_indices<WAVES * 64>(p, bid);
+  stage_geom<WAVES * 64, RES>(p.geom, s_geom, p.n_frames, threadIdx.x);
+  if (FUSED) fused_stage_step_table<WAVES * 64, RES>(p, s_bk);
   lds_barrier();
   PBA_STK(0);
 
@@ -1190,7 +1246,8 @@ void k_sample(SampleParams p_in) {
   double bs_mcc = 0.0, bs_st2 = 0.0, bs_x2 = 0.0;
   if (FUSED) {
     // ---- phase 0: back-substitution for this workgroup's points (fused_backsub) ------------------------------
-    fused_backsub<WAVES * 64>(p, rays, fi, s_bk, reinterpret_cast<double*>(&s_tex[0][0]), pt, slot, obs, active, X, bs_mcc, bs_st2, bs_x2);
+    if constexpr (RES) fused_backsub<WAVES * 64, ResLane<R>>(p, rays, fi, s_bk, reinterpret_cast<double*>(&s_tex[0][0]), pt, slot, obs, active, X, bs_mcc, bs_st2, bs_x2, &rl);
+    else fused_backsub<WAVES * 64>(p, rays, fi, s_bk, reinterpret_cast<double*>(&s_tex[0][0]), pt, slot, obs, active, X, bs_mcc, bs_st2, bs_x2);
     if (PBA_STEP_SUMS_EARLY) fused_wave_step_sums(bs_mcc, bs_st2, bs_x2);
   } else if (active) {
     pt = p.obs_point[obs];
@@ -1459,7 +1516,7 @@ void k_sample(SampleParams p_in) {
             }
             if (r >= 1) {
               const float sI = vlerp_u8_interior(dy, omdy, Hp[0][j], h0);
-              const double e = (double)p0[i * W + j] - (double)sI;   // photobundle.cc:720 (i0 - i1)
+              const double e = (double)(RES ? rl.desc[i * W + j] : p0[i * W + j]) - (double)sI;   // photobundle.cc:720 (i0 - i1)
               if (UNITW) {
                 cc = fma(e, e, cc);
                 if (JAC) {
@@ -1708,7 +1765,8 @@ void k_sample(SampleParams p_in) {
       const double rv[6] = {rho1 * m11, rho1 * m12, rho1 * m22, rho1 * b1, rho1 * b2, cost_obs};
 #pragma unroll
       for (int k = 0; k < 6; ++k) {
-        if (PBA_REC_SC1) store_agent(p.rec + k * p.rec_stride + obs, rv[k]);
+        if constexpr (RES) rl.recc[k] = rv[k];      // (resident solve: the record never leaves the lane)
+        else if (PBA_REC_SC1) store_agent(p.rec + k * p.rec_stride + obs, rv[k]);
         else __builtin_nontemporal_store(rv[k], p.rec + k * p.rec_stride + obs);
       }
     }
@@ -1734,7 +1792,23 @@ void k_sample(SampleParams p_in) {
   tk[0] |= (unsigned long long)(__builtin_amdgcn_s_getreg(6164) & 15u) << 56;   // HW_REG_XCC_ID[3:0]
   if (p.dbg && threadIdx.x == 0) for (int k = 0; k < 8; ++k) p.dbg[blockIdx.x * 8 + k] = tk[k];
 #undef PBA_STK
-  if (FUSED) fused_finalize<WAVES>(p, lane, wave, &s_base[0][0], reinterpret_cast<double*>(&s_tex[0][0]), t_begin);
+  (void)n_blocks;
+  if (FUSED && !RES) fused_finalize<WAVES>(p, lane, wave, &s_base[0][0], reinterpret_cast<double*>(&s_tex[0][0]), t_begin);
+}
+
+// amdgpu_waves_per_eu(N, N): the register allocator / scheduler works for exactly N resident waves per SIMD (with only a
+// lower bound it trades instruction-level parallelism for an occupancy the kernel does not profit from: measured).
+template <int R, bool JAC, int WAVES, bool FUSED, bool UNITW, bool FAST>
+__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu((R <= 2 ? (JAC ? PBA_SAMPLE_WAVES_PER_SIMD : 2) : (R >= 4 ? PBA_SAMPLE_WAVES_LARGE : 2)), (R <= 2 ? (JAC ? PBA_SAMPLE_WAVES_PER_SIMD : 2) : (R >= 4 ? PBA_SAMPLE_WAVES_LARGE : 2)))))
+void k_sample(SampleParams p_in) {
+  SampleParams p = p_in;
+  if (!PBA_PHASE_TIMING) p.dbg = nullptr;
+  if (FUSED && !fused_resolve_parity(p)) return;
+  if (FUSED && p.lm_init_dst && blockIdx.x == 0 && threadIdx.x < sizeof(LmState) / 4)      // (consumed by the NEXT kernel of the stream)
+    reinterpret_cast<unsigned*>(p.lm_init_dst)[threadIdx.x] = __hip_atomic_load(reinterpret_cast<const unsigned*>(p.lm_init_src) + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __shared__ SampleSmem<R, WAVES> sm;
+  ResLane<R> unused;      // (three-kernel path: nothing is resident)
+  sample_wg<R, JAC, WAVES, FUSED, UNITW, FAST, false>(p, sm, unused, xcd_logical_block(blockIdx.x, gridDim.x), (int)gridDim.x);
 }
 
 // =====================================================================================================
@@ -2239,19 +2313,15 @@ __device__ __forceinline__ int sym6(int i, int j) {  // packed upper triangle of
 //   [0, 36 n_pairs)           T: pair (a <= b, enumerated row by row) -> row-major 6x6 block (a, b)
 //   [.., +n) rhs   [.., +n) g_c   [.., +n) diag(U)
 //   partial only: +0 gmax_pts, +1 gnorm2_pts, +2 schur_fail
-__global__ __launch_bounds__(kTile, 2) void k_schur(SchurParams p_in) {
-  SchurParams p = p_in;
-  if (!PBA_PHASE_TIMING) p.dbg = nullptr;
-  if (p.pub_host_seq && blockIdx.x == 0)
-    lm_publish(p.lm, p.pub_state, p.pub_scal, p.pub_host_scal, p.pub_host_seq, p.pub_seq, threadIdx.x, kTile);
-  if (p.lm) {
-    if (p.lm->done && !p.final_pass) return;
-    if (p.final_pass && !lm_final_pass_needed(p.lm)) return;
-    if (p.lm->cur != p.enq_cur) { p.xyz = p.xyz_alt; p.geom = p.geom_alt; p.rec = p.rec_alt; }
-    p.radius = p.lm->radius;
-    p.inv_radius = 1.0 / p.radius;
-  }
-  __shared__ __attribute__((aligned(16))) char smem[kSchurSmemBytes];
+// The body of k_schur for the 128 threads `tid` of one tile owner.
+//   three-kernel path (RL = const void): persistent loop over the tiles part, part + n_parts, ...; everything through global memory.
+//   resident solve (RL = ResLane<R>, pba_resident.h): ONE tile per call whose indices, point, records and Jacobi scale come from the
+//   lane's registers and whose P | g_p | D^2 go back there; the camera table is already in LDS (`geom_res`); `has_tile` = false for the
+//   idle half of the last workgroup (it only keeps the barriers company).
+template <class RL>
+__device__ __forceinline__ void schur_body(SchurParams& p, char* smem, const int tid, const int part, const int n_parts, RL* rl,
+                                           const CamGeom* geom_res, const bool has_tile) {
+  constexpr bool RES = !std::is_void<RL>::value;
   double* s_obs = reinterpret_cast<double*>(smem);                       // [kTile][kObsStride]
   // V_l (6) g_l (3) per lane live INSIDE the s_obs region (after the staged camera table, before W | Y are
   // written): 40 KB per workgroup => 4 workgroups per CU instead of 3
@@ -2263,7 +2333,6 @@ __global__ __launch_bounds__(kTile, 2) void k_schur(SchurParams p_in) {
   double* s_red = s_obs + kTile * kObsStride;                            // [kTile]
   int8_t* s_lane_of = reinterpret_cast<int8_t*>(s_red + kTile);          // [kMaxFrames (FREE index)][kTile points]: a camera's lanes are contiguous bytes
 
-  const int tid = threadIdx.x;
   const int nf = p.n_free;
   const int n_groups = kTile / p.n_pairs;          // >= 1 (n_pairs <= 136 is clamped by kMaxFrames = 16 -> 120/136)
   const int grp = tid / p.n_pairs;
@@ -2296,7 +2365,7 @@ __global__ __launch_bounds__(kTile, 2) void k_schur(SchurParams p_in) {
 #pragma unroll
   for (int u = 0; u < kGeomRegs; ++u) {
     const int k = tid + u * kTile;
-    greg[u] = (k < n_geom_words) ? reinterpret_cast<const unsigned long long*>(p.geom)[k] : 0ull;
+    greg[u] = (!RES && k < n_geom_words) ? reinterpret_cast<const unsigned long long*>(p.geom)[k] : 0ull;
   }
 
   if (tid < kCamVals) s_red[tid] = 0.0;   // "row 128" of the camera-side sums: zeros (s_red is otherwise unused until the epilogue)
@@ -2305,21 +2374,27 @@ __global__ __launch_bounds__(kTile, 2) void k_schur(SchurParams p_in) {
   unsigned long long tlast = p.dbg ? __builtin_amdgcn_s_memtime() : 0;
   const unsigned long long t_rt0 = p.dbg ? __builtin_amdgcn_s_memrealtime() : 0;
 #define PBA_TICK(k) do { if (p.dbg) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); tph[k] += tn - tlast; tlast = tn; } } while (0)
-  int4 ti_next = p.tile_info[min((int)blockIdx.x, p.n_tiles - 1)];
+  int4 ti_next = make_int4(0, 0, 0, 0);
   // the observation's indices are requested one tile ahead (at the start of the pair-block phase) so that the
   // per-observation phase starts with its second round trip (point, Jacobi scale, record) instead of its first
   int nx_pt = 0, nx_slot = 0, nx_l0 = 0, nx_cnt = 0;
   double nx_x[3] = {0.0, 0.0, 0.0};
-  {
-    const int2 r = p.lane_rec[(size_t)min((int)blockIdx.x, p.n_tiles - 1) * kTile + tid];     // with the descriptor, not after it
-    nx_pt = r.x; nx_slot = r.y & 0xff; nx_l0 = (r.y >> 8) & 0xff; nx_cnt = (r.y >> 16) & 0xff;
+  if constexpr (RES) {
+    if (has_tile) { ti_next = rl->ti; nx_pt = rl->pt; nx_slot = rl->slot; nx_l0 = rl->l0; nx_cnt = rl->cnt; nx_x[0] = rl->X[0]; nx_x[1] = rl->X[1]; nx_x[2] = rl->X[2]; }
+  } else {
+    ti_next = p.tile_info[min(part, p.n_tiles - 1)];
+    {
+      const int2 r = p.lane_rec[(size_t)min(part, p.n_tiles - 1) * kTile + tid];     // with the descriptor, not after it
+      nx_pt = r.x; nx_slot = r.y & 0xff; nx_l0 = (r.y >> 8) & 0xff; nx_cnt = (r.y >> 16) & 0xff;
+    }
+    if (tid < ti_next.y) {
+      nx_x[0] = p.xyz[3 * (size_t)nx_pt]; nx_x[1] = p.xyz[3 * (size_t)nx_pt + 1]; nx_x[2] = p.xyz[3 * (size_t)nx_pt + 2];
+    }
   }
-  if (tid < ti_next.y) {
-    nx_x[0] = p.xyz[3 * (size_t)nx_pt]; nx_x[1] = p.xyz[3 * (size_t)nx_pt + 1]; nx_x[2] = p.xyz[3 * (size_t)nx_pt + 2];
-  }
-  for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
+  // (resident solve: exactly one trip, the lane's own tile)
+  for (int tile = part; RES ? (tile == part) : (tile < p.n_tiles); tile += n_parts) {
     const int4 ti = ti_next;
-    ti_next = p.tile_info[min(tile + (int)gridDim.x, p.n_tiles - 1)];   // prefetch the next tile's descriptor
+    if constexpr (!RES) ti_next = p.tile_info[min(tile + n_parts, p.n_tiles - 1)];   // prefetch the next tile's descriptor
     const int cur_pt = nx_pt, cur_slot = nx_slot, cur_l0 = nx_l0, cur_cnt = nx_cnt;
     const double cur_x[3] = {nx_x[0], nx_x[1], nx_x[2]};
     const int o0 = ti.x, n_here = ti.y, pt0 = ti.z, n_pts = ti.w;
@@ -2327,13 +2402,16 @@ __global__ __launch_bounds__(kTile, 2) void k_schur(SchurParams p_in) {
     const int obs = o0 + tid;
 
     for (int k = tid; k < kMaxFrames * kTile / 4; k += kTile) reinterpret_cast<uint32_t*>(s_lane_of)[k] = 0x80808080u;   // -128: no observation
-    CamGeom* s_geom = reinterpret_cast<CamGeom*>(s_obs);   // P1 only; P2 overwrites the region with W | Y
+    // P1 only; P2 overwrites the region with W | Y  (resident solve: the workgroup's persistent copy of the table, staged once per step)
+    const CamGeom* s_geom = RES ? geom_res : reinterpret_cast<const CamGeom*>(s_obs);
+    if constexpr (!RES) {
 #pragma unroll
     for (int u = 0; u < kGeomRegs; ++u) {
       const int k = tid + u * kTile;
-      if (k < n_geom_words) reinterpret_cast<unsigned long long*>(s_geom)[k] = greg[u];
+      if (k < n_geom_words) reinterpret_cast<unsigned long long*>(s_obs)[k] = greg[u];
     }
-    {
+    }
+    if constexpr (!RES) {
       // the words beyond the register copy (windows of 11+ frames), all in flight together
       constexpr int kTail = (kMaxFrames * (int)(sizeof(CamGeom) / 8) + kTile - 1) / kTile - kGeomRegs;
       unsigned long long gt[kTail];
@@ -2345,7 +2423,7 @@ __global__ __launch_bounds__(kTile, 2) void k_schur(SchurParams p_in) {
 #pragma unroll
       for (int u = 0; u < kTail; ++u) {
         const int k = tid + (kGeomRegs + u) * kTile;
-        if (k < n_geom_words) reinterpret_cast<unsigned long long*>(s_geom)[k] = gt[u];
+        if (k < n_geom_words) reinterpret_cast<unsigned long long*>(s_obs)[k] = gt[u];
       }
     }
     lds_barrier();
@@ -2360,7 +2438,8 @@ __global__ __launch_bounds__(kTile, 2) void k_schur(SchurParams p_in) {
       pt = cur_pt;
       const int slot = cur_slot;
       l0 = cur_l0; l1 = l0 + cur_cnt;
-      if (!p.init_scale) { s_pt[0] = p.sp[3 * (size_t)pt]; s_pt[1] = p.sp[3 * (size_t)pt + 1]; s_pt[2] = p.sp[3 * (size_t)pt + 2]; }
+      if constexpr (RES) { if (!p.init_scale) { s_pt[0] = rl->sp[0]; s_pt[1] = rl->sp[1]; s_pt[2] = rl->sp[2]; } }
+      else if (!p.init_scale) { s_pt[0] = p.sp[3 * (size_t)pt]; s_pt[1] = p.sp[3 * (size_t)pt + 1]; s_pt[2] = p.sp[3 * (size_t)pt + 2]; }
       const CamGeom& g = s_geom[slot];
       fa = g.free_index;
       const double prm[3] = {cur_x[0], cur_x[1], cur_x[2]};
@@ -2370,8 +2449,11 @@ __global__ __launch_bounds__(kTile, 2) void k_schur(SchurParams p_in) {
       transform_point(g, X, xw);
       projection_jacobians(g, X, xw, p.fx, p.fy, Ac, Ap);
       point_jacobian(p.rays, qd, Ap);
+      if constexpr (RES) { M[0] = rl->rec[0]; M[1] = rl->rec[1]; M[2] = rl->rec[2]; b[0] = rl->rec[3]; b[1] = rl->rec[4]; }
+      else {
       M[0] = p.rec[0 * p.rec_stride + obs]; M[1] = p.rec[1 * p.rec_stride + obs]; M[2] = p.rec[2 * p.rec_stride + obs];
       b[0] = p.rec[3 * p.rec_stride + obs]; b[1] = p.rec[4 * p.rec_stride + obs];
+      }
       // MAp = M Ap (2x3);  V_l = Ap^T M Ap;  g_l = -Ap^T b   (J = -w g A  =>  J^T r = -A^T b)
 #pragma unroll
       for (int k = 0; k < 3; ++k) { MAp[0][k] = M[0] * Ap[0][k] + M[1] * Ap[1][k]; MAp[1][k] = M[1] * Ap[0][k] + M[2] * Ap[1][k]; }
@@ -2439,7 +2521,8 @@ __global__ __launch_bounds__(kTile, 2) void k_schur(SchurParams p_in) {
       if (p.init_scale) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) s[k] = p.jacobi ? 1.0 / (1.0 + sqrt(vd[k])) : 1.0;
-        if (head) { p.sp[3 * (size_t)pt] = s[0]; p.sp[3 * (size_t)pt + 1] = s[1]; p.sp[3 * (size_t)pt + 2] = s[2]; }
+        if constexpr (RES) { rl->sp[0] = s[0]; rl->sp[1] = s[1]; rl->sp[2] = s[2]; }      // (every lane of the point keeps its own copy)
+        else if (head) { p.sp[3 * (size_t)pt] = s[0]; p.sp[3 * (size_t)pt + 1] = s[1]; p.sp[3 * (size_t)pt + 2] = s[2]; }
       } else {
 #pragma unroll
         for (int k = 0; k < 3; ++k) s[k] = s_pt[k];
@@ -2476,12 +2559,20 @@ __global__ __launch_bounds__(kTile, 2) void k_schur(SchurParams p_in) {
       } else if (head) {
         fail = 1;
       }
+      if constexpr (RES) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) rl->pr[k] = Pm[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { rl->pr[6 + k] = gp[k]; rl->pr[9 + k] = D2[k]; }
+      }
       if (head) {
+        if constexpr (!RES) {
         double* pr = p.ptrec + 12 * (size_t)pt;
 #pragma unroll
         for (int k = 0; k < 6; ++k) pr[k] = Pm[k];
 #pragma unroll
         for (int k = 0; k < 3; ++k) { pr[6 + k] = gp[k]; pr[9 + k] = D2[k]; }
+        }
 #pragma unroll
         for (int k = 0; k < 3; ++k) { gmax = fmax(gmax, fabs(gp[k])); gn2 += gp[k] * gp[k]; }
       }
@@ -2518,8 +2609,8 @@ __global__ __launch_bounds__(kTile, 2) void k_schur(SchurParams p_in) {
     }
     lds_barrier();
     PBA_TICK(3);
-    if (tile + (int)gridDim.x < p.n_tiles) {      // next tile's indices: two phases ahead of its coordinates
-      const int2 r = p.lane_rec[(size_t)(tile + (int)gridDim.x) * kTile + tid];
+    if (!RES && tile + n_parts < p.n_tiles) {      // next tile's indices: two phases ahead of its coordinates
+      const int2 r = p.lane_rec[(size_t)(tile + n_parts) * kTile + tid];
       nx_pt = r.x; nx_slot = r.y & 0xff; nx_l0 = (r.y >> 8) & 0xff; nx_cnt = (r.y >> 16) & 0xff;
     }
 
@@ -2555,7 +2646,7 @@ __global__ __launch_bounds__(kTile, 2) void k_schur(SchurParams p_in) {
     }
     lds_barrier();
     PBA_TICK(4);
-    if (tile + (int)gridDim.x < p.n_tiles && tid < ti_next.y) {      // next tile's point coordinates: one phase ahead
+    if (!RES && tile + n_parts < p.n_tiles && tid < ti_next.y) {      // next tile's point coordinates: one phase ahead
       nx_x[0] = p.xyz[3 * (size_t)nx_pt]; nx_x[1] = p.xyz[3 * (size_t)nx_pt + 1]; nx_x[2] = p.xyz[3 * (size_t)nx_pt + 2];
     }
     if (grad_only) continue;      // (uniform) the barrier above already separates this tile's reads from the next tile's stores
@@ -2624,14 +2715,21 @@ __global__ __launch_bounds__(kTile, 2) void k_schur(SchurParams p_in) {
     PBA_TICK(6);
   }
   if (p.dbg) tph[7] = __builtin_amdgcn_s_memrealtime() - t_rt0;     // tile loop, 100 MHz
-  if (p.dbg && tid == 0) for (int k = 0; k < 8; ++k) p.dbg[blockIdx.x * 8 + k] = tph[k];
+  if (p.dbg && tid == 0) for (int k = 0; k < 8; ++k) p.dbg[part * 8 + k] = tph[k];
 #undef PBA_TICK
 
   // ---- combine the point groups (fixed order), then per-block partials -----------------------------------
   // Partial layout (r4): entry e of workgroup b at ((e >> 4) * gridDim.x + b) * 16 + (e & 15) -- 16-entry (128-byte) chunks, all
   // workgroups' copies of one chunk contiguous: the reduction workgroup of a chunk then reads ONE sequential region of
   // gridDim.x x 128 bytes (it used to gather 128-byte pieces 9 - 37 KB apart: 2.4 TB/s), a store here still fills whole lines.
-  auto out_at = [&](int e) -> double* { return p.partial + ((size_t)(e >> 4) * gridDim.x + blockIdx.x) * 16 + (e & 15); };
+  auto out_at = [&](int e) -> double* { return p.partial + ((size_t)(e >> 4) * n_parts + part) * 16 + (e & 15); };
+  // resident solve: the partials are consumed by other workgroups of the SAME launch -- every store is a write-through one; the idle
+  // half of the last workgroup stores nothing
+  auto put = [&](double* dst, double v, bool sc1) {
+    if (RES) { if (has_tile) store_agent(dst, v); }
+    else if (sc1) store_agent(dst, v);
+    else *dst = v;
+  };
   if (owner && grp > 0) {
     double* dst = s_obs + ((grp - 1) * p.n_pairs + pair) * 36;
 #pragma unroll
@@ -2655,12 +2753,12 @@ __global__ __launch_bounds__(kTile, 2) void k_schur(SchurParams p_in) {
     if (e < kCamVals * nf) {
       s_cam[e] = acc_cam[u];
       const int a = e / kCamVals, v = e - a * kCamVals;
-      if (v >= 27) *out_at(36 * p.n_pairs + n + 6 * a + (v - 27)) = acc_cam[u];            // g_c
-      else if (v >= 21) *out_at(36 * p.n_pairs + 6 * a + (v - 21)) = acc_cam[u];          // rhs
+      if (v >= 27) put(out_at(36 * p.n_pairs + n + 6 * a + (v - 27)), acc_cam[u], false);            // g_c
+      else if (v >= 21) put(out_at(36 * p.n_pairs + 6 * a + (v - 21)), acc_cam[u], false);          // rhs
       else {
         // packed upper triangle: entry v is a diagonal (i, i) iff v == sym6(i, i) = 6 i - i (i - 1) / 2
 #pragma unroll
-        for (int i = 0; i < 6; ++i) if (v == 6 * i - (i * (i - 1)) / 2) *out_at(36 * p.n_pairs + 2 * n + 6 * a + i) = acc_cam[u];   // diag(U)
+        for (int i = 0; i < 6; ++i) if (v == 6 * i - (i * (i - 1)) / 2) put(out_at(36 * p.n_pairs + 2 * n + 6 * a + i), acc_cam[u], false);   // diag(U)
       }
     }
   }
@@ -2675,8 +2773,7 @@ __global__ __launch_bounds__(kTile, 2) void k_schur(SchurParams p_in) {
     }
 #pragma unroll
     for (int k = 0; k < 36; ++k) {
-      double* dst = out_at(PBA_PARTIAL_T ? k * p.n_pairs + pair : pair * 36 + k);
-      if (PBA_PARTIAL_SC1) store_agent(dst, acc[k]); else *dst = acc[k];
+      put(out_at(PBA_PARTIAL_T ? k * p.n_pairs + pair : pair * 36 + k), acc[k], PBA_PARTIAL_SC1 != 0);
     }
   }
   lds_barrier();
@@ -2688,12 +2785,28 @@ __global__ __launch_bounds__(kTile, 2) void k_schur(SchurParams p_in) {
     if (tid == 0) {
       double a = 0.0, m = 0.0, f = 0.0;
       for (int w = 0; w < kTile / 64; ++w) { a += s_red[3 * w]; m = fmax(m, s_red[3 * w + 1]); f = fmax(f, s_red[3 * w + 2]); }
-      *out_at(36 * p.n_pairs + 3 * n + 0) = m;
-      *out_at(36 * p.n_pairs + 3 * n + 1) = a;
-      *out_at(36 * p.n_pairs + 3 * n + 2) = f;
-      if (p.stamp && blockIdx.x < kStampSchurBlocks) p.stamp[kStampSchur0 + blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+      put(out_at(36 * p.n_pairs + 3 * n + 0), m, false);
+      put(out_at(36 * p.n_pairs + 3 * n + 1), a, false);
+      put(out_at(36 * p.n_pairs + 3 * n + 2), f, false);
+      if (!RES && p.stamp && part < kStampSchurBlocks) p.stamp[kStampSchur0 + part] = __builtin_amdgcn_s_memrealtime();
     }
   }
+}
+
+__global__ __launch_bounds__(kTile, 2) void k_schur(SchurParams p_in) {
+  SchurParams p = p_in;
+  if (!PBA_PHASE_TIMING) p.dbg = nullptr;
+  if (p.pub_host_seq && blockIdx.x == 0)
+    lm_publish(p.lm, p.pub_state, p.pub_scal, p.pub_host_scal, p.pub_host_seq, p.pub_seq, threadIdx.x, kTile);
+  if (p.lm) {
+    if (p.lm->done && !p.final_pass) return;
+    if (p.final_pass && !lm_final_pass_needed(p.lm)) return;
+    if (p.lm->cur != p.enq_cur) { p.xyz = p.xyz_alt; p.geom = p.geom_alt; p.rec = p.rec_alt; }
+    p.radius = p.lm->radius;
+    p.inv_radius = 1.0 / p.radius;
+  }
+  __shared__ __attribute__((aligned(16))) char smem[kSchurSmemBytes];
+  schur_body<const void>(p, smem, (int)threadIdx.x, (int)blockIdx.x, (int)gridDim.x, nullptr, nullptr, true);
 }
 
 }  // namespace pba
