@@ -305,6 +305,13 @@ int pba_set_profiling(pba_engine* e, int32_t mode);
 int pba_get_counters(pba_engine* e, pba_counters* c);
 int pba_reset_counters(pba_engine* e);
 
+/* Which driver ran the LAST pba_solve: "resident" (the whole solve as ONE cooperative launch, every workgroup keeping its tiles'
+ * state in registers across the iterations: windows that fit one resident round of workgroups -- <= 2 x 128 observations per CU --
+ * on a single rank, patch radius <= 2, <= 8 free cameras; PBA_RESIDENT=0 switches it off), "pipelined" (three kernels per
+ * iteration enqueued ahead of the device-side decisions), "host-stepped" (PBA_ASYNC=0, event profiling), "none".  The three take
+ * the same decisions on the same numbers; "resident" and "pipelined" are bit-identical. */
+const char* pba_solve_driver(const pba_engine* e);
+
 #ifdef __cplusplus
 }
 #endif

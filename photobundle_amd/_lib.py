@@ -72,7 +72,7 @@ SYMBOLS = [
     "pba_set_frame_u8", "pba_set_frame_channels_f32", "pba_get_frame_planes", "pba_get_frame_channel", "pba_sample_frame", "pba_set_frame_descriptor_u8", "pba_get_frame_channels_f32", "pba_set_frame_pyr_down", "pba_set_problem", "pba_set_cameras", "pba_set_inverse_depth", "pba_get_points_world", "pba_get_state",
     "pba_linearize", "pba_step", "pba_accept", "pba_get_reduced_system", "pba_get_obs_records", "pba_solve",
     "pba_comm_unique_id", "pba_comm_init_rccl", "pba_comm_init_callback", "pba_comm_enable_peer_exchange", "pba_comm_transport", "pba_comm_rank_count",
-    "pba_set_profiling", "pba_get_counters", "pba_reset_counters",
+    "pba_set_profiling", "pba_get_counters", "pba_reset_counters", "pba_solve_driver",
     "pba_frontend_visibility", "pba_frontend_candidates", "pba_frontend_get_candidates", "pba_frontend_descriptors", "pba_frontend_zncc_probe",
 ]
 
@@ -128,6 +128,8 @@ def lib():
     L.pba_comm_enable_peer_exchange.argtypes = [C.c_void_p]
     L.pba_comm_transport.argtypes = [C.c_void_p]
     L.pba_comm_transport.restype = C.c_char_p
+    L.pba_solve_driver.argtypes = [C.c_void_p]
+    L.pba_solve_driver.restype = C.c_char_p
     L.pba_comm_rank_count.argtypes = [C.c_void_p]
     L.pba_get_counters.argtypes = [C.c_void_p, C.POINTER(Counters)]
     L.pba_reset_counters.argtypes = [C.c_void_p]

@@ -8,6 +8,7 @@
 #include "pba_internal.h"
 #include "pba_kernels.h"
 #include "pba_frontend.h"
+#include "pba_resident.h"
 
 #include <algorithm>
 #include <chrono>
@@ -120,6 +121,15 @@ struct pba_engine {
   static constexpr int kMaxLog = 1024;
   int async_cur = 0;                // parity assumed at enqueue time
   bool use_async = true;            // PBA_ASYNC=0 disables
+  // resident solve (pba_resident.h): one cooperative launch per pba_solve when the window fits one resident round of workgroups
+  bool use_resident = true;         // PBA_RESIDENT=0 disables
+  unsigned* d_res_sync = nullptr;   // flag block (kResSyncBytes), zeroed once: epochs grow from launch to launch
+  unsigned res_epoch = 1;
+  int res_groups_max[2][2] = {{-1, -1}, {-1, -1}};   // [radius - 1][unit weights]: co-resident workgroups of k_resident (-1: not asked yet, 0: none)
+  int res_groups_n[2][2] = {{-1, -1}, {-1, -1}};     // ... the reduced-system size that answer was given for
+  int n_cus = 0, coop_launch = 0;
+  int64_t res_launches = 0;
+  int last_driver = 0;              // 0 none, 1 resident, 2 pipelined, 3 host-stepped (pba_solve_driver)
   double wait_timeout_s = 120.0;    // PBA_WAIT_TIMEOUT_S: watchdog of the publication waits
   double tick_hz = 1e8;             // rate of s_memrealtime (hipDeviceAttributeWallClockRate; 100 MHz on gfx950): device-side time-outs
   bool poisoned = false;            // a publication wait timed out: the stream still holds the stalled work, every later
@@ -546,6 +556,11 @@ int pba_create(const pba_config* cfg, pba_engine** out) {
   if (const char* sv = getenv("PBA_SPECULATE")) e->speculate = atoi(sv) != 0;
   if (const char* sv = getenv("PBA_FUSE")) e->fuse = atoi(sv) != 0;
   if (const char* sv = getenv("PBA_ASYNC")) e->use_async = atoi(sv) != 0;
+  if (const char* sv = getenv("PBA_RESIDENT")) e->use_resident = atoi(sv) != 0;
+  (void)hipDeviceGetAttribute(&e->n_cus, hipDeviceAttributeMultiprocessorCount, cfg->device);
+  (void)hipDeviceGetAttribute(&e->coop_launch, hipDeviceAttributeCooperativeLaunch, cfg->device);
+  if ((rc = dev_alloc(e, &e->d_res_sync, kResSyncBytes / sizeof(unsigned)))) return bail(rc);
+  if (hipMemsetAsync(e->d_res_sync, 0, kResSyncBytes, e->stream) != hipSuccess) return bail(PBA_ERR_HIP);
   if (const char* sv = getenv("PBA_WAIT_TIMEOUT_S")) { const double v = atof(sv); if (v > 0.0) e->wait_timeout_s = v; }
   { int khz = 0; if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, cfg->device) == hipSuccess && khz > 0) e->tick_hz = 1e3 * khz; }
   if ((rc = dev_alloc(e, &e->d_lm, (size_t)1))) return bail(rc);
@@ -615,6 +630,7 @@ void pba_destroy(pba_engine* e) {
   if (e->h_log) (void)hipHostFree(e->h_log);
   dev_free(&e->d_lm);
   dev_free(&e->d_log);
+  dev_free(&e->d_res_sync);
   for (int k = 0; k < 2 * pba_engine::kEvPairs; ++k) if (e->ev[k]) (void)hipEventDestroy(e->ev[k]);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
@@ -1227,6 +1243,7 @@ int pba_step(pba_engine* e, double radius, int32_t init_scale, const pba_solver_
 int pba_internal_step(pba_engine* e, double radius, int32_t init_scale, const pba_solver_options* o, pba_step_info* out,
                       int grad_only) {
   if (!e || !o || !out || !(radius > 0.0)) return PBA_ERR_INVALID;
+  e->last_driver = 3;
   if (!e->have_lin) return fail(e, PBA_ERR_STATE, "call order violated: pba_step before pba_linearize");
   PBA_NOT_POISONED(e);
   HIP_TRY(e, hipSetDevice(e->cfg.device));
@@ -1503,6 +1520,11 @@ const char* pba_comm_transport(const pba_engine* e) {
   return e->comm.peer ? "callback+peer" : "callback";
 }
 
+const char* pba_solve_driver(const pba_engine* e) {
+  static const char* names[] = {"none", "resident", "pipelined", "host-stepped"};
+  return names[(e && e->last_driver >= 0 && e->last_driver <= 3) ? e->last_driver : 0];
+}
+
 int pba_get_counters(pba_engine* e, pba_counters* c) {
   if (!e || !c) return PBA_ERR_INVALID;
   if (e->stamps && e->d_stamp) {
@@ -1563,6 +1585,20 @@ int pba_set_profiling(pba_engine* e, int32_t mode) {
 
 }  // extern "C"
 
+// resident solve (pba_resident.h): kernel and LDS pool of the engine's patch radius / weights
+namespace {
+template <int R, bool UNITW>
+const void* resident_kernel() { return reinterpret_cast<const void*>(&k_resident<R, UNITW>); }
+const void* resident_kernel_for(const pba_engine* e) {
+  if (e->cfg.radius == 1) return e->unit_weights ? resident_kernel<1, true>() : resident_kernel<1, false>();
+  return e->unit_weights ? resident_kernel<2, true>() : resident_kernel<2, false>();
+}
+size_t resident_pool_for(const pba_engine* e) {
+  const int n = 6 * e->n_free;
+  return e->cfg.radius == 1 ? resident_pool_bytes<1>(n) : resident_pool_bytes<2>(n);
+}
+}  // namespace
+
 // engine internals needed by the LM driver (pba_lm.cpp)
 extern "C" {
 int pba_internal_world(const pba_engine* e) { return e->comm.world; }
@@ -1604,6 +1640,7 @@ int pba_internal_async_begin(pba_engine* e, const pba_solver_options* o) {
     HIP_TRY(e, hipGetLastError());
   }
   e->async_cur = e->cur;
+  e->last_driver = 2;
   return PBA_OK;
 }
 
@@ -1757,6 +1794,84 @@ int pba_internal_async_wait(pba_engine* e, unsigned long long seq) {
   }
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
   return comm_failed(e);      // (normal with the pipelined driver: the awaited number was already visible on entry)
+}
+
+// ---- resident solve ------------------------------------------------------------------------------------------------
+
+// The window fits ONE resident round of 256-thread workgroups (two whole-point tiles each) and the solve is one the resident kernel
+// covers: single rank, single channel, reference-exact sampler, free world points, patch radius <= 2, <= 8 free cameras.
+int pba_internal_resident_capable(pba_engine* e, const pba_solver_options* o) {
+  if (!e->use_resident || !e->use_async || !e->coop_launch || e->comm.multi() || e->channels != 1 || !fused_capable(e) || e->inverse_depth) return 0;
+  if (e->cfg.radius > 2 || e->n_free < 1 || e->n_free > kSolveNarrowFree || (e->cfg.flags & 1) || e->solve_kind != 0 || e->profile || PBA_PHASE_TIMING) return 0;
+  if (o->max_num_iterations >= pba_engine::kMaxLog - 2) return 0;
+  const int groups = (e->n_tiles + 1) / 2;
+  if (groups > kResMaxGroups || (e->part_stride + kReduceEntries - 1) / kReduceEntries + 1 > kResMaxReduce) return 0;
+  int& gmax = e->res_groups_max[e->cfg.radius - 1][e->unit_weights ? 1 : 0];
+  int& gn = e->res_groups_n[e->cfg.radius - 1][e->unit_weights ? 1 : 0];
+  if (gmax < 0 || gn != e->n_free) {
+    gmax = 0; gn = e->n_free;
+    if (hipSetDevice(e->cfg.device) != hipSuccess) return 0;
+    const void* fn = resident_kernel_for(e);
+    const size_t pool = resident_pool_for(e);
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pool);
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kResThreads, pool) == hipSuccess && per_cu > 0) gmax = per_cu * e->n_cus;
+    (void)hipGetLastError();
+  }
+  return groups <= gmax ? 1 : 0;
+}
+
+int pba_internal_resident_launch(pba_engine* e, const pba_solver_options* o, unsigned long long* seq_out) {
+  { const int rc0 = check_ready(e, "pba_solve"); if (rc0) return rc0; }
+  PBA_NOT_POISONED(e);
+  HIP_TRY(e, hipSetDevice(e->cfg.device));
+  LmState st;
+  std::memset(&st, 0, sizeof(st));
+  st.radius = o->initial_trust_region_radius; st.decrease_factor = 2.0;
+  st.cur = e->cur; st.pending_grad = -1; st.first = 1;
+  st.function_tolerance = o->function_tolerance; st.gradient_tolerance = o->gradient_tolerance;
+  st.parameter_tolerance = o->parameter_tolerance; st.max_radius = o->max_trust_region_radius;
+  st.min_radius = o->min_trust_region_radius; st.min_relative_decrease = o->min_relative_decrease;
+  st.max_num_iterations = o->max_num_iterations; st.max_invalid = o->max_num_consecutive_invalid_steps;
+  *e->h_lm = st;
+  __atomic_thread_fence(__ATOMIC_RELEASE);
+  ResidentParams P{};
+  P.frames = e->d_frames; P.desc = e->d_desc; P.w2 = e->d_w2; P.tile_info = e->d_tile_info; P.lane_rec = e->d_lane_rec;
+  for (int k = 0; k < 2; ++k) {
+    P.xyz[k] = e->d_xyz[k]; P.rec[k] = e->d_rec[k]; P.cams[k] = e->d_cams[k]; P.geom[k] = e->d_geom[k];
+    P.block_cost[k] = e->d_block_cost[k]; P.block_fail[k] = e->d_block_fail[k];
+  }
+  P.sp = e->d_sp; P.ptrec = e->d_ptrec; P.delta_c = e->d_delta_c; P.sc = e->d_sc; P.packed = e->d_packed; P.partial = e->d_partial;
+  P.scal = e->d_scal; P.block_bs = e->d_bs_out; P.tab = e->d_solve_tab; P.rec_stride = e->rec_stride;
+  P.n_tiles = e->n_tiles; P.n_obs = e->n_obs; P.n_frames = e->n_frames; P.n_free = e->n_free; P.n_pairs = e->n_pairs;
+  P.part_stride = e->part_stride; P.fixed_slot = e->fixed_slot; P.rows = e->cfg.rows; P.cols = e->cfg.cols; P.jacobi = o->jacobi_scaling;
+  P.cur0 = e->cur; P.max_num_iterations = o->max_num_iterations;
+  P.fx = e->cfg.fx; P.fy = e->cfg.fy; P.cx = e->cfg.cx; P.cy = e->cfg.cy; P.huber = e->cfg.huber;
+  P.min_diag = o->min_lm_diagonal; P.max_diag = o->max_lm_diagonal; P.radius0 = o->initial_trust_region_radius;
+  P.sync = e->d_res_sync; P.epoch0 = e->res_epoch;
+  e->res_epoch += (unsigned)std::max(0, o->max_num_iterations) + 8u;
+  // every device-side wait is bounded (a lost flag must not hang the GPU): well below the host watchdog and the compute-queue's own
+  P.timeout_ticks = (unsigned long long)(std::min(2.0, 0.25 * e->wait_timeout_s) * e->tick_hz);
+  P.lm_init = e->h_lm_dev; P.host_state = e->h_lm_dev; P.log = e->d_log; P.host_log = e->h_log_dev; P.max_log = (int)pba_engine::kMaxLog;
+  P.host_scal = e->h_scal_dev; P.host_seq = reinterpret_cast<unsigned long long*>(e->h_scal_dev + kNumScal);
+  const unsigned long long seq = ++e->seq;
+  P.seq = seq;
+  P.stamp = nullptr;
+  if (const char* sv = getenv("PBA_RES_STOP")) P.debug_stop = atoi(sv);
+  if (e->stamps && e->d_stamp) {
+    // (the stamp block of pba_set_profiling(e, 2) is large enough for kStampMaxIters + 1 records of kStampRecord words)
+    static_assert((int)kResStampRecord <= (int)kStampRecord, "resident stamp records fit the block");
+    if (o->max_num_iterations + 2 <= kStampMaxIters) P.stamp = e->d_stamp;
+  }
+  const int groups = (e->n_tiles + 1) / 2;
+  void* args[] = {&P};
+  HIP_TRY(e, hipLaunchCooperativeKernel(resident_kernel_for(e), dim3(groups), dim3(kResThreads), args, (unsigned)resident_pool_for(e), e->stream));
+  e->res_launches++;
+  e->last_driver = 1;
+  e->stamp_iter = o->max_num_iterations;
+  e->cost_blocks[0] = e->cost_blocks[1] = groups;
+  *seq_out = seq;
+  return PBA_OK;
 }
 
 const void* pba_internal_async_state(const pba_engine* e) { return e->h_lm; }

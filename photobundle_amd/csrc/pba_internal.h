@@ -25,5 +25,8 @@ int pba_internal_async_wait(pba_engine* e, unsigned long long seq);
 const void* pba_internal_async_state(const pba_engine* e);
 const pba_iteration_summary* pba_internal_async_log(const pba_engine* e);
 int pba_internal_async_end(pba_engine* e);
+// resident solve (pba_resident.h): the whole pba_solve as ONE cooperative launch
+int pba_internal_resident_capable(pba_engine* e, const pba_solver_options* o);
+int pba_internal_resident_launch(pba_engine* e, const pba_solver_options* o, unsigned long long* seq_out);
 int pba_internal_final_flushes(const pba_engine* e);   /* 1: the kind-2 enqueue also flushes (no kind 3 behind it) */
 }

@@ -844,10 +844,10 @@ __device__ __forceinline__ bool fused_resolve_parity(SampleParams& p) {
 // whole-point tiles of <= 128 observations, two per 256-thread workgroup
 struct FusedIdx { int4 ti; int pt, slot, l0, cnt; };
 template <int NT>
-__device__ __forceinline__ FusedIdx fused_prefetch_indices(const SampleParams& p, int bid) {
+__device__ __forceinline__ FusedIdx fused_prefetch_indices(const SampleParams& p, int bid, const int tix) {
   FusedIdx f{make_int4(0, 0, 0, 0), 0, 0, 0, 0};
-  const int tile = bid * (NT / 128) + (int)(threadIdx.x >> 7);
-  const int lt = threadIdx.x & 127;
+  const int tile = bid * (NT / 128) + (int)(tix >> 7);
+  const int lt = tix & 127;
   if (tile < p.n_tiles) {
     f.ti = p.tile_info[tile];
     const int2 r = p.lane_rec[(size_t)tile * 128 + lt];      // (lanes beyond the tile's observations hold zeros)
@@ -858,7 +858,7 @@ __device__ __forceinline__ FusedIdx fused_prefetch_indices(const SampleParams& p
 }
 
 template <int NT, bool AG = false>
-__device__ __forceinline__ void fused_stage_step_table(const SampleParams& p, double* s_bk) {
+__device__ __forceinline__ void fused_stage_step_table(const SampleParams& p, double* s_bk, const int tix) {
   if (!p.skip_backsub) {
     // Branch-free: every entry issues the same seven loads (three table words, the rotation part of the camera step, one translation
     // component, the free index) and selects afterwards.  The five-way branch on the entry kind this replaces was divergent inside
@@ -873,7 +873,7 @@ __device__ __forceinline__ void fused_stage_step_table(const SampleParams& p, do
     const int n_e = kBk * p.n_frames;
 #pragma unroll
     for (int u = 0; u < IT; ++u) {
-      const int e_raw = threadIdx.x + u * NT;
+      const int e_raw = tix + u * NT;
       const int e = e_raw < n_e ? e_raw : 0;        // (idle lanes recompute entry 0: no exec-mask branch around the loads)
       const int a = e / kBk, k = e - a * kBk;
       const double* g = G + (size_t)a * GW;
@@ -902,10 +902,10 @@ __device__ __forceinline__ void fused_stage_step_table(const SampleParams& p, do
 template <int NT, class RL = const void>
 __device__ __forceinline__ void fused_backsub(const SampleParams& p, const double* rays, const FusedIdx& fi, const double* s_bk,
                                               double* s_bs, int& pt, int& slot, int& obs, bool& active, double (&X)[3],
-                                              double& bs_mcc, double& bs_st2, double& bs_x2, RL* rl = nullptr) {
+                                              double& bs_mcc, double& bs_st2, double& bs_x2, const int tix, RL* rl = nullptr) {
   constexpr bool RES = !std::is_void<RL>::value;
   // delta_p = -P (g_p + sum_l W_l^T delta_c[slot_l]),  W_l^T delta_c = Ap^T M' (Ac delta_c)
-  const int half = threadIdx.x >> 7, lt = threadIdx.x & 127;
+  const int half = tix >> 7, lt = tix & 127;
   const int4 ti = fi.ti;
   active = lt < ti.y;
   obs = ti.x + lt;
@@ -965,7 +965,7 @@ __device__ __forceinline__ void fused_backsub(const SampleParams& p, const doubl
       if (rays) { c3[0] = qd[0] * c3[0] + qd[1] * c3[1] + qd[2] * c3[2]; c3[1] = 0.0; c3[2] = 0.0; }   // Ap -> Ap q (point_jacobian)
     }
   }
-  s_bs[threadIdx.x * 3 + 0] = c3[0]; s_bs[threadIdx.x * 3 + 1] = c3[1]; s_bs[threadIdx.x * 3 + 2] = c3[2];
+  s_bs[tix * 3 + 0] = c3[0]; s_bs[tix * 3 + 1] = c3[1]; s_bs[tix * 3 + 2] = c3[2];
   lds_barrier();
   if (active && !p.skip_backsub) {
     double acc[3] = {0.0, 0.0, 0.0};
@@ -1025,7 +1025,7 @@ __device__ __forceinline__ void fused_wave_step_sums(double& bs_mcc, double& bs_
 // bs_*: already summed over the wave (fused_wave_step_sums)
 template <int WAVES>
 __device__ __forceinline__ void fused_block_partials(const SampleParams& p, int bid, int lane, int wave, double cost_obs,
-                                                     double bs_mcc, double bs_st2, double bs_x2, double* s_red, const int32_t& s_fail) {
+                                                     double bs_mcc, double bs_st2, double bs_x2, double* s_red, const int32_t& s_fail, const int tix) {
   double q4[4] = {wave_sum(cost_obs), bs_mcc, bs_st2, bs_x2};
   if (lane == 0) {
 #pragma unroll
@@ -1040,24 +1040,61 @@ __device__ __forceinline__ void fused_block_partials(const SampleParams& p, int 
     for (int w = 0; w < WAVES; ++w) a += s_red[q * WAVES + w];
     red_out[q] = a;
   }
-  if (threadIdx.x == 0) {
+  if (tix == 0) {
     // consumed by the last workgroup of THIS launch: write-through stores; a non-finite block poisons its cost
     store_agent(p.block_cost + bid, s_fail ? __longlong_as_double(0x7ff8000000000000ll) : red_out[0]);
     store_agent(p.block_bs + 3 * bid, red_out[1]);
     store_agent(p.block_bs + 3 * bid + 1, red_out[2]);
     store_agent(p.block_bs + 3 * bid + 2, red_out[3]);
-    p.block_fail[bid] = s_fail;
+    __hip_atomic_store(p.block_fail + bid, (int32_t)s_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
 // Step finalisation by the last workgroup to arrive (agent-scope release / acquire around the ticket): fixed-order sums
 // of all block partials, the trust-region decision (single rank), the exchange buffer (multi-rank), publication.
 // s_f: [NTH] ints, s_r4: [4][NTH] doubles of LDS scratch that is free by now.
+// Fixed-order sums of the per-workgroup partials of a fused sampling pass (by ONE workgroup of WAVES waves): s_r4[q * WAVES] = model cost
+// change | step^2 | x^2 (point parts) | candidate cost, s_f[0] = non-finite flag.  Shared by fused_finalize and the deciding workgroup of
+// the resident solve (pba_resident.h), so that both paths add the same numbers in the same order.
 template <int WAVES>
-__device__ __forceinline__ void fused_finalize(const SampleParams& p, int lane, int wave, int* s_f, double* s_r4, unsigned long long t_begin) {
+__device__ __forceinline__ void fused_sum_partials(const double* block_bs, const double* block_cost, const int n_blocks, const int lane, const int wave,
+                                                   int* s_f, double* s_r4, unsigned long long* t_loaded, const int tix) {
+  constexpr int NTH = WAVES * 64;
+  double a0 = 0, a1 = 0, a2 = 0, a3 = 0; int f = 0;
+  // 8 blocks' partials in flight per thread (every load misses this XCD's L2), summed in block order
+  for (int b0 = tix; b0 < n_blocks; b0 += 8 * NTH) {
+    double v0[8], v1[8], v2[8], v3[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int b = b0 + k * NTH;
+      const bool ok = b < n_blocks;
+      v0[k] = ok ? load_agent(block_bs + 3 * b) : 0.0;
+      v1[k] = ok ? load_agent(block_bs + 3 * b + 1) : 0.0;
+      v2[k] = ok ? load_agent(block_bs + 3 * b + 2) : 0.0;
+      v3[k] = ok ? load_agent(block_cost + b) : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { a0 += v0[k]; a1 += v1[k]; a2 += v2[k]; a3 += v3[k]; f |= (v3[k] != v3[k]) ? 1 : 0; }
+  }
+  if (t_loaded) *t_loaded = __builtin_amdgcn_s_memrealtime();
+  a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3);
+  f = __any(f) ? 1 : 0;
+  if (lane == 0) { s_r4[wave] = a0; s_r4[WAVES + wave] = a1; s_r4[2 * WAVES + wave] = a2; s_r4[3 * WAVES + wave] = a3; s_f[wave] = f; }
+  __syncthreads();
+  if (tix == 0) {
+    for (int w = 1; w < WAVES; ++w) {
+      s_r4[0] += s_r4[w]; s_r4[WAVES] += s_r4[WAVES + w]; s_r4[2 * WAVES] += s_r4[2 * WAVES + w]; s_r4[3 * WAVES] += s_r4[3 * WAVES + w];
+      s_f[0] |= s_f[w];
+    }
+  }
+  __syncthreads();
+}
+
+template <int WAVES>
+__device__ __forceinline__ void fused_finalize(const SampleParams& p, int lane, int wave, int* s_f, double* s_r4, unsigned long long t_begin, const int tix) {
   constexpr int NTH = WAVES * 64;
   __shared__ int s_last;
-  if (threadIdx.x == 0) {
+  if (tix == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the write-through partials have left this CU
     const unsigned t = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_last = (t == gridDim.x - 1) ? 1 : 0;
@@ -1065,36 +1102,10 @@ __device__ __forceinline__ void fused_finalize(const SampleParams& p, int lane, 
   __syncthreads();
   if (s_last) {
     const unsigned long long t_fin0 = p.dbg ? __builtin_amdgcn_s_memrealtime() : 0;
-    double a0 = 0, a1 = 0, a2 = 0, a3 = 0; int f = 0;
-    // 8 blocks' partials in flight per thread (every load misses this XCD's L2), summed in block order
-    for (int b0 = threadIdx.x; b0 < (int)gridDim.x; b0 += 8 * NTH) {
-      double v0[8], v1[8], v2[8], v3[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int b = b0 + k * NTH;
-        const bool ok = b < (int)gridDim.x;
-        v0[k] = ok ? load_agent(p.block_bs + 3 * b) : 0.0;
-        v1[k] = ok ? load_agent(p.block_bs + 3 * b + 1) : 0.0;
-        v2[k] = ok ? load_agent(p.block_bs + 3 * b + 2) : 0.0;
-        v3[k] = ok ? load_agent(p.block_cost + b) : 0.0;
-      }
-#pragma unroll
-      for (int k = 0; k < 8; ++k) { a0 += v0[k]; a1 += v1[k]; a2 += v2[k]; a3 += v3[k]; f |= (v3[k] != v3[k]) ? 1 : 0; }
-    }
-    const unsigned long long t_fin1 = p.dbg ? __builtin_amdgcn_s_memrealtime() : 0;
-    a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3);
-    f = __any(f) ? 1 : 0;
-    if (lane == 0) { s_r4[wave] = a0; s_r4[WAVES + wave] = a1; s_r4[2 * WAVES + wave] = a2; s_r4[3 * WAVES + wave] = a3; s_f[wave] = f; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      for (int w = 1; w < WAVES; ++w) {
-        s_r4[0] += s_r4[w]; s_r4[WAVES] += s_r4[WAVES + w]; s_r4[2 * WAVES] += s_r4[2 * WAVES + w]; s_r4[3 * WAVES] += s_r4[3 * WAVES + w];
-        s_f[0] |= s_f[w];
-      }
-    }
-    __syncthreads();
+    unsigned long long t_fin1 = 0;
+    fused_sum_partials<WAVES>(p.block_bs, p.block_cost, (int)gridDim.x, lane, wave, s_f, s_r4, p.dbg ? &t_fin1 : nullptr, tix);
     unsigned long long t_fin2 = 0, t_fin3 = 0;
-    if (threadIdx.x == 0) {
+    if (tix == 0) {
       t_fin2 = p.dbg ? __builtin_amdgcn_s_memrealtime() : 0;
       p.scal[kMccPts] = s_r4[0]; p.scal[kStep2Pts] = s_r4[WAVES]; p.scal[kX2Pts] = s_r4[2 * WAVES];
       p.scal[kCandCost] = s_r4[3 * WAVES]; p.scal[kEvalFailCand] = (double)s_f[0];
@@ -1105,19 +1116,19 @@ __device__ __forceinline__ void fused_finalize(const SampleParams& p, int lane, 
     }
     if (p.xchg) {
       __syncthreads();
-      xchg_pack(p.scal, p.xchg, p.xchg_rank, p.xchg_world, threadIdx.x, NTH, p.xchg_sys != 0);
+      xchg_pack(p.scal, p.xchg, p.xchg_rank, p.xchg_world, tix, NTH, p.xchg_sys != 0);
       if (p.xchg_flag) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every thread's system-scope stores have left
         __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_store(p.xchg_flag, p.xchg_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (tix == 0) __hip_atomic_store(p.xchg_flag, p.xchg_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
       }
     }
     if (p.host_scal) {
       __syncthreads();
-      lm_publish(p.lm, (p.lm && p.decide) ? p.host_state : nullptr, p.scal, p.host_scal, p.host_seq, p.seq, threadIdx.x, NTH);
+      lm_publish(p.lm, (p.lm && p.decide) ? p.host_state : nullptr, p.scal, p.host_scal, p.host_seq, p.seq, tix, NTH);
     }
-    if (p.stamp && threadIdx.x == 0) p.stamp[kStampEndSample] = __builtin_amdgcn_s_memrealtime();
-    if (p.dbg && threadIdx.x == 0) {
+    if (p.stamp && tix == 0) p.stamp[kStampEndSample] = __builtin_amdgcn_s_memrealtime();
+    if (p.dbg && tix == 0) {
       p.dbg[(size_t)gridDim.x * 8] = __builtin_amdgcn_s_memrealtime() - t_fin0;
       p.dbg[(size_t)gridDim.x * 8 + 1] = t_fin0 - t_begin;
       p.dbg[(size_t)gridDim.x * 8 + 2] = t_fin1 - t_fin0;      // partial loads
@@ -1193,7 +1204,9 @@ struct ResLane {
 //        its records go back there; tables produced by other workgroups of the SAME launch are read with agent-scope loads; the
 //        step finalisation (ticket, fixed-order reduction, decision) is the caller's.
 template <int R, bool JAC, int WAVES, bool FUSED, bool UNITW, bool FAST, bool RES>
-__device__ __forceinline__ void sample_wg(SampleParams& p, SampleSmem<R, WAVES>& sm, ResLane<R>& rl, const int bid, const int n_blocks) {
+// tix = threadIdx.x (the resident solve passes it through an opaque copy per trip of its loop: with the plain builtin the compiler
+// hoists every per-lane address and mask of every phase out of the loop -- hundreds of registers live across all of it)
+__device__ __forceinline__ void sample_wg(SampleParams& p, SampleSmem<R, WAVES>& sm, ResLane<R>& rl, const int bid, const int n_blocks, const int tix, CamGeom* geom_lds = nullptr) {
   static_assert(!FUSED || (WAVES * 64) % 128 == 0, "fused tiles are 128 observations");
   static_assert(!FAST || UNITW, "the reduced-precision walk assumes unit patch weights");
   static_assert(!RES || (FUSED && !FAST), "the resident phase is the fused exact kernel");
@@ -1218,15 +1231,16 @@ __device__ __forceinline__ void sample_wg(SampleParams& p, SampleSmem<R, WAVES>&
   auto& s_red = sm.red;
   int32_t& s_fail = sm.fail;
 
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  int obs = bid * (WAVES * 64) + threadIdx.x;
+  const int lane = tix & 63;
+  const int wave = tix >> 6;
+  int obs = bid * (WAVES * 64) + tix;
   bool active = obs < p.n_obs;
-  if (threadIdx.x == 0) s_fail = 0;
+  if (tix == 0) s_fail = 0;
 
   // camera geometry tables -> LDS (the texel region is free until the staging phase)
-  CamGeom* s_geom = reinterpret_cast<CamGeom*>(s_raw + sizeof(double) * 3 * WAVES * 64);
-  double* s_bk = reinterpret_cast<double*>(s_geom + kMaxFrames);
+  // (resident solve: the table of the point being sampled goes to the workgroup's PERSISTENT copy, which the next elimination reads)
+  CamGeom* s_geom = RES ? geom_lds : reinterpret_cast<CamGeom*>(s_raw + sizeof(double) * 3 * WAVES * 64);
+  double* s_bk = reinterpret_cast<double*>(reinterpret_cast<CamGeom*>(s_raw + sizeof(double) * 3 * WAVES * 64) + kMaxFrames);
   unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tl = p.dbg ? __builtin_amdgcn_s_memtime() : 0;
   const unsigned long long t_begin = p.dbg ? __builtin_amdgcn_s_memrealtime() : 0;   // 100 MHz, device-wide
@@ -1235,9 +1249,9 @@ __device__ __forceinline__ void sample_wg(SampleParams& p, SampleSmem<R, WAVES>&
   // that their two dependent round trips overlap the table loads instead of following the barrier
   FusedIdx fi{make_int4(0, 0, 0, 0), 0, 0, 0, 0};
   if constexpr (RES) { fi.ti = rl.ti; fi.pt = rl.pt; fi.slot = rl.slot; fi.l0 = rl.l0; fi.cnt = rl.cnt; }
-  else if (FUSED) fi = fused_prefetch_indices<WAVES * 64>(p, bid);
-  stage_geom<WAVES * 64, RES>(p.geom, s_geom, p.n_frames, threadIdx.x);
-  if (FUSED) fused_stage_step_table<WAVES * 64, RES>(p, s_bk);
+  else if (FUSED) fi = fused_prefetch_indices<WAVES * 64>(p, bid, tix);
+  stage_geom<WAVES * 64, RES>(p.geom, s_geom, p.n_frames, tix);
+  if (FUSED) fused_stage_step_table<WAVES * 64, RES>(p, s_bk, tix);
   lds_barrier();
   PBA_STK(0);
 
@@ -1246,8 +1260,8 @@ __device__ __forceinline__ void sample_wg(SampleParams& p, SampleSmem<R, WAVES>&
   double bs_mcc = 0.0, bs_st2 = 0.0, bs_x2 = 0.0;
   if (FUSED) {
     // ---- phase 0: back-substitution for this workgroup's points (fused_backsub) ------------------------------
-    if constexpr (RES) fused_backsub<WAVES * 64, ResLane<R>>(p, rays, fi, s_bk, reinterpret_cast<double*>(&s_tex[0][0]), pt, slot, obs, active, X, bs_mcc, bs_st2, bs_x2, &rl);
-    else fused_backsub<WAVES * 64>(p, rays, fi, s_bk, reinterpret_cast<double*>(&s_tex[0][0]), pt, slot, obs, active, X, bs_mcc, bs_st2, bs_x2);
+    if constexpr (RES) fused_backsub<WAVES * 64, ResLane<R>>(p, rays, fi, s_bk, reinterpret_cast<double*>(&s_tex[0][0]), pt, slot, obs, active, X, bs_mcc, bs_st2, bs_x2, tix, &rl);
+    else fused_backsub<WAVES * 64>(p, rays, fi, s_bk, reinterpret_cast<double*>(&s_tex[0][0]), pt, slot, obs, active, X, bs_mcc, bs_st2, bs_x2, tix);
     if (PBA_STEP_SUMS_EARLY) fused_wave_step_sums(bs_mcc, bs_st2, bs_x2);
   } else if (active) {
     pt = p.obs_point[obs];
@@ -1774,7 +1788,7 @@ __device__ __forceinline__ void sample_wg(SampleParams& p, SampleSmem<R, WAVES>&
   // deterministic block reductions: butterfly inside each wave, then the waves in order
   if (FUSED) {
     if (!PBA_STEP_SUMS_EARLY) fused_wave_step_sums(bs_mcc, bs_st2, bs_x2);
-    fused_block_partials<WAVES>(p, bid, lane, wave, cost_obs, bs_mcc, bs_st2, bs_x2, s_red, s_fail);
+    fused_block_partials<WAVES>(p, bid, lane, wave, cost_obs, bs_mcc, bs_st2, bs_x2, s_red, s_fail, tix);
   } else {
     const double v = wave_sum(cost_obs);
     if (lane == 0) s_red[wave] = v;
@@ -1782,7 +1796,7 @@ __device__ __forceinline__ void sample_wg(SampleParams& p, SampleSmem<R, WAVES>&
     double a = 0.0;
 #pragma unroll
     for (int w = 0; w < WAVES; ++w) a += s_red[w];
-    if (threadIdx.x == 0) {
+    if (tix == 0) {
       p.block_cost[bid] = a;
       p.block_fail[bid] = s_fail;
     }
@@ -1790,10 +1804,10 @@ __device__ __forceinline__ void sample_wg(SampleParams& p, SampleSmem<R, WAVES>&
   PBA_STK(5);
   tk[6] = t_begin; tk[7] = p.dbg ? __builtin_amdgcn_s_memrealtime() : 0;
   tk[0] |= (unsigned long long)(__builtin_amdgcn_s_getreg(6164) & 15u) << 56;   // HW_REG_XCC_ID[3:0]
-  if (p.dbg && threadIdx.x == 0) for (int k = 0; k < 8; ++k) p.dbg[blockIdx.x * 8 + k] = tk[k];
+  if (p.dbg && tix == 0) for (int k = 0; k < 8; ++k) p.dbg[blockIdx.x * 8 + k] = tk[k];
 #undef PBA_STK
   (void)n_blocks;
-  if (FUSED && !RES) fused_finalize<WAVES>(p, lane, wave, &s_base[0][0], reinterpret_cast<double*>(&s_tex[0][0]), t_begin);
+  if (FUSED && !RES) fused_finalize<WAVES>(p, lane, wave, &s_base[0][0], reinterpret_cast<double*>(&s_tex[0][0]), t_begin, tix);
 }
 
 // amdgpu_waves_per_eu(N, N): the register allocator / scheduler works for exactly N resident waves per SIMD (with only a
@@ -1808,7 +1822,7 @@ void k_sample(SampleParams p_in) {
     reinterpret_cast<unsigned*>(p.lm_init_dst)[threadIdx.x] = __hip_atomic_load(reinterpret_cast<const unsigned*>(p.lm_init_src) + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   __shared__ SampleSmem<R, WAVES> sm;
   ResLane<R> unused;      // (three-kernel path: nothing is resident)
-  sample_wg<R, JAC, WAVES, FUSED, UNITW, FAST, false>(p, sm, unused, xcd_logical_block(blockIdx.x, gridDim.x), (int)gridDim.x);
+  sample_wg<R, JAC, WAVES, FUSED, UNITW, FAST, false>(p, sm, unused, xcd_logical_block(blockIdx.x, gridDim.x), (int)gridDim.x, (int)threadIdx.x);
 }
 
 // =====================================================================================================
@@ -2061,16 +2075,16 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(PBA_
   CamGeom* s_geom = reinterpret_cast<CamGeom*>(s_raw + kBsBytes);
   double* s_bk = reinterpret_cast<double*>(s_geom + kMaxFrames);
   FusedIdx fi{make_int4(0, 0, 0, 0), 0, 0, 0, 0};
-  if (FUSED) fi = fused_prefetch_indices<WAVES * 64>(p, bid);
+  if (FUSED) fi = fused_prefetch_indices<WAVES * 64>(p, bid, (int)threadIdx.x);
   stage_geom<WAVES * 64>(p.geom, s_geom, p.n_frames, threadIdx.x);
-  if (FUSED) fused_stage_step_table<WAVES * 64>(p, s_bk);
+  if (FUSED) fused_stage_step_table<WAVES * 64>(p, s_bk, (int)threadIdx.x);
   lds_barrier();
 
   int pt = 0, slot = 0;
   double prm[3] = {0.0, 0.0, 0.0};
   double bs_mcc = 0.0, bs_st2 = 0.0, bs_x2 = 0.0;
   if (FUSED) {
-    fused_backsub<WAVES * 64>(p, p.rays, fi, s_bk, reinterpret_cast<double*>(s_raw), pt, slot, obs, active, prm, bs_mcc, bs_st2, bs_x2);
+    fused_backsub<WAVES * 64>(p, p.rays, fi, s_bk, reinterpret_cast<double*>(s_raw), pt, slot, obs, active, prm, bs_mcc, bs_st2, bs_x2, (int)threadIdx.x);
   } else if (active) {
     pt = p.obs_point[obs];
     slot = p.obs_slot[obs];
@@ -2240,8 +2254,8 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(PBA_
   if (FUSED) {
     lds_barrier();        // every wave is done with the texel region / s_base before the finalisation reuses them
     fused_wave_step_sums(bs_mcc, bs_st2, bs_x2);
-    fused_block_partials<WAVES>(p, bid, lane, wave, cost_obs, bs_mcc, bs_st2, bs_x2, s_red, s_fail);
-    fused_finalize<WAVES>(p, lane, wave, &s_base[0][0], reinterpret_cast<double*>(s_raw), 0ull);
+    fused_block_partials<WAVES>(p, bid, lane, wave, cost_obs, bs_mcc, bs_st2, bs_x2, s_red, s_fail, (int)threadIdx.x);
+    fused_finalize<WAVES>(p, lane, wave, &s_base[0][0], reinterpret_cast<double*>(s_raw), 0ull, (int)threadIdx.x);
   } else {
     const double ws = wave_sum(cost_obs);
     if (lane == 0) s_red[wave] = ws;

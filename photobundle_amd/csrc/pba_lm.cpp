@@ -24,6 +24,23 @@ namespace {
 double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 }
 
+static int summarize_device_solve(pba_engine* e, const pba_solver_options* o, pba_solver_summary* sum, pba_iteration_summary* its,
+                                  int32_t max_out, double t_start, bool verbose, int64_t jac_passes);
+
+// Resident variant (pba_resident.h): the whole solve is ONE cooperative launch -- every workgroup keeps its tiles' state in registers
+// across the iterations, the serial workgroup takes the same decisions (lm_decide) -- and the host only waits for the flush.
+static int solve_resident(pba_engine* e, const pba_solver_options* o, pba_solver_summary* sum, pba_iteration_summary* its,
+                          int32_t max_out, double t_start, bool verbose) {
+  unsigned long long seq = 0;
+  int rc = pba_internal_resident_launch(e, o, &seq);
+  if (rc) return rc;
+  if ((rc = pba_internal_async_wait(e, seq))) return rc;
+  if ((rc = pba_internal_async_end(e))) return rc;
+  const pba::LmState* st = static_cast<const pba::LmState*>(pba_internal_async_state(e));
+  // one Jacobian pass at the initial point + one (speculative) Jacobian pass per step taken
+  return summarize_device_solve(e, o, sum, its, max_out, t_start, verbose, 1 + (int64_t)st->iteration);
+}
+
 // Asynchronous variant: the same trust-region rules are evaluated on the device by the last workgroup of every
 // candidate pass (pba_kernels.h: lm_decide), so the host enqueues iterations back to back (at most kAhead in flight
 // beyond the last one it has seen finish) instead of paying a launch + completion round trip per step.
@@ -77,6 +94,14 @@ static int solve_async(pba_engine* e, const pba_solver_options* o, pba_solver_su
   tt[6] = now();
   if (tr) std::fprintf(stderr, "solve_async us: entry->begin %.1f, begin %.1f, enqueue0 %.1f, loop %.1f, final enqueues %.1f, final wait %.1f, end %.1f\n",
                        1e6 * (tt[0] - t_start), 1e6 * (tt[1] - tt[0]), 1e6 * (tt[2] - tt[1]), 1e6 * (tt[3] - tt[2]), 1e6 * (tt[4] - tt[3]), 1e6 * (tt[5] - tt[4]), 1e6 * (tt[6] - tt[5]));
+  return summarize_device_solve(e, o, sum, its, max_out, t_start, verbose, -1);
+}
+
+// The host mirror of the device-side trust-region state and iteration log -> pba_solver_summary / iteration summaries.
+// jac_passes < 0: the pass counters of the engine (asynchronous driver); else the count to report (resident solve).
+static int summarize_device_solve(pba_engine* e, const pba_solver_options* o, pba_solver_summary* sum, pba_iteration_summary* its,
+                                  int32_t max_out, double t_start, bool verbose, int64_t jac_passes) {
+  using pba::LmState;
   LmState fin;
   std::memcpy(&fin, const_cast<const LmState*>(static_cast<const LmState*>(pba_internal_async_state(e))), sizeof(fin));
   const pba_iteration_summary* log = pba_internal_async_log(e);
@@ -98,6 +123,7 @@ static int solve_async(pba_engine* e, const pba_solver_options* o, pba_solver_su
   sum->num_iterations = n_log < max_out ? n_log : max_out;
   sum->num_resolve_passes = fin.num_unsuccessful;
   pba_internal_pass_counts(e, &sum->num_jacobian_passes, &sum->num_cost_passes);
+  if (jac_passes >= 0) { sum->num_jacobian_passes = jac_passes; sum->num_cost_passes = 0; }
   switch (fin.done) {
     case pba::kLmGradientTolerance:
       sum->termination_type = 0;
@@ -154,6 +180,7 @@ extern "C" int pba_solve(pba_engine* e, const pba_solver_options* o, pba_solver_
   const bool verbose = o->verbose && pba_internal_rank(e) == 0;
   if (pba_internal_async_capable(e, o)) {
     pba_internal_reset_pass_counts(e);
+    if (pba_internal_resident_capable(e, o)) return solve_resident(e, o, sum, its, max_out, t_start, verbose);
     return solve_async(e, o, sum, its, max_out, t_start, verbose);
   }
 

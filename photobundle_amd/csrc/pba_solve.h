@@ -74,50 +74,66 @@ struct ReduceParams {
   int32_t first_entry;      // entries below it are neither read nor stored (gradient-only final pass: the pair blocks and the rhs)
 };
 
-template <int STORE>
-__device__ __forceinline__ void reduce_partials(const ReduceParams& rp, double (*s_red)[kReduceEntries + 1], int* s_f) {
+// T = threads of the calling workgroup: kReduceThreads (the reduction kernels), or 256 in the resident solve, where every thread
+// plays 512 / T of the 512 (entry, sub-chunk) roles -- the same loads, the same sums in the same order.  (vb, nvb) = this workgroup's
+// index in / size of the reduction grid (blockIdx.x, gridDim.x in the kernels; virtual blocks in the resident solve).  AGL: the
+// partials and block costs were written by other workgroups of the SAME launch (resident solve): agent-scope loads.
+template <int STORE, int T = kReduceThreads, bool AGL = false>
+__device__ __forceinline__ void reduce_partials(const ReduceParams& rp, double (*s_red)[kReduceEntries + 1], int* s_f, const int vb, const int nvb,
+                                                const int tid = (int)threadIdx.x) {
   constexpr int EX = kReduceEntries, SUB = kReduceThreads / EX, NF = kReduceInFlight;
-  const int tid = threadIdx.x;
-  const int ex = tid % EX, sub = tid / EX;
+  constexpr int ROLES = kReduceThreads / T;
+  static_assert(T * ROLES == kReduceThreads && T % 64 == 0, "whole waves of roles");
   const int stride = rp.stride, n_blocks = rp.n_blocks;
   const int n = 6 * rp.n_free, TRI = tri_index(n + 1);
-  if ((int)blockIdx.x < (int)gridDim.x - 1) {
-    const int e = blockIdx.x * EX + ex;
+  auto ldp = [&](const double* q) { return AGL ? load_agent(q) : *q; };
+  if (vb < nvb - 1) {
+    const int ex = tid % EX;                       // (T is a multiple of EX: the same for every role of the thread)
+    const int e = vb * EX + ex;
     const bool valid = e < stride && e >= rp.first_entry;
     const bool is_max = (e == stride - 3) || (e == stride - 1);
-    double acc = 0.0;
-    double v[NF];
+    double acc[ROLES];
+    double v[ROLES][NF];
     if (valid) {
 #pragma unroll
-      for (int k = 0; k < NF; ++k) {
-        const int bb = sub + SUB * k;
-        v[k] = (bb < n_blocks) ? rp.partial[((size_t)blockIdx.x * n_blocks + bb) * EX + ex] : 0.0;
+      for (int r = 0; r < ROLES; ++r) {
+        const int sub = (tid + r * T) / EX;
+#pragma unroll
+        for (int k = 0; k < NF; ++k) {
+          const int bb = sub + SUB * k;
+          v[r][k] = (bb < n_blocks) ? ldp(rp.partial + ((size_t)vb * n_blocks + bb) * EX + ex) : 0.0;
+        }
       }
     }
     // destination of this entry: integer work under the loads
-    const int dest = (valid && sub == 0) ? packed_dest(e, rp.n_free, rp.n_pairs) : -1;
-    if (valid) {
+    const int dest = (valid && tid < EX) ? packed_dest(e, rp.n_free, rp.n_pairs) : -1;
 #pragma unroll
-      for (int k = 0; k < NF; ++k) acc = is_max ? fmax(acc, v[k]) : acc + v[k];
-      for (int b = sub + NF * SUB; b < n_blocks; b += NF * SUB) {      // (grids beyond 1024 partials: not used today)
+    for (int r = 0; r < ROLES; ++r) {
+      const int sub = (tid + r * T) / EX;
+      acc[r] = 0.0;
+      if (valid) {
 #pragma unroll
-        for (int k = 0; k < NF; ++k) {
-          const int bb = b + SUB * k;
-          v[k] = (bb < n_blocks) ? rp.partial[((size_t)blockIdx.x * n_blocks + bb) * EX + ex] : 0.0;
+        for (int k = 0; k < NF; ++k) acc[r] = is_max ? fmax(acc[r], v[r][k]) : acc[r] + v[r][k];
+        for (int b = sub + NF * SUB; b < n_blocks; b += NF * SUB) {      // (grids beyond 1024 partials: not used today)
+#pragma unroll
+          for (int k = 0; k < NF; ++k) {
+            const int bb = b + SUB * k;
+            v[r][k] = (bb < n_blocks) ? ldp(rp.partial + ((size_t)vb * n_blocks + bb) * EX + ex) : 0.0;
+          }
+#pragma unroll
+          for (int k = 0; k < NF; ++k) acc[r] = is_max ? fmax(acc[r], v[r][k]) : acc[r] + v[r][k];
         }
-#pragma unroll
-        for (int k = 0; k < NF; ++k) acc = is_max ? fmax(acc, v[k]) : acc + v[k];
       }
-    }
-    static_assert(EX == 16, "lane = 16 (sub % 4) + ex");
+      static_assert(EX == 16, "lane = 16 (sub % 4) + ex");
 #pragma unroll
-    for (int off = 16; off <= 32; off <<= 1) {
-      const double o = __shfl_xor(acc, off);
-      acc = is_max ? fmax(acc, o) : acc + o;
+      for (int off = 16; off <= 32; off <<= 1) {
+        const double o = __shfl_xor(acc[r], off);
+        acc[r] = is_max ? fmax(acc[r], o) : acc[r] + o;
+      }
+      if ((tid & 63) < EX) s_red[(tid + r * T) >> 6][ex] = acc[r];
     }
-    if ((tid & 63) < EX) s_red[tid >> 6][ex] = acc;
     __syncthreads();
-    if (sub == 0 && valid) {
+    if (tid < EX && valid) {
       double s = s_red[0][ex];
 #pragma unroll
       for (int w = 1; w < kReduceThreads / 64; ++w) s = is_max ? fmax(s, s_red[w][ex]) : s + s_red[w][ex];
@@ -129,11 +145,17 @@ __device__ __forceinline__ void reduce_partials(const ReduceParams& rp, double (
   } else {
     // last workgroup: cost of the linearisation point = fixed-order sum of the Jacobian-pass block partials (strided per
     // thread, butterfly per wave, the 8 waves in order: one barrier instead of a ten-level LDS tree)
-    double acc = 0.0; int f = 0;
-    for (int b = tid; b < rp.n_cost_blocks; b += kReduceThreads) { acc += rp.block_cost[b]; f |= rp.block_fail[b]; }
-    acc = wave_sum(acc);
-    f = __any(f) ? 1 : 0;
-    if ((tid & 63) == 0) { s_red[tid >> 6][0] = acc; s_f[tid >> 6] = f; }
+#pragma unroll
+    for (int r = 0; r < ROLES; ++r) {
+      double acc = 0.0; int f = 0;
+      for (int b = tid + r * T; b < rp.n_cost_blocks; b += kReduceThreads) {
+        acc += ldp(rp.block_cost + b);
+        f |= AGL ? __hip_atomic_load(rp.block_fail + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : rp.block_fail[b];
+      }
+      acc = wave_sum(acc);
+      f = __any(f) ? 1 : 0;
+      if ((tid & 63) == 0) { s_red[(tid + r * T) >> 6][0] = acc; s_f[(tid + r * T) >> 6] = f; }
+    }
     __syncthreads();
     if (tid == 0) {
       double s = s_red[0][0]; int ff = s_f[0];
@@ -857,8 +879,8 @@ __global__ __launch_bounds__(kReduceThreads) void k_reduce_final(ReduceFinalPara
   __shared__ int s_f[16];
   if (!skip) {
     if (fp.lm && fp.lm->cur != fp.enq_cur) { rp.block_cost = fp.block_cost_alt; rp.block_fail = fp.block_fail_alt; }
-    if (fp.sys_stores) reduce_partials<2>(rp, s_red, s_f);
-    else reduce_partials<0>(rp, s_red, s_f);
+    if (fp.sys_stores) reduce_partials<2>(rp, s_red, s_f, (int)blockIdx.x, (int)gridDim.x);
+    else reduce_partials<0>(rp, s_red, s_f, (int)blockIdx.x, (int)gridDim.x);
   }
   if (fp.peer_flag >= 0) {
     // (a terminated solve still raises the flag: the peers' consumers are no-ops too, but the sequence stays in step)
@@ -926,7 +948,7 @@ __global__ __launch_bounds__(kReduceThreads) void k_reduce_solve(ReduceSolvePara
   __shared__ int s_f[16];
   __shared__ int s_last;
   const int tid = threadIdx.x;
-  reduce_partials<1>(rp, s_red, s_f);
+  reduce_partials<1>(rp, s_red, s_f, (int)blockIdx.x, (int)gridDim.x);
   // ---- ticket: the last workgroup to arrive solves ----------------------------------------------------------------
   // every storing thread waits until its write-through stores have left the CU, then the workgroup takes its ticket
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

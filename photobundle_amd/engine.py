@@ -287,6 +287,10 @@ class Engine:
         self._check(self._L.pba_comm_enable_peer_exchange(self._h), "pba_comm_enable_peer_exchange")
         return self.comm_transport()
 
+    def solve_driver(self):
+        """Which driver ran the last solve: "resident" (one cooperative launch), "pipelined", "host-stepped" or "none"."""
+        return self._L.pba_solve_driver(self._h).decode()
+
     def comm_rank_count(self):
         return int(self._L.pba_comm_rank_count(self._h))
 
