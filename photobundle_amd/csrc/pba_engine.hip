@@ -1798,6 +1798,47 @@ int pba_internal_async_wait(pba_engine* e, unsigned long long seq) {
 
 // ---- resident solve ------------------------------------------------------------------------------------------------
 
+// PBA_RES_TRACE: phase intervals of the serial workgroup (100 MHz stamps), averaged over the steps of the last resident solve
+void pba_internal_resident_trace(pba_engine* e, int iterations) {
+  static const bool res_trace = getenv("PBA_RES_TRACE") != nullptr;
+  if (!res_trace || !e->d_stamp || iterations < 1 || iterations + 2 > kStampMaxIters) return;
+  std::vector<unsigned long long> st((size_t)kResStampRecord * (iterations + 2));
+  if (hipMemcpyAsync(st.data(), e->d_stamp, sizeof(unsigned long long) * st.size(), hipMemcpyDeviceToHost, e->stream) != hipSuccess) return;
+  if (hipStreamSynchronize(e->stream) != hipSuccess) return;
+  double d[5] = {0, 0, 0, 0, 0}, x[5] = {0, 0, 0, 0, 0};
+  int n = 0;
+  for (int r = 1; r <= iterations; ++r) {
+    const unsigned long long* c = &st[(size_t)r * kResStampRecord];
+    const unsigned long long prev = (r == 1) ? 0ull : st[(size_t)(r - 1) * kResStampRecord + kResStampDecided];
+    if (!c[kResStampDecided] || !c[kResStampSchur]) continue;
+    if (prev) d[0] += (double)(c[kResStampSchur] - prev);
+    d[1] += (double)(c[kResStampReduced] - c[kResStampSchur]); d[2] += (double)(c[kResStampSolved] - c[kResStampReduced]);
+    d[3] += (double)(c[kResStampSampled] - c[kResStampSolved]); d[4] += (double)(c[kResStampDecided] - c[kResStampSampled]);
+    if (prev) x[0] += (double)(c[kResStampSchurBegin] - prev);
+    x[1] += (double)(c[kResStampSchurBody] - c[kResStampSchurBegin]); x[2] += (double)(c[kResStampSchur] - c[kResStampSchurBody]);
+    x[3] += (double)(c[kResStampGathered] - c[kResStampSampled]); x[4] += (double)(c[kResStampSampled] - c[kResStampSampleBegin]);
+    ++n;
+  }
+  if (n > 1)
+    std::fprintf(stderr, "resident solve, serial workgroup, us per step over %d steps: elimination %.2f | wait partials + reduce + wait reducers %.2f | solve %.2f | "
+                         "back-substitution + sampling %.2f | wait cost partials + sum + decide %.2f | first linearisation + launch %.2f\n",
+                 n, 0.01 * d[0] / (n - 1), 0.01 * d[1] / n, 0.01 * d[2] / n, 0.01 * d[3] / n, 0.01 * d[4] / n,
+                 0.01 * (double)(st[kResStampRecord + kResStampSchur] - st[kResStampStart]));
+  if (atoi(getenv("PBA_RES_TRACE")) >= 2 && e->d_dbg) {
+    std::vector<unsigned long long> h(16 * (size_t)e->n_tiles);
+    (void)hipMemcpyAsync(h.data(), e->d_dbg, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost, e->stream);
+    (void)hipStreamSynchronize(e->stream);
+    double avg[12] = {0};
+    for (int b = 0; b < e->n_tiles; ++b) for (int k = 0; k < 12; ++k) avg[k] += (double)h[16 * b + k] / e->n_tiles;
+    std::fprintf(stderr, "   schur_body epilogue cycles: combine groups %.0f, camera sums out %.0f, pair blocks out %.0f, statistics %.0f\n", avg[8], avg[9], avg[10], avg[11]);
+    std::fprintf(stderr, "   schur_body phase cycles per tile (100 MHz x ?: s_memtime): stage %.0f, P1 %.0f, point totals %.0f, P + camera record %.0f, camera sums %.0f, factors %.0f, pair blocks %.0f; tile loop %.2f us\n",
+                 avg[0], avg[1], avg[2], avg[3], avg[4], avg[5], avg[6], 0.01 * avg[7]);
+  }
+  if (n > 1)
+    std::fprintf(stderr, "   detail: decision -> elimination starts %.2f, schur_body %.2f, partial stores drained + flag %.2f | cost partials gathered %.2f | "
+                         "sample_wg alone %.2f\n", 0.01 * x[0] / (n - 1), 0.01 * x[1] / n, 0.01 * x[2] / n, 0.01 * x[3] / n, 0.01 * x[4] / n);
+}
+
 // The window fits ONE resident round of 256-thread workgroups (two whole-point tiles each) and the solve is one the resident kernel
 // covers: single rank, single channel, reference-exact sampler, free world points, patch radius <= 2, <= 8 free cameras.
 int pba_internal_resident_capable(pba_engine* e, const pba_solver_options* o) {
@@ -1858,6 +1899,17 @@ int pba_internal_resident_launch(pba_engine* e, const pba_solver_options* o, uns
   P.seq = seq;
   P.stamp = nullptr;
   if (const char* sv = getenv("PBA_RES_STOP")) P.debug_stop = atoi(sv);
+  static const bool res_trace = getenv("PBA_RES_TRACE") != nullptr;      // dev aid: per-phase stamps of the serial workgroup, printed after the solve
+  if (res_trace && o->max_num_iterations + 2 <= kStampMaxIters) {
+    const int rcs = dev_alloc(e, &e->d_stamp, (size_t)(kStampMaxIters + 1) * kStampRecord);
+    if (rcs) return rcs;
+    HIP_TRY(e, hipMemsetAsync(e->d_stamp, 0, sizeof(unsigned long long) * kResStampRecord * (o->max_num_iterations + 2), e->stream));
+    P.stamp = e->d_stamp;
+    if (atoi(getenv("PBA_RES_TRACE")) >= 2) {
+      if (!e->d_dbg) { (void)hipMalloc(reinterpret_cast<void**>(&e->d_dbg), sizeof(unsigned long long) * 8 * (1024 + 4096)); }
+      P.schur_dbg = e->d_dbg;
+    }
+  }
   if (e->stamps && e->d_stamp) {
     // (the stamp block of pba_set_profiling(e, 2) is large enough for kStampMaxIters + 1 records of kStampRecord words)
     static_assert((int)kResStampRecord <= (int)kStampRecord, "resident stamp records fit the block");

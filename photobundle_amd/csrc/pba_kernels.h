@@ -2729,7 +2729,10 @@ __device__ __forceinline__ void schur_body(SchurParams& p, char* smem, const int
     PBA_TICK(6);
   }
   if (p.dbg) tph[7] = __builtin_amdgcn_s_memrealtime() - t_rt0;     // tile loop, 100 MHz
-  if (p.dbg && tid == 0) for (int k = 0; k < 8; ++k) p.dbg[part * 8 + k] = tph[k];
+  if (p.dbg && tid == 0) for (int k = 0; k < 8; ++k) p.dbg[part * (RES ? 16 : 8) + k] = tph[k];
+  unsigned long long tep[6] = {0, 0, 0, 0, 0, 0};
+#define PBA_TEP(k) do { if (RES && p.dbg) tep[k] = __builtin_amdgcn_s_memtime(); } while (0)
+  PBA_TEP(0);
 #undef PBA_TICK
 
   // ---- combine the point groups (fixed order), then per-block partials -----------------------------------
@@ -2744,23 +2747,56 @@ __device__ __forceinline__ void schur_body(SchurParams& p, char* smem, const int
     else if (sc1) store_agent(dst, v);
     else *dst = v;
   };
-  if (owner && grp > 0) {
-    double* dst = s_obs + ((grp - 1) * p.n_pairs + pair) * 36;
+  // r6: with many point groups (n_pairs <= 21: windows of up to seven frames) EVERY thread combines -- entry e = k n_pairs + pair of the
+  // (entry-major) pair-block part of the partial, groups added in group order, i.e. the sums the owners of group 0 used to form alone:
+  // at a 5-frame window that was 10 threads walking 11 x 36 dependent LDS reads each, 13.9 k cycles = 6 us at the end of every
+  // workgroup (profiles/r06/resident_phase_trace.txt), twice the tile loop itself.  Same adds in the same order, so the same bits.
+  const int n_ent = 36 * p.n_pairs;
+  // (six or more groups = windows of up to seven frames; with fewer, the owners' own 36 x (n_groups - 1) adds are cheaper than the detour of
+  // every accumulator through LDS: measured at configs[1], four groups, k_schur 38.9 -> 43.1 us with the spread form)
+  const bool spread = n_groups >= 6;
+  if (spread) {
+    static_assert(36 * kTile <= kTile * kObsStride, "every owner's block fits the observation region");
+    if (owner) {
+      double* dst = s_obs + (size_t)grp * n_ent + pair;
 #pragma unroll
-    for (int k = 0; k < 36; ++k) dst[k] = acc[k];
-  }
-  lds_barrier();
-  if (owner && grp == 0) {
-    for (int g = 1; g < n_groups; ++g) {
-      const double* src = s_obs + ((g - 1) * p.n_pairs + pair) * 36;
+      for (int k = 0; k < 36; ++k) dst[k * p.n_pairs] = acc[k];
+    }
+    lds_barrier();
+    // (rolled: <= 18 entries per thread, 3 at a 5-frame window; the sums land in the slot of group 0)
+#pragma unroll 1
+    for (int e = tid; e < n_ent; e += kTile) {
+      double v = s_obs[e];
+#pragma unroll 1
+      for (int g0 = 1; g0 < n_groups; g0 += 8) {
+        double x[8];
 #pragma unroll
-      for (int k = 0; k < 36; ++k) acc[k] += src[k];
+        for (int l = 0; l < 8; ++l) x[l] = s_obs[(size_t)min(g0 + l, n_groups - 1) * n_ent + e];
+#pragma unroll
+        for (int l = 0; l < 8; ++l) if (g0 + l < n_groups) v += x[l];
+      }
+      s_obs[e] = v;
+    }
+  } else {
+    if (owner && grp > 0) {
+      double* dst = s_obs + ((grp - 1) * p.n_pairs + pair) * 36;
+#pragma unroll
+      for (int k = 0; k < 36; ++k) dst[k] = acc[k];
+    }
+    lds_barrier();
+    if (owner && grp == 0) {
+      for (int g = 1; g < n_groups; ++g) {
+        const double* src = s_obs + ((g - 1) * p.n_pairs + pair) * 36;
+#pragma unroll
+        for (int k = 0; k < 36; ++k) acc[k] += src[k];
+      }
     }
   }
   lds_barrier();
+  PBA_TEP(1);
   // camera-side sums -> LDS: the owners of the diagonal blocks add U_a, the vector entries go out directly
   const int n = 6 * nf;
-  double* s_cam = s_obs;                                                   // [nf][kCamVals]
+  double* s_cam = spread ? s_obs + n_ent : s_obs;                          // [nf][kCamVals] (spread: in the dead slot of group 1, 36 n_pairs >= 33 n_free doubles)
 #pragma unroll
   for (int u = 0; u < kCamAcc; ++u) {
     const int e = tid + u * kTile;
@@ -2777,7 +2813,18 @@ __device__ __forceinline__ void schur_body(SchurParams& p, char* smem, const int
     }
   }
   lds_barrier();
-  if (owner && grp == 0) {
+  PBA_TEP(2);
+  if (spread) {
+#pragma unroll 1
+    for (int e = tid; e < n_ent; e += kTile) {
+      const int k = e / p.n_pairs, pe = e - k * p.n_pairs;
+      int a = 0, rem = pe;
+      while (rem >= nf - a) { rem -= nf - a; ++a; }      // pairs enumerated row by row: diagonal iff rem == 0
+      double v = s_obs[e];
+      if (rem == 0) { const int i = k / 6, j = k - 6 * i; v += s_cam[a * kCamVals + sym6(i, j)]; }
+      put(out_at(PBA_PARTIAL_T ? e : pe * 36 + k), v, PBA_PARTIAL_SC1 != 0);
+    }
+  } else if (owner && grp == 0) {
     if (pa == pb) {
       const double* U = s_cam + pa * kCamVals;
 #pragma unroll
@@ -2791,6 +2838,7 @@ __device__ __forceinline__ void schur_body(SchurParams& p, char* smem, const int
     }
   }
   lds_barrier();
+  PBA_TEP(3);
   // block reductions of the point-gradient statistics (butterfly per wave, then the two waves in order)
   {
     const double g2 = wave_sum(gn2), gm = wave_max(gmax), fl = wave_max((double)fail);
@@ -2805,6 +2853,9 @@ __device__ __forceinline__ void schur_body(SchurParams& p, char* smem, const int
       if (!RES && p.stamp && part < kStampSchurBlocks) p.stamp[kStampSchur0 + part] = __builtin_amdgcn_s_memrealtime();
     }
   }
+  PBA_TEP(4);
+  if (RES && p.dbg && tid == 0) for (int k = 0; k < 4; ++k) p.dbg[part * 16 + 8 + k] = tep[k + 1] - tep[k];
+#undef PBA_TEP
 }
 
 __global__ __launch_bounds__(kTile, 2) void k_schur(SchurParams p_in) {

@@ -66,9 +66,11 @@ struct ResidentParams {
   LmState* host_state; pba_iteration_summary* log; pba_iteration_summary* host_log; int32_t max_log;
   double* host_scal; unsigned long long* host_seq; unsigned long long seq;
   unsigned long long* stamp;      // null, or [kResStampRecord * (iterations + 2)] 100 MHz stamps of the serial workgroup
+  unsigned long long* schur_dbg;  // development aid (PBA_RES_TRACE=2): [n_tiles][8] per-phase cycle sums of the elimination (thread 0 of every tile)
   int32_t debug_stop;             // development aid (PBA_RES_STOP): leave the loop behind phase k of the first step (0: never)
 };
-enum ResStamp { kResStampStart = 0, kResStampSchur, kResStampReduced, kResStampSolved, kResStampSampled, kResStampDecided, kResStampRecord = 8 };
+enum ResStamp { kResStampStart = 0, kResStampSchur, kResStampReduced, kResStampSolved, kResStampSampled, kResStampDecided, kResStampSchurBegin, kResStampSchurBody,
+                kResStampGathered, kResStampSampleBegin, kResStampRecord = 12 };
 
 __device__ __forceinline__ void res_flag_set(unsigned* sync, int idx, unsigned ep) {
   __hip_atomic_store(sync + (size_t)idx * kResFlagStride, ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -199,6 +201,7 @@ __global__ __launch_bounds__(kResThreads) void k_resident(ResidentParams P) {
       sp.geom = P.geom[which]; sp.geom_prev = P.geom[cur];
       sp.block_cost = P.block_cost[which]; sp.block_fail = P.block_fail[which];
       sp.skip_backsub = skip;
+      if (stamp) stamp[kResStampSampleBegin] = __builtin_amdgcn_s_memrealtime();
       sample_wg<R, true, WAVES, true, UNITW, false, true>(sp, sm, rl, w, G, tid, s_geomL[which]);
     }
     if (P.debug_stop == (skip ? 1 : 5)) break;
@@ -211,6 +214,7 @@ __global__ __launch_bounds__(kResThreads) void k_resident(ResidentParams P) {
       // ---- trust-region decision (serial workgroup), read by everybody ----
       if (serial) {
         if (!res_wait(sync, kResFlagArrive4, G, ep, P.timeout_ticks)) { ok = false; break; }
+        if (stamp) stamp[kResStampGathered] = __builtin_amdgcn_s_memrealtime();
         fused_sum_partials<WAVES>(P.block_bs, P.block_cost[1 - cur], G, lane, wave, s_f, s_r4, nullptr, tid);
       } else {
         if (!res_wait(sync, kResFlagGo5, 1, ep, P.timeout_ticks)) { ok = false; break; }
@@ -268,9 +272,11 @@ __global__ __launch_bounds__(kResThreads) void k_resident(ResidentParams P) {
       SchurParams sc{};
       sc.partial = P.partial; sc.rec_stride = P.rec_stride; sc.n_tiles = P.n_tiles; sc.n_frames = P.n_frames; sc.n_free = P.n_free;
       sc.n_pairs = P.n_pairs; sc.part_stride = P.part_stride; sc.init_scale = init_scale; sc.jacobi = P.jacobi; sc.fx = P.fx; sc.fy = P.fy;
-      sc.radius = radius; sc.inv_radius = 1.0 / radius; sc.min_diag = P.min_diag; sc.max_diag = P.max_diag; sc.final_pass = final_pass;
+      sc.radius = radius; sc.inv_radius = 1.0 / radius; sc.min_diag = P.min_diag; sc.max_diag = P.max_diag; sc.final_pass = final_pass; sc.dbg = final_pass ? nullptr : P.schur_dbg;
       __syncthreads();                                    // the pool changes hands: sampling -> Schur tiles (s_dec is free again, too)
+      if (stamp) stamp[kResStampSchurBegin] = __builtin_amdgcn_s_memrealtime();
       schur_body<ResLane<R>>(sc, pool + (size_t)half * kSchurSmemBytes, lt, tile, P.n_tiles, &rl, s_geomL[cur], has_tile);
+      if (stamp) stamp[kResStampSchurBody] = __builtin_amdgcn_s_memrealtime();
     }
     if (P.debug_stop == 2) break;
     arrive(kResFlagArrive1 + w);
@@ -283,7 +289,7 @@ __global__ __launch_bounds__(kResThreads) void k_resident(ResidentParams P) {
       rp.block_cost = P.block_cost[cur]; rp.block_fail = P.block_fail[cur]; rp.n_cost_blocks = G; rp.packed = P.packed; rp.scal = P.scal;
       rp.first_entry = grad_only ? 36 * P.n_pairs + n : 0;
       for (int v = w; v < nred; v += G) {
-        reduce_partials<1, kResThreads, true>(rp, s_red, s_f, v, nred, tid);
+        reduce_partials<1, kResThreads, true, 16>(rp, s_red, s_f, v, nred, tid);
         arrive(kResFlagArrive2 + v);
       }
     }

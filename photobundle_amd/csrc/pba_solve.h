@@ -78,10 +78,11 @@ struct ReduceParams {
 // plays 512 / T of the 512 (entry, sub-chunk) roles -- the same loads, the same sums in the same order.  (vb, nvb) = this workgroup's
 // index in / size of the reduction grid (blockIdx.x, gridDim.x in the kernels; virtual blocks in the resident solve).  AGL: the
 // partials and block costs were written by other workgroups of the SAME launch (resident solve): agent-scope loads.
-template <int STORE, int T = kReduceThreads, bool AGL = false>
+// NF = partials in flight per (entry, sub-chunk) role: the same sums in the same order for every NF (the resident solve, <= 512 partials, uses 16).
+template <int STORE, int T = kReduceThreads, bool AGL = false, int NF = kReduceInFlight>
 __device__ __forceinline__ void reduce_partials(const ReduceParams& rp, double (*s_red)[kReduceEntries + 1], int* s_f, const int vb, const int nvb,
                                                 const int tid = (int)threadIdx.x) {
-  constexpr int EX = kReduceEntries, SUB = kReduceThreads / EX, NF = kReduceInFlight;
+  constexpr int EX = kReduceEntries, SUB = kReduceThreads / EX;
   constexpr int ROLES = kReduceThreads / T;
   static_assert(T * ROLES == kReduceThreads && T % 64 == 0, "whole waves of roles");
   const int stride = rp.stride, n_blocks = rp.n_blocks;
