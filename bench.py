@@ -15,6 +15,10 @@ With N > 1 the same launch also appends a `strong` record: BASELINE.json configs
 solved by rank 0 alone and then point-sharded over the N ranks, time per LM iteration of each and their ratio
 (PBA_BENCH_STRONG=0 skips it).  Inputs are resident in HBM before the timed region.
 
+--config 2 is configs[2], the 3-level pyramid path (reference src/photobundle_pyramid.cc:9-69): one window per level (1241x376,
+621x188, 311x94; calibration halved per level), every level timed like the headline, plus the device-side pyramid build; one JSON
+line whose `levels` list carries the per-level iteration time, kernel shares and roofline figures.
+
 --config 3 is configs[3] as the STRONG-scaling workload itself (`value` = LM iterations per second of the one window);
 `--config 3 --emulate-rank-of R` runs, on ONE GPU, the full window AND one rank's 1/R shard through the multi-rank code
 path (peer exchange at world = 1) and prints the projected R-GPU speed-up; --config 4 is configs[4] (11x11 patches +
@@ -78,13 +82,145 @@ def usable_cores():
     return n
 
 
+def bench_pyramid(args):
+    """BASELINE.json configs[2]: 3-level pyramid (photobundle_pyramid path), 8-frame window, 50k points, 5x5 patch, 1 GPU.
+    The reference runs one PhotometricBundleAdjustment per level, coarse to fine, every level selecting its own points on its own
+    image (src/photobundle_pyramid.cc:34-66); here every level gets a synthetic window of its own size with the calibration halved per
+    level (Calibration::pyrDown) and as many points as the level holds, up to 50k (a 311x94 image has 29k pixels).  One "step" = one LM
+    iteration on EACH level; `value` = such coarse-to-fine iterations per second, `levels` carries every level on its own."""
+    import torch
+    if args.gpus != 1 or int(os.environ.get("WORLD_SIZE", "1")) != 1:
+        raise SystemExit("--config 2 is a single-GPU workload (the pyramid levels of one window run one after the other)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
+    torch.cuda.set_device(0)
+    from photobundle_amd import synthetic
+    from photobundle_amd.engine import Engine, default_solver_options
+    frames = args.frames or 8
+    radius = args.radius or 2
+    want = args.points or 50000
+    size, K = synthetic.KITTI_SIZE, synthetic.KITTI_K
+    t0 = time.time()
+    levels = []
+    for lvl in range(3):
+        rows, cols = size
+        Kl = tuple(v * 0.5 ** lvl for v in K)
+        for _ in range(lvl):
+            rows, cols = (rows + 1) // 2, (cols + 1) // 2
+        # points the level can hold: sites are distinct pixels that stay inside the image in all frames (synthetic.make_window)
+        n_pts = min(want, int(0.40 * (rows - 2 * (radius + 2)) * (cols - 2 * (radius + 2))))
+        prob = synthetic.make_window(n_frames=frames, n_points=n_pts, radius=radius, size=(rows, cols), K=Kl, huber=args.huber or 0.0)
+        levels.append(dict(level=lvl, rows=rows, cols=cols, prob=prob))
+    t_gen = time.time() - t0
+
+    def opts(k):
+        return default_solver_options(max_num_iterations=k, function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0)
+
+    raw_buffers = Engine.solve_buffers()
+    out_levels, total_s, total_bytes = [], 0.0, 0.0
+    engines = []
+    for L in levels:
+        prob = L["prob"]
+        eng = Engine(L["rows"], L["cols"], prob.K, prob.radius, prob.n_frames, huber=prob.huber, device=0)
+        eng.load(prob)
+        engines.append(eng)
+
+        def reset(eng=eng, prob=prob):
+            eng.set_problem(prob.xyz, prob.desc, prob.obs_point, prob.obs_slot, prob.weights)
+            eng.set_cameras(prob.cams, prob.fixed_slot)
+        if args.warmup > 0:
+            eng.solve(opts(args.warmup))
+        times, res = [], None
+        for _ in range(max(1, args.repeats)):
+            reset()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            raw = eng.solve_raw(opts(args.steps), buffers=raw_buffers)
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t1)
+            res = Engine.unpack_solve(*raw)
+        times.sort()
+        el = times[len(times) // 2]
+        iters = len(res["iterations"]) - 1
+        n_succ = sum(1 for i in res["iterations"][1:] if i["step_is_successful"])
+        reset()
+        eng.set_profiling(2)
+        eng.solve(opts(args.steps))
+        ctr = eng.counters()
+        n_bar = prob.n_obs / prob.n_points
+        ab = algorithmic_bytes(prob.radius, n_bar)
+        n_jac, n_cost, n_res = res["num_jacobian_passes"], res["num_cost_passes"], res["num_resolve_passes"]
+        run_bytes = prob.n_obs * (n_jac * ab["b_jac"] + n_cost * ab["b_cost"] + n_res * ab["b_res"])
+        run_bytes_nominal = prob.n_obs * ((1 + n_succ) * ab["b_jac"] + iters * ab["b_cost"] + (iters - n_succ) * ab["b_res"])
+        per = lambda k: (1e3 * ctr[k + "_ms"] / ctr[k + "_launches"]) if ctr[k + "_launches"] else 0.0
+        kern = {"k_sample<JAC> (Jacobian pass)": (per("linearize"), ab["sample_jac"]), "k_schur (point elimination)": (per("schur"), ab["schur"]),
+                "k_reduce_solve (partials + reduced solve)": (per("solve"), 0.0)}
+        frame_mb = frames * L["rows"] * L["cols"] * 4 / 1e6
+        out_levels.append({
+            "level": L["level"], "image": "%dx%d u8" % (L["cols"], L["rows"]), "points": prob.n_points, "observations": prob.n_obs,
+            "us_per_iteration": 1e6 * el / max(1, iters), "us_per_iteration_min": 1e6 * times[0] / max(1, iters),
+            "us_per_iteration_max": 1e6 * times[-1] / max(1, iters), "iterations": iters, "successful": n_succ,
+            "solve_driver": eng.solve_driver(), "initial_cost": res["initial_cost"], "final_cost": res["final_cost"],
+            "packed_frames_MB": frame_mb,
+            "frames_resident_in": "one XCD's 4 MiB L2" if frame_mb / 8 <= 4.0 else ("the 256 MB Infinity Cache" if frame_mb <= 256 else "HBM"),
+            "kernels_us_per_launch": {k: v[0] for k, v in kern.items()},
+            "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK / 1e9,
+                         "whole_iteration_frac": (run_bytes / el) / HBM_PEAK, "whole_iteration_frac_nominal": (run_bytes_nominal / el) / HBM_PEAK,
+                         "algorithmic_bytes_per_obs": {"b_jac": ab["b_jac"], "b_cost": ab["b_cost"], "b_res": ab["b_res"]},
+                         "per_kernel": {k: {"avg_launch_us": v[0], "algorithmic_bytes_per_obs": v[1],
+                                            "achieved": (prob.n_obs * v[1] / (1e-6 * v[0]) / 1e9) if v[0] > 0 else 0.0,
+                                            "frac": (prob.n_obs * v[1] / (1e-6 * v[0]) / HBM_PEAK) if v[0] > 0 else 0.0} for k, v in kern.items()},
+                         "traffic": None,
+                         "traffic_note": "counter passes of this workload: profiles/r06/config2_* (tools/profile_config2.sh)"}})
+        total_s += el / max(1, iters)
+        total_bytes += run_bytes / max(1, iters)
+    # ---- pyramid build: level 0 frames are resident; levels 1, 2 are produced on the device, level to level (pba_set_frame_pyr_down) ----
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    build_ms = []
+    for _ in range(5):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for s_ in range(frames):
+            engines[1].set_frame_pyr_down(s_, engines[0], s_, want_image=False)
+            engines[2].set_frame_pyr_down(s_, engines[1], s_, want_image=False)
+        torch.cuda.synchronize()
+        build_ms.append(1e3 * (time.perf_counter() - t1))
+    build_ms.sort()
+    dom = max(out_levels, key=lambda l: l["us_per_iteration"])
+    dk = max((k for k in dom["roofline"]["per_kernel"] if dom["roofline"]["per_kernel"][k]["algorithmic_bytes_per_obs"] > 0),
+             key=lambda k: dom["roofline"]["per_kernel"][k]["avg_launch_us"])
+    out = {
+        "metric": "LM iters/sec + residuals/sec, 8-frame KITTI window, 50k pts, 5x5 patch",
+        "value": 1.0 / total_s, "unit": "coarse-to-fine LM iterations/s (one iteration on each of the 3 pyramid levels)",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * total_s, "repeats": max(1, args.repeats),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "configs[2]: 3-level pyramid, %d-frame window, up to %d points per level, %dx%d patch, dense visibility"
+                               % (frames, want, 2 * radius + 1, 2 * radius + 1),
+                   "levels": [l["image"] for l in out_levels], "observations": [l["observations"] for l in out_levels],
+                   "sampler_precision": "exact", "channels": 1, "parallelism": "single GPU, the levels one after the other (coarse to fine in the class)"},
+        "levels": out_levels,
+        "pyramid_build": {"ms_per_window": build_ms[len(build_ms) // 2], "ms_per_frame": build_ms[len(build_ms) // 2] / frames,
+                          "what": "cv::pyrDown of %d frames into levels 1 and 2 on the device (k_pyr_down + k_pack_frame, pba_set_frame_pyr_down), host wall clock "
+                                  "around the %d calls + synchronize; the class pays it once per NEW frame, i.e. 1/%d of this per addFrame" % (frames, 2 * frames, frames)},
+        "roofline": {"bound": "hbm", "kernel": "%s at level %d (%s)" % (dk, dom["level"], dom["image"]),
+                     "achieved": dom["roofline"]["per_kernel"][dk]["achieved"], "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                     "frac": dom["roofline"]["per_kernel"][dk]["frac"], "traffic": None,
+                     "whole_pass_frac": (total_bytes / total_s) / HBM_PEAK, "kernel_source_id": kernel_source_id(), "traffic_matches_build": None},
+        "gen_seconds": t_gen,
+    }
+    print(json.dumps(out))
+    for e_ in engines:
+        e_.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", type=int, default=1, choices=(1, 3, 4),
+    ap.add_argument("--config", type=int, default=1, choices=(1, 2, 3, 4),
                     help="BASELINE.json configs[k]: 1 = 8 frames x 50k points x 5x5 per GPU (weak scaling, the headline); "
+                         "2 = the 3-level pyramid path: the same window shape at 1241x376, 621x188 and 311x94 (single GPU); "
                          "3 = ONE 16-frame x 200k-point window point-sharded over the N ranks (STRONG scaling: 200k / N points per "
                          "rank, value is not multiplied by N); 4 = 8 frames x 50k points x 11x11 + Huber 0.05 per GPU")
     ap.add_argument("--frames", type=int, default=None)
@@ -114,6 +250,8 @@ def main():
     ap.add_argument("--cpu-points", type=int, default=50000, help="points of the bounded CPU-baseline sample")
     ap.add_argument("--cpu-steps", type=int, default=20)
     args = ap.parse_args()
+    if args.config == 2:
+        return bench_pyramid(args)
     preset = {1: dict(frames=8, points=50000, radius=2, huber=0.0), 3: dict(frames=16, points=200000, radius=2, huber=0.0),
               4: dict(frames=8, points=50000, radius=5, huber=0.05)}[args.config]
     explicit = any(getattr(args, k) is not None for k in preset)
@@ -349,6 +487,9 @@ def main():
         eng.set_profiling(2)
         eng.solve(opts(args.steps))
         timing_source = "device time stamps in the asynchronous pipeline (interval between consecutive kernel ends)"
+        if eng.solve_driver() == "resident":
+            timing_source = ("phase stamps of the serial workgroup of the resident solve (one launch per solve): elimination | reduction + reduced "
+                             "solve | back-substitution + sampling + decision, reported under the names of the kernels that do this work on the pipelined path")
     else:
         eng.reset_counters()
         eng.solve(opts(min(args.steps, 10)))
@@ -442,6 +583,7 @@ def main():
                    "point_parameterisation": "inverse depth on fixed rays (no reference counterpart)" if args.inverse_depth else "free world points (reference)",
                    "parallelism": "points sharded x%d, cameras+frames replicated, %s" % (world, transport)},
         "iters_per_sec": iters_per_sec, "residuals_per_sec": residuals_per_sec,
+        "solve_driver": eng.solve_driver(),
         "lm": {"iterations": iters_done, "successful": n_succ, "solves": -(-args.steps // CHUNK), "jacobian_passes": n_jac,
                "cost_passes": n_cost, "resolve_passes": n_res, "initial_cost": res["initial_cost"],
                "final_cost": res["final_cost"], "message": res["message"]},

@@ -1527,7 +1527,29 @@ const char* pba_solve_driver(const pba_engine* e) {
 
 int pba_get_counters(pba_engine* e, pba_counters* c) {
   if (!e || !c) return PBA_ERR_INVALID;
-  if (e->stamps && e->d_stamp) {
+  if (e->stamps && e->d_stamp && e->last_driver == 1) {
+    // resident solve: phase stamps of the serial workgroup.  The three counters keep their meaning as SHARES OF THE ITERATION: elimination
+    // (k_schur's work) | reduction of the partials + reduced solve (k_reduce_solve's) | back-substitution + sampling + decision (k_sample's)
+    PBA_NOT_POISONED(e);
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    const int n_rec = std::min(std::max(e->stamp_iter, 0) + 2, (int)kStampMaxIters);
+    std::vector<unsigned long long> st((size_t)n_rec * kResStampRecord);
+    HIP_TRY(e, hipMemcpyAsync(st.data(), e->d_stamp, sizeof(unsigned long long) * st.size(), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    double d_sample = 0.0, d_schur = 0.0, d_solve = 0.0;
+    int64_t n = 0;
+    for (int it = 2; it < n_rec; ++it) {
+      const unsigned long long* r = &st[(size_t)it * kResStampRecord];
+      const unsigned long long prev = st[(size_t)(it - 1) * kResStampRecord + kResStampDecided];
+      if (!prev || r[kResStampSchur] <= prev || r[kResStampSolved] <= r[kResStampSchur] || r[kResStampDecided] <= r[kResStampSolved]) continue;   // a step that did not run
+      d_schur += (double)(r[kResStampSchur] - prev); d_solve += (double)(r[kResStampSolved] - r[kResStampSchur]);
+      d_sample += (double)(r[kResStampDecided] - r[kResStampSolved]);
+      ++n;
+    }
+    e->ctr.linearize_ms = 1e-5 * d_sample; e->ctr.linearize_launches = n;
+    e->ctr.schur_ms = 1e-5 * d_schur; e->ctr.schur_launches = n;
+    e->ctr.solve_ms = 1e-5 * d_solve; e->ctr.solve_launches = n;
+  } else if (e->stamps && e->d_stamp) {
     // device time stamps of the LAST asynchronous solve (100 MHz ticks): intervals between consecutive kernel ends
     PBA_NOT_POISONED(e);
     HIP_TRY(e, hipSetDevice(e->cfg.device));
@@ -1910,10 +1932,11 @@ int pba_internal_resident_launch(pba_engine* e, const pba_solver_options* o, uns
       P.schur_dbg = e->d_dbg;
     }
   }
-  if (e->stamps && e->d_stamp) {
-    // (the stamp block of pba_set_profiling(e, 2) is large enough for kStampMaxIters + 1 records of kStampRecord words)
+  if (!P.stamp && e->stamps && e->d_stamp && o->max_num_iterations + 2 <= kStampMaxIters) {
+    // pba_set_profiling(e, 2): the serial workgroup's phase stamps (the block holds kStampMaxIters + 1 records of kStampRecord words)
     static_assert((int)kResStampRecord <= (int)kStampRecord, "resident stamp records fit the block");
-    if (o->max_num_iterations + 2 <= kStampMaxIters) P.stamp = e->d_stamp;
+    HIP_TRY(e, hipMemsetAsync(e->d_stamp, 0, sizeof(unsigned long long) * kResStampRecord * (o->max_num_iterations + 2), e->stream));
+    P.stamp = e->d_stamp;
   }
   const int groups = (e->n_tiles + 1) / 2;
   void* args[] = {&P};

@@ -77,6 +77,9 @@ __device__ __forceinline__ void res_flag_set(unsigned* sync, int idx, unsigned e
 }
 // All threads of the workgroup: wait until the n flags first, first + 1, ... show epoch `ep` (or later).  Returns false when the wait
 // timed out or another workgroup raised the abort word (uniform over the workgroup).
+// (One poll per round trip.  Keeping four polls of every flag in flight, issued a fraction of a microsecond apart so that a flag is seen
+// sooner after it lands, was measured and is SLOWER: the gather of 200 cost partials 2.8 -> 4.8 us, partials + reduction 6.2 -> 9.0 us --
+// the extra loads queue in front of the write-through stores they are waiting for.  profiles/r06/resident_phase_trace.txt.)
 __device__ __forceinline__ bool res_wait(unsigned* sync, int first, int n, unsigned ep, unsigned long long timeout_ticks) {
   const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
   unsigned spins = 0;

@@ -581,7 +581,9 @@ void PhotometricBundleAdjustment::optimize(Result* result) {
   // SAME window independently on the CPU (tests/test_gpu_configs0.py).  Not part of the reference.
   if (const char* dump_dir = std::getenv("PBA_DUMP_WINDOWS")) {
     char fn[1024];
-    std::snprintf(fn, sizeof(fn), "%s/window_%06u.bin", dump_dir, (unsigned)frame_id_end);
+    // (PBA_DUMP_TAG_SIZE: the image size joins the name -- the levels of a pyramid are objects of this class with the same frame ids)
+    if (std::getenv("PBA_DUMP_TAG_SIZE")) std::snprintf(fn, sizeof(fn), "%s/window_%06u_%dx%d.bin", dump_dir, (unsigned)frame_id_end, _image_size.cols, _image_size.rows);
+    else std::snprintf(fn, sizeof(fn), "%s/window_%06u.bin", dump_dir, (unsigned)frame_id_end);
     if (std::FILE* f = std::fopen(fn, "wb")) {
       const Options& op = *_options_ptr;
       const int32_t hdr[12] = {window, (int32_t)selected.size(), (int32_t)obs_point.size(), P, op.patchRadius,

@@ -73,3 +73,23 @@ def test_rank_of_eight_emulation_and_counter_file_id():
     assert 0 < sp["us_per_iteration_one_rank"] < sp["us_per_iteration_full_window_1gpu"]
     assert abs(sp["projected_speedup"] - sp["us_per_iteration_full_window_1gpu"] / sp["projected_us_per_iteration"]) < 1e-9
     assert len(d["roofline"]["kernel_source_id"]) == 12
+
+
+@pytest.mark.timeout(900)
+def test_config2_pyramid_line():
+    """--config 2: BASELINE configs[2], the 3-level pyramid path, as ONE JSON line -- per level (1241x376, 621x188,
+    311x94) the time per LM iteration, the kernel shares and the roofline figures, plus the device-side pyramid build."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "2", "--points", "6000", "--steps", "6", "--warmup", "2",
+                        "--repeats", "3"], capture_output=True, text=True, timeout=850, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _json_line(r.stdout)
+    assert KEYS <= set(d) and d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["workload"].startswith("configs[2]")
+    assert [l["image"] for l in d["levels"]] == ["1241x376 u8", "621x188 u8", "311x94 u8"]
+    for l in d["levels"]:
+        assert l["iterations"] == 6 and l["us_per_iteration"] > 0 and l["final_cost"] < l["initial_cost"]
+        assert l["observations"] == 8 * l["points"] and l["points"] <= 6000
+        assert set(l["kernels_us_per_launch"]) == {"k_sample<JAC> (Jacobian pass)", "k_schur (point elimination)", "k_reduce_solve (partials + reduced solve)"}
+        assert all(v > 0 for v in l["kernels_us_per_launch"].values()), l["kernels_us_per_launch"]
+        assert 0 < l["roofline"]["whole_iteration_frac"] < 1 and l["roofline"]["algorithmic_bytes_per_obs"]["b_jac"] > 700
+    assert abs(d["ms_per_step"] - 1e-3 * sum(l["us_per_iteration"] for l in d["levels"])) < 1e-9
+    assert d["pyramid_build"]["ms_per_window"] > 0 and {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(d["roofline"])

@@ -2,6 +2,7 @@
 reference's apps/run_kitti.cc, checked against a numpy restatement of the front-end + the CPU oracle solve."""
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -228,6 +229,87 @@ def test_configs2_full_size_three_level_pyramid(tmp_path):
     r_ini, t_ini = _pose_errors(chained, T_gt)
     print("configs[2]: mean rotation error %.3e -> %.3e rad, mean translation error %.3e -> %.3e m" % (r_ini.mean(), r_ref.mean(), t_ini.mean(), t_ref.mean()))
     assert r_ref.mean() < 0.5 * r_ini.mean() and t_ref.mean() < 0.5 * t_ini.mean()
+
+
+@pytest.mark.timeout(2400)
+def test_configs2_full_size_windows_replayed_through_the_oracle(tmp_path):
+    """BASELINE configs[2] at its stated shape AGAINST THE ORACLE: the windows the three-level pyramid class hands to its
+    engines (PBA_DUMP_WINDOWS: cameras, points, descriptors, observation lists exactly as passed to pba_set_problem / pba_set_cameras) are
+    solved again by the CPU oracle on the images of their level (cv::pyrDown restatement, calibration halved per level: reference
+    src/photobundle_pyramid.cc:9-69) -- the coarsest (311x94) and the finest (1241x376, ~50k points, ~400k residual blocks) window of two
+    frames, four iterations each as tests/test_gpu_fullsize.py does at configs[1] / configs[3]: identical decisions, costs at 1e-9,
+    cameras at 1e-5 for the engine (same window through the C-ABI), and the finest level's own Result (the class's iteration log as
+    run_kitti -r wrote it) carries the oracle's costs."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from oracle import oracle
+    from oracle.frontend import pyr_down_u8
+    from photobundle_amd import imgproc, synthetic
+    from photobundle_amd.engine import default_solver_options
+    from photobundle_amd.problem import WindowProblem
+    from gpu_util import make_engine
+    from test_gpu_configs0 import _read_window
+    size, K = synthetic.KITTI_SIZE, synthetic.KITTI_K
+    n_frames, window, radius, n_it = 9, 8, 2, 4
+    tmp = str(tmp_path)
+    imgs, depths, local = _write_sequence(tmp, n_frames, size, K)
+    cfg = os.path.join(tmp, "cfg2.cfg")
+    with open(cfg, "w") as f:
+        f.write("DataDirectory = %s\nTrajectory = %s/init.txt\n" % (tmp, tmp))
+        f.write("numLevels = 3\nmaxNumPoints = 16000\nnonMaxSuppRadius = 0\nslidingWindowSize = %d\npatchRadius = %d\nminScore = 0.75\n"
+                "robustThreshold = 0.05\nverbose = 0\n" % (window, radius))
+    dump_dir = os.path.join(tmp, "windows")
+    os.makedirs(dump_dir)
+    res_file = os.path.join(tmp, "results.txt")
+    r = subprocess.run([RUN, "-c", cfg, "-o", os.path.join(tmp, "refined.txt"), "-r", res_file, "-p"], capture_output=True, text=True, timeout=1000,
+                       env=dict(os.environ, PBA_DUMP_WINDOWS=dump_dir, PBA_DUMP_TAG_SIZE="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    levels = [(size[0], size[1])]
+    for _ in range(2):
+        levels.append(((levels[-1][0] + 1) // 2, (levels[-1][1] + 1) // 2))
+    assert levels == [(376, 1241), (188, 621), (94, 311)]
+    names = sorted(os.listdir(dump_dir))
+    assert names == sorted("window_%06d_%dx%d.bin" % (fid, c_, r_) for fid in range(window - 1, n_frames) for (r_, c_) in levels), names
+    results = {g["frame"]: g for g in _read_results(res_file)}
+    # image pyramid of every frame (cv::pyrDown on u8, oracle/frontend.py) and its planes
+    pyr = [[im] for im in imgs]
+    for p_ in pyr:
+        for _ in range(2):
+            p_.append(pyr_down_u8(p_[-1]))
+    for fid in (window - 1, n_frames - 1):
+        for lvl in (2, 0):                      # coarsest, finest
+            rows, cols = levels[lvl]
+            w = _read_window(os.path.join(dump_dir, "window_%06d_%dx%d.bin" % (fid, cols, rows)))
+            assert (w["window"], w["radius"], w["id_end"], w["id_start"]) == (window, radius, fid, fid - window + 1)
+            Kl = tuple(v * 0.5 ** lvl for v in K)                                 # Calibration::pyrDown: K * 0.5 per level
+            frames = [pyr[w["id_start"] + ((s_ - w["id_start"]) % window)][lvl] for s_ in range(window)]      # slot = id % window
+            assert frames[0].shape == (rows, cols)
+            planes = np.stack([imgproc.planes_from_u8(im) for im in frames])
+            fixed = w["first_slot"]
+            p = WindowProblem(K=Kl, radius=radius, planes=planes, cams=w["cams"], xyz=w["xyz"], desc=w["desc"], obs_point=w["obs_point"],
+                              obs_slot=w["obs_slot"], weights=w["weights"], huber=w["huber"], fixed_slot=fixed, images=np.stack(frames))
+            if lvl == 0:
+                assert p.n_points >= 40000 and p.n_obs >= 300000, (p.n_points, p.n_obs)      # the "50k points" window of configs[2]
+            ref = oracle.solve(p, oracle.default_options(max_num_iterations=n_it, use_autodiff=0))
+            with make_engine(p, keep_reduced_system=False) as e:
+                res = e.solve(default_solver_options(max_num_iterations=n_it))
+            assert len(res["iterations"]) == len(ref["iterations"]) == n_it + 1
+            worst = 0.0
+            for a, b in zip(ref["iterations"], res["iterations"]):
+                assert a["step_is_successful"] == b["step_is_successful"] and a["step_is_valid"] == b["step_is_valid"]
+                assert abs(a["cost"] - b["cost"]) <= 1e-9 * abs(a["cost"]), (fid, lvl, a["cost"], b["cost"])
+                worst = max(worst, abs(a["cost"] - b["cost"]) / abs(a["cost"]))
+            cam_err = float(np.abs(res["cams"] - ref["cams"]).max())
+            assert cam_err <= 1e-5, (fid, lvl, cam_err)
+            print("configs[2] frame %d level %d (%dx%d, %d points, %d residual blocks): %d iterations, decisions identical, costs within %.1e, "
+                  "cameras within %.1e of the oracle" % (fid, lvl, cols, rows, p.n_points, p.n_obs, n_it, worst, cam_err))
+            if lvl == 0:
+                # the class's own Result of this frame (finest level): same window, same engine -- its log must carry the oracle's costs too
+                g = results[fid]
+                assert g["residuals"] == p.n_obs * (2 * radius + 1) ** 2
+                assert np.isclose(g["initial"], ref["initial_cost"], rtol=1e-12)
+                for a, b in zip(ref["iterations"], g["it"][:n_it + 1]):
+                    assert b[0] == a["iteration"] and b[2] == a["step_is_successful"]
+                    assert np.isclose(b[3], a["cost"], rtol=1e-9), (fid, b[3], a["cost"])
 
 
 @pytest.mark.timeout(1500)

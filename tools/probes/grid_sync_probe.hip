@@ -6,10 +6,13 @@
 //   mode 4  mode 3 with the flags 64 bytes apart
 //   mode 5  gather + broadcast: workgroup 0 polls the G per-workgroup flags, then stores ONE go-flag everybody else polls (the shape of
 //           "partials -> fixed serial workgroup -> decision")
+//   mode 6  cooperative_groups::this_grid().sync() (the runtime's grid barrier)
+//   mode 7  mode 6 with the 4 KB payload of mode 2 around it
 //   mode 2  mode 1 with a 4 KB write-through (sc1) payload stored and drained (s_waitcnt vmcnt(0)) in front of the ticket and
 //           read back (sc1 loads) by every workgroup behind the flag -- the shape of "partials -> last arriver -> broadcast"
 // Launched cooperatively (hipLaunchCooperativeKernel) with G = CUs x {1, 2} workgroups of 256 threads.
 #include <hip/hip_runtime.h>
+#include <hip/hip_cooperative_groups.h>
 #include <cstdio>
 #include <vector>
 
@@ -33,7 +36,18 @@ __global__ __launch_bounds__(256) void k_sync(unsigned* cnt, unsigned* flag, dou
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
     }
-    if (mode >= 3) {
+    if (mode >= 6) {
+      if (mode == 7) {
+        store_agent(payload + ((size_t)(it & 1) * G + blockIdx.x) * 512 + tid, (double)(it + tid));
+        store_agent(payload + ((size_t)(it & 1) * G + blockIdx.x) * 512 + 256 + tid, (double)(it - tid));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      cooperative_groups::this_grid().sync();
+      if (mode == 7) {
+        const int src = (blockIdx.x + 1 + it) % G;
+        acc += load_agent(payload + ((size_t)(it & 1) * G + src) * 512 + tid) + load_agent(payload + ((size_t)(it & 1) * G + src) * 512 + 256 + tid);
+      }
+    } else if (mode >= 3) {
       const int stride = (mode == 4) ? 16 : 1;
       const unsigned ep = (unsigned)(it + 1);
       unsigned* flags = reinterpret_cast<unsigned*>(payload);      // (reused as the flag array)
@@ -87,7 +101,7 @@ int main() {
   int khz = 0; hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev);
   printf("device %s, %d CUs, wall clock %d kHz, cooperative launch %d\n", prop.name, cus, khz, prop.cooperativeLaunch);
   for (int per_cu : {1, 2})
-    for (int mode : {0, 1, 2, 3, 4, 5})
+    for (int mode : {5, 2, 6, 7})
       for (int sleep : {0, 1}) {
         int G = cus * per_cu, iters = 2000;
         hipMemset(cnt, 0, 4); hipMemset(flag, 0, 4); hipMemset(payload, 0, sizeof(double) * 2 * 1024 * 512);
