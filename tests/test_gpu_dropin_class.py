@@ -288,7 +288,7 @@ def test_configs2_full_size_windows_replayed_through_the_oracle(tmp_path):
             p = WindowProblem(K=Kl, radius=radius, planes=planes, cams=w["cams"], xyz=w["xyz"], desc=w["desc"], obs_point=w["obs_point"],
                               obs_slot=w["obs_slot"], weights=w["weights"], huber=w["huber"], fixed_slot=fixed, images=np.stack(frames))
             if lvl == 0:
-                assert p.n_points >= 40000 and p.n_obs >= 300000, (p.n_points, p.n_obs)      # the "50k points" window of configs[2]
+                assert p.n_points >= 40000 and p.n_obs >= 200000, (p.n_points, p.n_obs)      # the "50k points" window of configs[2] (causal visibility: 4-5 blocks per point)
             ref = oracle.solve(p, oracle.default_options(max_num_iterations=n_it, use_autodiff=0))
             with make_engine(p, keep_reduced_system=False) as e:
                 res = e.solve(default_solver_options(max_num_iterations=n_it))
