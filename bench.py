@@ -56,7 +56,7 @@ def kernel_source_id():
     """sha1 (12 hex digits) over the device sources: ties profiles/traffic.json (tools/collect_profiles.py stores the id of the
     build its counters were taken on) to the build that prints the line."""
     h = hashlib.sha1()
-    for f in ("pba_kernels.h", "pba_solve.h", "pba_device.h", "pba_engine.hip"):
+    for f in ("pba_kernels.h", "pba_solve.h", "pba_resident.h", "pba_device.h", "pba_engine.hip"):
         with open(os.path.join(ROOT, "photobundle_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:12]

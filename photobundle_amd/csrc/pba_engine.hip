@@ -592,6 +592,15 @@ int pba_create(const pba_config* cfg, pba_engine** out) {
   // loads this library's code object now rather than at the first frame (10+ ms in a process that has not touched it yet)
   hipLaunchKernelGGL(k_noop, dim3(1), dim3(64), 0, e->stream);
   if (hipGetLastError() != hipSuccess) return bail(PBA_ERR_HIP);
+  if (e->use_resident && e->coop_launch) {
+    // ... and the first COOPERATIVE launch of a process (the resident solve's kind) sets up its own queue, ~10 ms: paid here, not by the
+    // first optimize().  A refusal only switches the resident driver off (the pipelined one serves everything).
+    void* no_args[] = {nullptr};
+    if (hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&k_noop), dim3(1), dim3(64), no_args, 0, e->stream) != hipSuccess) {
+      (void)hipGetLastError();
+      e->use_resident = false;
+    }
+  }
   if (hipStreamSynchronize(e->stream) != hipSuccess) return bail(PBA_ERR_HIP);
   *out = e;
   return PBA_OK;

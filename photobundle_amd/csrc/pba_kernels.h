@@ -817,7 +817,24 @@ struct SampleParams {
   // first linearisation of an asynchronous solve: workgroup 0 copies the initial trust-region state from the host-mapped mirror
   // to the device (it was a launch of its own, k_lm_init, in front of every solve); null otherwise
   LmState* lm_init_dst; const LmState* lm_init_src;
+  // resident solve (pba_resident.h): the workgroup's four block partials ALSO go out as one line of self-validating words -- eight u64
+  // = epoch << 32 | one half of a double -- that the deciding workgroup polls directly: no drain of the stores in front of a flag, no flag,
+  // no separate load of the partials behind it (three dependent round trips become one).  null on the three-kernel path.
+  unsigned long long* res_tag; unsigned res_epoch;
 };
+
+// epoch-tagged halves of a double (the self-validating words of the resident solve's hand-overs)
+__device__ __forceinline__ void store_tagged(unsigned long long* w, unsigned ep, double v) {
+  const unsigned long long e = (unsigned long long)ep << 32;
+  __hip_atomic_store(w, e | (unsigned)__double2hiint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(w + 1, e | (unsigned)__double2loint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool load_tagged(const unsigned long long* w, unsigned ep, double& v) {
+  const unsigned long long a = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long b = __hip_atomic_load(w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  v = __hiloint2double((int)(unsigned)a, (int)(unsigned)b);
+  return (unsigned)(a >> 32) == ep && (unsigned)(b >> 32) == ep;
+}
 
 // ---- pieces of the FUSED sampling kernels (k_sample, k_sample_mc): the step that leads to the point being sampled -------
 // Compact table of the PREVIOUS cameras for the back-substitution, per slot: R (9) | t (3) | Omega (9) | dt (3) |
@@ -1047,6 +1064,13 @@ __device__ __forceinline__ void fused_block_partials(const SampleParams& p, int 
     store_agent(p.block_bs + 3 * bid + 1, red_out[2]);
     store_agent(p.block_bs + 3 * bid + 2, red_out[3]);
     __hip_atomic_store(p.block_fail + bid, (int32_t)s_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (p.res_tag) {
+      unsigned long long* w = p.res_tag + 8 * (size_t)bid;
+      store_tagged(w, p.res_epoch, s_fail ? __longlong_as_double(0x7ff8000000000000ll) : red_out[0]);
+      store_tagged(w + 2, p.res_epoch, red_out[1]);
+      store_tagged(w + 4, p.res_epoch, red_out[2]);
+      store_tagged(w + 6, p.res_epoch, red_out[3]);
+    }
   }
 }
 
@@ -1056,10 +1080,12 @@ __device__ __forceinline__ void fused_block_partials(const SampleParams& p, int 
 // Fixed-order sums of the per-workgroup partials of a fused sampling pass (by ONE workgroup of WAVES waves): s_r4[q * WAVES] = model cost
 // change | step^2 | x^2 (point parts) | candidate cost, s_f[0] = non-finite flag.  Shared by fused_finalize and the deciding workgroup of
 // the resident solve (pba_resident.h), so that both paths add the same numbers in the same order.
-template <int WAVES>
+// AGL = false: the partials are already in this workgroup's LDS (resident solve: gathered from the tagged lines) -- plain loads.
+template <int WAVES, bool AGL = true>
 __device__ __forceinline__ void fused_sum_partials(const double* block_bs, const double* block_cost, const int n_blocks, const int lane, const int wave,
                                                    int* s_f, double* s_r4, unsigned long long* t_loaded, const int tix) {
   constexpr int NTH = WAVES * 64;
+  auto load_agent = [](const double* q) { return AGL ? pba::load_agent(q) : *q; };
   double a0 = 0, a1 = 0, a2 = 0, a3 = 0; int f = 0;
   // 8 blocks' partials in flight per thread (every load misses this XCD's L2), summed in block order
   for (int b0 = tix; b0 < n_blocks; b0 += 8 * NTH) {

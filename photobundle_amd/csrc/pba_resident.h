@@ -41,7 +41,11 @@ constexpr int kResFlagGo3 = kResFlagArrive4 + kResMaxGroups;
 constexpr int kResFlagGo5 = kResFlagGo3 + 1;
 constexpr int kResFlagAbort = kResFlagGo5 + 1;
 constexpr int kResFlagCount = kResFlagAbort + 1;
-constexpr size_t kResSyncBytes = sizeof(unsigned) * kResFlagStride * kResFlagCount + 8 * sizeof(double);
+// ... behind the flags: the decision as three self-validating words (epoch << 32 | radius high | radius low | parity, termination, final
+// pass), 64 bytes apart, then one 64-byte line of eight such words per workgroup for its four block partials of the sampling pass
+constexpr size_t kResDecisionOffset = sizeof(unsigned) * kResFlagStride * kResFlagCount;      // bytes
+constexpr size_t kResTagOffset = kResDecisionOffset + 3 * 64;
+constexpr size_t kResSyncBytes = kResTagOffset + (size_t)kResMaxGroups * 64;
 
 struct ResidentParams {
   // ---- problem (device memory) ----
@@ -102,6 +106,27 @@ __device__ __forceinline__ bool res_wait(unsigned* sync, int first, int n, unsig
   }
 }
 
+// The same wait on self-validating words instead of flags: not_ready() = this thread's words do not carry the epoch yet (it loads them
+// itself and keeps what it read); uniform result, false on time-out / abort.
+template <class F>
+__device__ __forceinline__ bool res_poll(unsigned* sync, unsigned long long timeout_ticks, F&& not_ready) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  unsigned spins = 0;
+  for (;;) {
+    int vote = not_ready() ? 1 : 0;
+    if (threadIdx.x == kResThreads - 1 && (++spins & 63u) == 0) {
+      if (__hip_atomic_load(sync + (size_t)kResFlagAbort * kResFlagStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) vote |= 2;
+      if (__builtin_amdgcn_s_memrealtime() - t0 > timeout_ticks) {
+        res_flag_set(sync, kResFlagAbort, 1u);
+        vote |= 2;
+      }
+    }
+    const int r = __syncthreads_or(vote);
+    if (r & 2) return false;
+    if (r == 0) return true;
+  }
+}
+
 // LDS the phases share (they never overlap in time inside a workgroup): sampling | two Schur tiles | reduction + reduced solve
 template <int R>
 constexpr size_t resident_pool_bytes(int n) {
@@ -124,6 +149,7 @@ __global__ __launch_bounds__(kResThreads) void k_resident(ResidentParams P) {
   __shared__ double s_r4[4 * WAVES];
   __shared__ LmState s_lm;                               // serial workgroup: THE trust-region state of the solve
   __shared__ double s_dec[4];                            // decision as every workgroup reads it: parity, termination, radius, final pass needed
+  __shared__ unsigned s_decw[3];                         // ... its three payload words as polled
 
   const int tid0 = threadIdx.x;
   const int G = gridDim.x;
@@ -134,7 +160,8 @@ __global__ __launch_bounds__(kResThreads) void k_resident(ResidentParams P) {
   const int n = 6 * P.n_free;
   const int nred = (P.part_stride + kReduceEntries - 1) / kReduceEntries + 1;
   unsigned* sync = P.sync;
-  double* dec_g = reinterpret_cast<double*>(sync + (size_t)kResFlagStride * kResFlagCount);      // decision block in global memory
+  unsigned long long* dec_g = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(sync) + kResDecisionOffset);      // decision words (64 bytes apart)
+  unsigned long long* tag_g = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(sync) + kResTagOffset);          // [G][8] tagged block partials
   unsigned ep = P.epoch0;
   unsigned long long* stamp = (serial && tid0 == 0) ? P.stamp : nullptr;
   if (stamp) stamp[kResStampStart] = __builtin_amdgcn_s_memrealtime();
@@ -204,6 +231,7 @@ __global__ __launch_bounds__(kResThreads) void k_resident(ResidentParams P) {
       sp.geom = P.geom[which]; sp.geom_prev = P.geom[cur];
       sp.block_cost = P.block_cost[which]; sp.block_fail = P.block_fail[which];
       sp.skip_backsub = skip;
+      if (!skip) { sp.res_tag = tag_g; sp.res_epoch = ep; }
       if (stamp) stamp[kResStampSampleBegin] = __builtin_amdgcn_s_memrealtime();
       sample_wg<R, true, WAVES, true, UNITW, false, true>(sp, sm, rl, w, G, tid, s_geomL[which]);
     }
@@ -212,22 +240,29 @@ __global__ __launch_bounds__(kResThreads) void k_resident(ResidentParams P) {
 #pragma unroll
       for (int k = 0; k < 6; ++k) rl.rec[k] = rl.recc[k];
     } else {
-      arrive(kResFlagArrive4 + w);
       if (stamp) stamp[kResStampSampled] = __builtin_amdgcn_s_memrealtime();
-      // ---- trust-region decision (serial workgroup), read by everybody ----
+      // ---- trust-region decision (serial workgroup), read by everybody.  Both hand-overs are SELF-VALIDATING words (epoch << 32 | payload,
+      // 64-bit atomic stores, fire and forget): the consumer polls the data itself, so "drain the stores, raise a flag, see the flag, load the
+      // data" -- three dependent round trips of 1-2 us -- is one. ----
       if (serial) {
-        if (!res_wait(sync, kResFlagArrive4, G, ep, P.timeout_ticks)) { ok = false; break; }
+        double* s_bsL = reinterpret_cast<double*>(pool);            // [3 G] | [G]: the gathered partials, laid out like the global arrays
+        double* s_costL = s_bsL + 3 * kResMaxGroups;
+        auto gather = [&]() -> bool {
+          bool behind = false;
+          for (int g = tid; g < G; g += kResThreads) {
+            double v[4];
+            bool okl = true;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) okl = load_tagged(tag_g + 8 * (size_t)g + 2 * q, ep, v[q]) && okl;
+            s_costL[g] = v[0]; s_bsL[3 * g] = v[1]; s_bsL[3 * g + 1] = v[2]; s_bsL[3 * g + 2] = v[3];
+            behind = behind || !okl;
+          }
+          return behind;
+        };
+        __syncthreads();                                  // (every thread is done with the sampling phase's LDS)
+        if (!res_poll(sync, P.timeout_ticks, gather)) { ok = false; break; }
         if (stamp) stamp[kResStampGathered] = __builtin_amdgcn_s_memrealtime();
-        fused_sum_partials<WAVES>(P.block_bs, P.block_cost[1 - cur], G, lane, wave, s_f, s_r4, nullptr, tid);
-      } else {
-        if (!res_wait(sync, kResFlagGo5, 1, ep, P.timeout_ticks)) { ok = false; break; }
-        if (tid < 4) s_dec[tid] = load_agent(dec_g + tid);
-        __syncthreads();
-      }
-    }
-    int final_pass = 0;
-    {
-      if (serial && !skip) {
+        fused_sum_partials<WAVES, false>(s_bsL, s_costL, G, lane, wave, s_f, s_r4, nullptr, tid);
         // the serial workgroup's decision for the step and its publication
         if (tid == 0) {
           double sl[kNumScal];
@@ -239,14 +274,33 @@ __global__ __launch_bounds__(kResThreads) void k_resident(ResidentParams P) {
           P.scal[kCandCost] = sl[kCandCost]; P.scal[kEvalFailCand] = sl[kEvalFailCand];
           lm_decide(&s_lm, sl, P.log, P.max_log, 0);
           if (s_lm.done && s_lm.done_seq == 0) s_lm.done_seq = P.seq;
-          s_dec[0] = (double)s_lm.cur; s_dec[1] = (double)s_lm.done; s_dec[2] = s_lm.radius; s_dec[3] = lm_final_pass_needed(&s_lm) ? 1.0 : 0.0;
+          s_decw[0] = (unsigned)__double2hiint(s_lm.radius); s_decw[1] = (unsigned)__double2loint(s_lm.radius);
+          s_decw[2] = (unsigned)(s_lm.cur & 1) | ((unsigned)s_lm.done << 4) | (lm_final_pass_needed(&s_lm) ? 1u << 12 : 0u);
 #pragma unroll
-          for (int k = 0; k < 4; ++k) store_agent(dec_g + k, s_dec[k]);
+          for (int k = 0; k < 3; ++k)
+            __hip_atomic_store(dec_g + 8 * k, ((unsigned long long)ep << 32) | s_decw[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (stamp) stamp[kResStampDecided] = __builtin_amdgcn_s_memrealtime();
-        arrive(kResFlagGo5);
+        __syncthreads();
+      } else {
+        auto decision = [&]() -> bool {
+          bool behind = false;
+          if (tid < 3) {
+            const unsigned long long wv = __hip_atomic_load(dec_g + 8 * tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            behind = (unsigned)(wv >> 32) != ep;
+            s_decw[tid] = (unsigned)wv;
+          }
+          return behind;
+        };
+        if (!res_poll(sync, P.timeout_ticks, decision)) { ok = false; break; }
       }
+      if (tid == 0) {
+        s_dec[0] = (double)(s_decw[2] & 1u); s_dec[1] = (double)((s_decw[2] >> 4) & 0xffu); s_dec[3] = (double)((s_decw[2] >> 12) & 1u);
+        s_dec[2] = __hiloint2double((int)s_decw[0], (int)s_decw[1]);
+      }
+      __syncthreads();
     }
+    int final_pass = 0;
     if (!skip && P.debug_stop == 6) break;
     if (!skip) {
       const int new_cur = (int)s_dec[0];
