@@ -1276,8 +1276,10 @@ __device__ __forceinline__ void sample_wg(SampleParams& p, SampleSmem<R, WAVES>&
   FusedIdx fi{make_int4(0, 0, 0, 0), 0, 0, 0, 0};
   if constexpr (RES) { fi.ti = rl.ti; fi.pt = rl.pt; fi.slot = rl.slot; fi.l0 = rl.l0; fi.cnt = rl.cnt; }
   else if (FUSED) fi = fused_prefetch_indices<WAVES * 64>(p, bid, tix);
-  stage_geom<WAVES * 64, RES>(p.geom, s_geom, p.n_frames, tix);
-  if (FUSED) fused_stage_step_table<WAVES * 64, RES>(p, s_bk, tix);
+  // (resident solve, step trips: p.geom == null -- the candidate table is in `geom_lds` already, polled there from the solve's tagged words,
+  // and geom_prev / delta_c name LDS copies; its first linearisation stages the initial table from global memory like everybody else)
+  if (!RES || p.geom) stage_geom<WAVES * 64, RES>(p.geom, s_geom, p.n_frames, tix);
+  if (FUSED) fused_stage_step_table<WAVES * 64, false>(p, s_bk, tix);
   lds_barrier();
   PBA_STK(0);
 

@@ -45,7 +45,10 @@ constexpr int kResFlagCount = kResFlagAbort + 1;
 // pass), 64 bytes apart, then one 64-byte line of eight such words per workgroup for its four block partials of the sampling pass
 constexpr size_t kResDecisionOffset = sizeof(unsigned) * kResFlagStride * kResFlagCount;      // bytes
 constexpr size_t kResTagOffset = kResDecisionOffset + 3 * 64;
-constexpr size_t kResSyncBytes = kResTagOffset + (size_t)kResMaxGroups * 64;
+// ... then the solve's output -- camera step (6 doubles per frame) and candidate camera table (CamGeom as 8-byte words) -- as tagged word pairs
+constexpr size_t kResGeoOffset = kResTagOffset + (size_t)kResMaxGroups * 64;
+constexpr int kResGeoDoubles = 6 * kMaxFrames + kMaxFrames * (int)(sizeof(CamGeom) / 8);
+constexpr size_t kResSyncBytes = kResGeoOffset + (size_t)kResGeoDoubles * 16;
 
 struct ResidentParams {
   // ---- problem (device memory) ----
@@ -143,7 +146,7 @@ __global__ __launch_bounds__(kResThreads) void k_resident(ResidentParams P) {
   extern __shared__ __attribute__((aligned(16))) char pool[];
   __shared__ CamGeom s_geomL[2][kMaxFrames];             // camera tables of the two parities, persistent
   __shared__ CamGeom s_gc[kMaxFrames];                   // serial workgroup: candidate table as the solve's epilogue writes it
-  __shared__ double s_dc[6 * kMaxFrames];                // serial workgroup: camera step
+  __shared__ double s_dc[6 * kMaxFrames];                // camera step of the step being taken (serial workgroup: written by the solve's epilogue)
   __shared__ double s_red[kReduceThreads / kReduceEntries][kReduceEntries + 1];
   __shared__ int s_f[16];
   __shared__ double s_r4[4 * WAVES];
@@ -162,6 +165,7 @@ __global__ __launch_bounds__(kResThreads) void k_resident(ResidentParams P) {
   unsigned* sync = P.sync;
   unsigned long long* dec_g = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(sync) + kResDecisionOffset);      // decision words (64 bytes apart)
   unsigned long long* tag_g = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(sync) + kResTagOffset);          // [G][8] tagged block partials
+  unsigned long long* geo_g = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(sync) + kResGeoOffset);          // tagged camera step | candidate table
   unsigned ep = P.epoch0;
   unsigned long long* stamp = (serial && tid0 == 0) ? P.stamp : nullptr;
   if (stamp) stamp[kResStampStart] = __builtin_amdgcn_s_memrealtime();
@@ -227,8 +231,8 @@ __global__ __launch_bounds__(kResThreads) void k_resident(ResidentParams P) {
       SampleParams sp{};
       sp.frames = P.frames; sp.desc = P.desc; sp.w2 = P.w2; sp.rec_stride = P.rec_stride; sp.n_obs = P.n_obs; sp.n_frames = P.n_frames;
       sp.rows = P.rows; sp.cols = P.cols; sp.fx = P.fx; sp.fy = P.fy; sp.cx = P.cx; sp.cy = P.cy; sp.huber = P.huber;
-      sp.delta_c = P.delta_c; sp.block_bs = P.block_bs; sp.n_tiles = P.n_tiles;
-      sp.geom = P.geom[which]; sp.geom_prev = P.geom[cur];
+      sp.delta_c = s_dc; sp.block_bs = P.block_bs; sp.n_tiles = P.n_tiles;
+      sp.geom = skip ? P.geom[which] : nullptr; sp.geom_prev = s_geomL[cur];      // (step trips: both tables and the camera step are in LDS)
       sp.block_cost = P.block_cost[which]; sp.block_fail = P.block_fail[which];
       sp.skip_backsub = skip;
       if (!skip) { sp.res_tag = tag_g; sp.res_epoch = ep; }
@@ -373,20 +377,41 @@ __global__ __launch_bounds__(kResThreads) void k_resident(ResidentParams P) {
           if (s_lm.done && s_lm.done_seq == 0) s_lm.done_seq = P.seq;
         }
       } else {
-        // camera step and candidate table -> global memory, write-through (every workgroup reads them behind the flag)
-        for (int k = tid; k < 6 * P.n_frames; k += kResThreads) store_agent(P.delta_c + k, s_dc[k]);
+        // camera step and candidate table -> every workgroup, as self-validating word pairs (epoch << 32 | half a double: fire and forget, the
+        // consumers poll the data itself); the serial workgroup's own copies go LDS -> LDS; the table in global memory (plain stores) is for
+        // the calls behind pba_solve
         const int words = P.n_frames * (int)(sizeof(CamGeom) / 8);
-        const unsigned long long* src = reinterpret_cast<const unsigned long long*>(s_gc);
-        unsigned long long* dst = reinterpret_cast<unsigned long long*>(P.geom[1 - cur]);
-        for (int k = tid; k < words; k += kResThreads) __hip_atomic_store(dst + k, src[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double* src = reinterpret_cast<const double*>(s_gc);
+        double* mine = reinterpret_cast<double*>(s_geomL[1 - cur]);
+        double* glob = reinterpret_cast<double*>(P.geom[1 - cur]);
+        for (int k = tid; k < 6 * P.n_frames; k += kResThreads) store_tagged(geo_g + 2 * k, ep, s_dc[k]);
+        for (int k = tid; k < words; k += kResThreads) {
+          const double v = src[k];
+          store_tagged(geo_g + 2 * (6 * kMaxFrames + k), ep, v);
+          mine[k] = v; glob[k] = v;
+        }
         if (stamp) stamp[kResStampSolved] = __builtin_amdgcn_s_memrealtime();
-        arrive(kResFlagGo3);
       }
     }
     if (final_pass || P.debug_stop == 4) break;
     // ---- everybody: the camera step is there ------------------------------------------------------------------------------------------
-    if (!serial && !res_wait(sync, kResFlagGo3, 1, ep, P.timeout_ticks)) { ok = false; break; }
-    __syncthreads();                                    // the pool changes hands: Schur tiles / solve -> sampling
+    if (!serial) {
+      const int words = P.n_frames * (int)(sizeof(CamGeom) / 8);
+      double* tab = reinterpret_cast<double*>(s_geomL[1 - cur]);
+      auto tables = [&]() -> bool {
+        bool behind = false;
+        for (int k = tid; k < 6 * P.n_frames + words; k += kResThreads) {
+          const bool is_dc = k < 6 * P.n_frames;
+          const int idx = is_dc ? k : 6 * kMaxFrames + (k - 6 * P.n_frames);
+          double v;
+          if (!load_tagged(geo_g + 2 * idx, ep, v)) behind = true;
+          if (is_dc) s_dc[k] = v; else tab[k - 6 * P.n_frames] = v;
+        }
+        return behind;
+      };
+      if (!res_poll(sync, P.timeout_ticks, tables)) { ok = false; break; }
+    }
+    __syncthreads();                                    // the pool changes hands: Schur tiles / solve -> sampling; the tables are in LDS
     which = 1 - cur; skip = 0;
   }
   // ---- state back to global memory for the calls behind pba_solve (pba_get_state, pba_get_obs_records, pba_step) -----------------
