@@ -592,15 +592,10 @@ int pba_create(const pba_config* cfg, pba_engine** out) {
   // loads this library's code object now rather than at the first frame (10+ ms in a process that has not touched it yet)
   hipLaunchKernelGGL(k_noop, dim3(1), dim3(64), 0, e->stream);
   if (hipGetLastError() != hipSuccess) return bail(PBA_ERR_HIP);
-  if (e->use_resident && e->coop_launch) {
-    // ... and the first COOPERATIVE launch of a process (the resident solve's kind) sets up its own queue, ~10 ms: paid here, not by the
-    // first optimize().  A refusal only switches the resident driver off (the pipelined one serves everything).
-    void* no_args[] = {nullptr};
-    if (hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&k_noop), dim3(1), dim3(64), no_args, 0, e->stream) != hipSuccess) {
-      (void)hipGetLastError();
-      e->use_resident = false;
-    }
-  }
+  // (The first COOPERATIVE launch of a process -- the resident solve's kind -- sets up a queue of its own, ~10 ms.  It is NOT paid here:
+  // a cooperative queue is exclusive on the device, so two processes that share one GPU -- two ranks on one device in the tests -- then
+  // time-slice at ~20 ms per LM step (measured: 139 us -> 22.5 ms), and rocprofv3 crashes in its exit handlers once a process has made
+  // a cooperative launch (its output files are complete by then).  The first resident solve pays it; multi-rank engines never make one.)
   if (hipStreamSynchronize(e->stream) != hipSuccess) return bail(PBA_ERR_HIP);
   *out = e;
   return PBA_OK;

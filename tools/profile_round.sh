@@ -6,6 +6,7 @@ TAG=${1:-final}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
+# (configs[1] runs on the pipelined driver; rocprofv3 crashes in its exit handlers -- after its output is written -- in a process that made a cooperative launch)
 BENCH="python $OLDPWD/bench.py --no-cpu-baseline --repeats 3"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o s -- $BENCH > "$OUT/bench_under_rocprof.json" 2> /dev/null
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o f -- $BENCH > /dev/null 2>&1

@@ -1,4 +1,5 @@
-"""Dev tool: soak run of the asynchronous LM pipeline (python tools/soak.py [seconds] [steps]).  One engine, BASELINE configs[1]; the
+"""Dev tool: soak run of the LM drivers (python tools/soak.py [seconds] [steps] [small]).  One engine, BASELINE configs[1] -- or, with a third
+argument, the reference's operating point (5 frames x 5 000 points x 3x3: the RESIDENT driver, one cooperative launch per solve); the
 same window is solved over and over for the given wall time; every solve must return the bits of the first one (final cost,
 cameras, iteration log), device memory in use must not grow, and the per-solve time distribution is printed."""
 import os, sys, time
@@ -12,7 +13,9 @@ from photobundle_amd.engine import Engine, default_solver_options
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-    prob = synthetic.make_window(n_frames=8, n_points=50000, radius=2, visibility="dense")
+    small = len(sys.argv) > 3
+    prob = (synthetic.make_window(n_frames=5, n_points=5000, radius=1, visibility="dense") if small else
+            synthetic.make_window(n_frames=8, n_points=50000, radius=2, visibility="dense"))
     eng = Engine(prob.planes.shape[2], prob.planes.shape[3], prob.K, prob.radius, max_frames=prob.cams.shape[0], huber=prob.huber)
     eng.load(prob)
     o = default_solver_options(max_num_iterations=steps, function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0)
@@ -36,6 +39,7 @@ def main():
         n += 1
     free1 = torch.cuda.mem_get_info()[0]
     t = np.sort(np.array(times[1:])) * 1e3
+    print("driver of the last solve: %s" % eng.solve_driver())
     print("%d solves of %d LM iterations in %.0f s, all bit-identical (final cost %.9e); ms per solve incl. read-back: min %.3f  p50 %.3f  "
           "p99 %.3f  max %.3f; device memory in use grew by %d bytes" % (n, steps, budget, first[0], t[0], t[len(t) // 2], t[int(0.99 * len(t))], t[-1], free0 - free1))
     eng.close()
