@@ -1824,6 +1824,13 @@ int pba_internal_async_wait(pba_engine* e, unsigned long long seq) {
 
 // ---- resident solve ------------------------------------------------------------------------------------------------
 
+// A resident launch that left without publishing: one of its device-side waits timed out (a lost hand-over) and raised the abort word, which
+// stays raised -- like every timed-out wait, this poisons the engine (later calls fail fast, pba_destroy does not wait for the stream).
+void pba_internal_resident_failed(pba_engine* e) {
+  e->poisoned = true;
+  e->err += " -- the resident solve ended without publishing (a device-side wait timed out); the engine is unusable, destroy it";
+}
+
 // PBA_RES_TRACE: phase intervals of the serial workgroup (100 MHz stamps), averaged over the steps of the last resident solve
 void pba_internal_resident_trace(pba_engine* e, int iterations) {
   static const bool res_trace = getenv("PBA_RES_TRACE") != nullptr;

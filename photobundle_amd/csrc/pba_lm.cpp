@@ -34,7 +34,7 @@ static int solve_resident(pba_engine* e, const pba_solver_options* o, pba_solver
   unsigned long long seq = 0;
   int rc = pba_internal_resident_launch(e, o, &seq);
   if (rc) return rc;
-  if ((rc = pba_internal_async_wait(e, seq))) return rc;
+  if ((rc = pba_internal_async_wait(e, seq))) { pba_internal_resident_failed(e); return rc; }
   if ((rc = pba_internal_async_end(e))) return rc;
   const pba::LmState* st = static_cast<const pba::LmState*>(pba_internal_async_state(e));
   pba_internal_resident_trace(e, st->iteration);

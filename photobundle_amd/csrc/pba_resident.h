@@ -99,13 +99,16 @@ __device__ __forceinline__ bool res_wait(unsigned* sync, int first, int n, unsig
     if (threadIdx.x == kResThreads - 1 && (++spins & 63u) == 0) {
       if (__hip_atomic_load(sync + (size_t)kResFlagAbort * kResFlagStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) vote |= 2;
       if (__builtin_amdgcn_s_memrealtime() - t0 > timeout_ticks) {
+#ifdef PBA_RES_DEBUG_PRINT
+        printf("wg %d: wait timed out\n", (int)blockIdx.x);
+#endif
         res_flag_set(sync, kResFlagAbort, 1u);
         vote |= 2;
       }
     }
-    const int r = __syncthreads_or(vote);
-    if (r & 2) return false;
-    if (r == 0) return true;
+    // (__syncthreads_or returns a PREDICATE, not the OR of the values: two collectives -- the second only while somebody is still behind)
+    if (!__syncthreads_or(vote)) return true;
+    if (__syncthreads_or(vote & 2)) return false;
   }
 }
 
@@ -120,13 +123,16 @@ __device__ __forceinline__ bool res_poll(unsigned* sync, unsigned long long time
     if (threadIdx.x == kResThreads - 1 && (++spins & 63u) == 0) {
       if (__hip_atomic_load(sync + (size_t)kResFlagAbort * kResFlagStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) vote |= 2;
       if (__builtin_amdgcn_s_memrealtime() - t0 > timeout_ticks) {
+#ifdef PBA_RES_DEBUG_PRINT
+        printf("wg %d: wait timed out\n", (int)blockIdx.x);
+#endif
         res_flag_set(sync, kResFlagAbort, 1u);
         vote |= 2;
       }
     }
-    const int r = __syncthreads_or(vote);
-    if (r & 2) return false;
-    if (r == 0) return true;
+    // (__syncthreads_or returns a PREDICATE, not the OR of the values: two collectives -- the second only while somebody is still behind)
+    if (!__syncthreads_or(vote)) return true;
+    if (__syncthreads_or(vote & 2)) return false;
   }
 }
 
@@ -340,6 +346,9 @@ __global__ __launch_bounds__(kResThreads) void k_resident(ResidentParams P) {
       if (stamp) stamp[kResStampSchurBody] = __builtin_amdgcn_s_memrealtime();
     }
     if (P.debug_stop == 2) break;
+    // (fault injection, PBA_RES_STOP=100, tests/test_gpu_resident.py: in the second step the last workgroup keeps its flag to itself -- every
+    // wait that depends on it must end in the time-out / abort path, the kernel must leave, the host must report an error instead of hanging)
+    if (!(P.debug_stop == 100 && it == 1 && w == G - 1 && !serial))
     arrive(kResFlagArrive1 + w);
     if (stamp) stamp[kResStampSchur] = __builtin_amdgcn_s_memrealtime();
     // ---- reduction of the per-tile partials: virtual blocks w, w + G, ... of the reduction grid -----------------------------------
@@ -414,6 +423,9 @@ __global__ __launch_bounds__(kResThreads) void k_resident(ResidentParams P) {
     __syncthreads();                                    // the pool changes hands: Schur tiles / solve -> sampling; the tables are in LDS
     which = 1 - cur; skip = 0;
   }
+#ifdef PBA_RES_DEBUG_PRINT
+  if (threadIdx.x == 0 && !ok) printf("wg %d (w %d) leaves the loop, ok %d it %d\n", (int)blockIdx.x, w, (int)ok, it);
+#endif
   // ---- state back to global memory for the calls behind pba_solve (pba_get_state, pba_get_obs_records, pba_step) -----------------
   if (active) {
     if ((tid0 & 127) == rl.l0) {

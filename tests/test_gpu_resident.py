@@ -115,3 +115,42 @@ def test_resident_solve_against_the_oracle():
         assert a["step_is_successful"] == b["step_is_successful"]
         assert abs(a["cost"] - b["cost"]) <= 1e-9 * abs(a["cost"]), (a["cost"], b["cost"])
     assert float(np.abs(res["cams"] - ref["cams"]).max()) <= 1e-5
+
+
+def test_a_lost_hand_over_ends_in_an_error_not_in_a_hang():
+    """Every wait of the resident kernel is bounded: with a flag deliberately withheld (fault injection, PBA_RES_STOP=100: in the second step
+    the last workgroup keeps its arrival flag to itself) the dependent waits time out on the device, the abort word makes every workgroup
+    leave, the host finds a finished stream without a published result and returns an error; the engine is unusable afterwards (fails
+    fast) -- nothing hangs."""
+    code = textwrap.dedent("""
+        import sys, time
+        sys.path.insert(0, %r)
+        from photobundle_amd import synthetic
+        from photobundle_amd.engine import Engine, EngineError, default_solver_options
+        p = synthetic.make_window(n_frames=5, n_points=2000, radius=1, size=(188, 621), K=(359.4, 359.4, 303.6, 92.6))
+        e = Engine(188, 621, p.K, p.radius, p.n_frames, huber=p.huber)
+        e.load(p)
+        t0 = time.time()
+        try:
+            e.solve(default_solver_options(max_num_iterations=6))
+            print("RESULT no error")
+        except EngineError as exc:
+            print("RESULT error after %%.1f s: %%s" %% (time.time() - t0, exc))
+        t0 = time.time()
+        try:
+            e.solve(default_solver_options(max_num_iterations=6))
+            print("SECOND no error")
+        except EngineError as exc:
+            print("SECOND error after %%.3f s: %%s" %% (time.time() - t0, exc))
+        e.close()
+    """ % ROOT)
+    env = dict(os.environ, PBA_RESIDENT="1", PBA_RES_STOP="100", PBA_WAIT_TIMEOUT_S="4")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    first = [l for l in r.stdout.splitlines() if l.startswith("RESULT")][0]
+    second = [l for l in r.stdout.splitlines() if l.startswith("SECOND")][0]
+    print(first)
+    print(second)
+    assert first.startswith("RESULT error after") and "without publishing" in first, first
+    assert float(first.split()[3]) < 30.0
+    assert second.startswith("SECOND error after") and "unusable" in second and float(second.split()[3]) < 1.0, second
