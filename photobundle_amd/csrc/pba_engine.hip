@@ -124,7 +124,8 @@ struct pba_engine {
   // resident solve (pba_resident.h): one cooperative launch per pba_solve when the window fits one resident round of workgroups
   bool use_resident = true;         // PBA_RESIDENT=0 disables
   unsigned* d_res_sync = nullptr;   // flag block (kResSyncBytes), zeroed once: epochs grow from launch to launch
-  unsigned res_epoch = 1;
+  unsigned res_epoch = 1;           // first epoch of the next resident launch
+  unsigned res_epoch_launch = 1;    // ... of the one in flight / last finished
   int res_groups_max[2][2] = {{-1, -1}, {-1, -1}};   // [radius - 1][unit weights]: co-resident workgroups of k_resident (-1: not asked yet, 0: none)
   int res_groups_n[2][2] = {{-1, -1}, {-1, -1}};     // ... the reduced-system size that answer was given for
   int n_cus = 0, coop_launch = 0;
@@ -1831,6 +1832,10 @@ void pba_internal_resident_failed(pba_engine* e) {
   e->err += " -- the resident solve ended without publishing (a device-side wait timed out); the engine is unusable, destroy it";
 }
 
+void pba_internal_resident_done(pba_engine* e, int iterations) {
+  e->res_epoch = e->res_epoch_launch + (unsigned)std::max(0, iterations) + 8u;
+}
+
 // PBA_RES_TRACE: phase intervals of the serial workgroup (100 MHz stamps), averaged over the steps of the last resident solve
 void pba_internal_resident_trace(pba_engine* e, int iterations) {
   static const bool res_trace = getenv("PBA_RES_TRACE") != nullptr;
@@ -1922,7 +1927,10 @@ int pba_internal_resident_launch(pba_engine* e, const pba_solver_options* o, uns
   P.cur0 = e->cur; P.max_num_iterations = o->max_num_iterations;
   P.fx = e->cfg.fx; P.fy = e->cfg.fy; P.cx = e->cfg.cx; P.cy = e->cfg.cy; P.huber = e->cfg.huber;
   P.min_diag = o->min_lm_diagonal; P.max_diag = o->max_lm_diagonal; P.radius0 = o->initial_trust_region_radius;
+  // epochs: one per step trip; the launch reserves max_num_iterations + 8 of them, pba_internal_resident_done hands back what the solve did not use
+  // (the reference's 500-iteration limit against ~30 iterations actually taken: the 32-bit epochs then last ten times longer)
   P.sync = e->d_res_sync; P.epoch0 = e->res_epoch;
+  e->res_epoch_launch = e->res_epoch;
   e->res_epoch += (unsigned)std::max(0, o->max_num_iterations) + 8u;
   // every device-side wait is bounded (a lost flag must not hang the GPU): well below the host watchdog and the compute-queue's own
   P.timeout_ticks = (unsigned long long)(std::min(2.0, 0.25 * e->wait_timeout_s) * e->tick_hz);

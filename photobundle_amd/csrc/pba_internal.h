@@ -28,6 +28,7 @@ int pba_internal_async_end(pba_engine* e);
 // resident solve (pba_resident.h): the whole pba_solve as ONE cooperative launch
 int pba_internal_resident_capable(pba_engine* e, const pba_solver_options* o);
 int pba_internal_resident_launch(pba_engine* e, const pba_solver_options* o, unsigned long long* seq_out);
+void pba_internal_resident_done(pba_engine* e, int iterations);   /* the solve took `iterations` step trips: unused epochs go back */
 void pba_internal_resident_failed(pba_engine* e);   /* a resident launch ended without publishing (device-side wait timed out): the engine is unusable */
 void pba_internal_resident_trace(pba_engine* e, int iterations);   /* PBA_RES_TRACE: phase intervals of the last resident solve to stderr */
 int pba_internal_final_flushes(const pba_engine* e);   /* 1: the kind-2 enqueue also flushes (no kind 3 behind it) */

@@ -37,6 +37,7 @@ static int solve_resident(pba_engine* e, const pba_solver_options* o, pba_solver
   if ((rc = pba_internal_async_wait(e, seq))) { pba_internal_resident_failed(e); return rc; }
   if ((rc = pba_internal_async_end(e))) return rc;
   const pba::LmState* st = static_cast<const pba::LmState*>(pba_internal_async_state(e));
+  pba_internal_resident_done(e, st->iteration);
   pba_internal_resident_trace(e, st->iteration);
   // one Jacobian pass at the initial point + one (speculative) Jacobian pass per step taken
   return summarize_device_solve(e, o, sum, its, max_out, t_start, verbose, 1 + (int64_t)st->iteration);
