@@ -1959,7 +1959,22 @@ int pba_internal_resident_launch(pba_engine* e, const pba_solver_options* o, uns
   }
   const int groups = (e->n_tiles + 1) / 2;
   void* args[] = {&P};
-  HIP_TRY(e, hipLaunchCooperativeKernel(resident_kernel_for(e), dim3(groups), dim3(kResThreads), args, (unsigned)resident_pool_for(e), e->stream));
+  // A cooperative launch can be REFUSED by the runtime before anything runs (the grid does not fit the co-residency this process is
+  // granted on this device: CU masks, partition modes, a queue limit).  That is not an error of the solve: the epochs and the sequence
+  // number go back, this engine stays on the pipelined driver from here on and the caller runs the same solve there (same device
+  // functions, same bits).  PBA_RES_REFUSE=1 injects the refusal (tests/test_gpu_resident.py).
+  const char* inject = getenv("PBA_RES_REFUSE");
+  const hipError_t le = (inject && atoi(inject) != 0) ? hipErrorCooperativeLaunchTooLarge
+      : hipLaunchCooperativeKernel(resident_kernel_for(e), dim3(groups), dim3(kResThreads), args, (unsigned)resident_pool_for(e), e->stream);
+  if (le != hipSuccess) {
+    (void)hipGetLastError();
+    e->res_epoch = e->res_epoch_launch;
+    e->seq = seq - 1;
+    e->use_resident = 0;
+    std::fprintf(stderr, "[pba] cooperative launch of %d workgroups refused (%s): this engine solves on the pipelined driver from here on\n", groups,
+                 hipGetErrorString(le));
+    return PBA_INTERNAL_RESIDENT_REFUSED;
+  }
   e->res_launches++;
   e->last_driver = 1;
   e->stamp_iter = o->max_num_iterations;

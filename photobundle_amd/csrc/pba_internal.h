@@ -27,6 +27,9 @@ const pba_iteration_summary* pba_internal_async_log(const pba_engine* e);
 int pba_internal_async_end(pba_engine* e);
 // resident solve (pba_resident.h): the whole pba_solve as ONE cooperative launch
 int pba_internal_resident_capable(pba_engine* e, const pba_solver_options* o);
+/* PBA_INTERNAL_RESIDENT_REFUSED: the runtime refused the cooperative launch before anything ran -- nothing changed, the engine has left the
+   resident driver for good and the caller runs the solve on the pipelined one */
+#define PBA_INTERNAL_RESIDENT_REFUSED (-1000)
 int pba_internal_resident_launch(pba_engine* e, const pba_solver_options* o, unsigned long long* seq_out);
 void pba_internal_resident_done(pba_engine* e, int iterations);   /* the solve took `iterations` step trips: unused epochs go back */
 void pba_internal_resident_failed(pba_engine* e);   /* a resident launch ended without publishing (device-side wait timed out): the engine is unusable */

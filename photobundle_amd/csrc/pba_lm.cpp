@@ -29,10 +29,14 @@ static int summarize_device_solve(pba_engine* e, const pba_solver_options* o, pb
 
 // Resident variant (pba_resident.h): the whole solve is ONE cooperative launch -- every workgroup keeps its tiles' state in registers
 // across the iterations, the serial workgroup takes the same decisions (lm_decide) -- and the host only waits for the flush.
+static int solve_async(pba_engine* e, const pba_solver_options* o, pba_solver_summary* sum, pba_iteration_summary* its,
+                       int32_t max_out, double t_start, bool verbose);
+
 static int solve_resident(pba_engine* e, const pba_solver_options* o, pba_solver_summary* sum, pba_iteration_summary* its,
                           int32_t max_out, double t_start, bool verbose) {
   unsigned long long seq = 0;
   int rc = pba_internal_resident_launch(e, o, &seq);
+  if (rc == PBA_INTERNAL_RESIDENT_REFUSED) return solve_async(e, o, sum, its, max_out, t_start, verbose);
   if (rc) return rc;
   if ((rc = pba_internal_async_wait(e, seq))) { pba_internal_resident_failed(e); return rc; }
   if ((rc = pba_internal_async_end(e))) return rc;

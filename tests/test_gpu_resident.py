@@ -154,3 +154,33 @@ def test_a_lost_hand_over_ends_in_an_error_not_in_a_hang():
     assert first.startswith("RESULT error after") and "without publishing" in first, first
     assert float(first.split()[3]) < 30.0
     assert second.startswith("SECOND error after") and "unusable" in second and float(second.split()[3]) < 1.0, second
+
+
+def test_a_refused_cooperative_launch_falls_back_to_the_pipelined_driver():
+    """The runtime may refuse a cooperative launch before anything runs (co-residency granted to the process: CU masks, partition modes).
+    PBA_RES_REFUSE=1 injects that refusal: the SAME pba_solve call then runs on the pipelined driver (reported as such), with the bits the
+    resident solve produces; the engine stays there for later solves."""
+    from photobundle_amd import synthetic
+    from photobundle_amd.engine import Engine, default_solver_options
+    wkw, skw = CASES[1]
+    p = synthetic.make_window(**wkw)
+    rows, cols = wkw["size"]
+    out = []
+    for refuse in (False, True):
+        with Engine(rows, cols, p.K, p.radius, p.n_frames, huber=p.huber) as e:
+            e.load(p)
+            if refuse:
+                os.environ["PBA_RES_REFUSE"] = "1"
+            try:
+                r = e.solve(default_solver_options(**skw))
+            finally:
+                os.environ.pop("PBA_RES_REFUSE", None)
+            drivers = [e.solve_driver()]
+            r2 = e.solve(default_solver_options(**skw))     # (no injection any more: a refused engine does not try again)
+            drivers.append(e.solve_driver())
+            out.append((drivers, r, r2))
+    assert out[0][0] == ["resident", "resident"] and out[1][0] == ["pipelined", "pipelined"], (out[0][0], out[1][0])
+    for k in (1, 2):
+        a, b = out[0][k], out[1][k]
+        assert [i["cost"] for i in a["iterations"]] == [i["cost"] for i in b["iterations"]]
+        assert a["cams"].tobytes() == b["cams"].tobytes() and a["xyz"].tobytes() == b["xyz"].tobytes()
