@@ -362,8 +362,8 @@ def step_accuracy(p, iterations):
         (block_step) of the same elimination -- the conditioning-free measure;
       * forward error of the camera step against the extended-precision step, again next to the float64 restatement's (on these
         windows the 3x3 point blocks at 0.01 m baselines amplify rounding to 1e-10 .. 1e-5 of the step for ANY double algorithm).
-    Returns per iteration dict(it, cond, bwd_engine, bwd_f64, fwd_engine, fwd_f64, fwd_f64_band, data_shift); fwd_f64_band = the largest
-    forward error of five double-precision evaluations (records as they are + four one-ulp copies); data_shift = how far the 1e-15
+    Returns per iteration dict(it, cond, bwd_engine, bwd_f64, bwd_f64_band, fwd_engine, fwd_f64, fwd_f64_band, data_shift); *_band = the largest
+    backward / forward error of five double-precision evaluations (records as they are + four one-ulp copies); data_shift = how far the 1e-15
     differences between the engine's and the oracle's evaluation of the blocks move the extended-precision step."""
     free = [c for c in range(p.n_frames) if c != p.fixed_slot]
     rows = []
@@ -390,14 +390,20 @@ def step_accuracy(p, iterations):
             # sweep the same restatement sat at 2.8e-9 on the round-4 build's records and at 6.0e-11 on round 5's (the records differ in
             # the last bits), the engine at 4.6e-9 both times.  The band a double algorithm may use is therefore taken from an ENSEMBLE:
             # the restatement on the records as they are and on four copies moved by one ulp (seeded signs).
+            # The same holds for the BACKWARD error from the second iteration on (r6, window 671 of the 1 000-case sweep, 13 frames x 11x11,
+            # cond(S) 433, iteration 1: the restatement sits at 8.3e-14 on the round-6 build's records and at 1.6e-12 on round 5's -- last-bit
+            # differences of the records -- the engine at 1.6e-12 and 5.7e-13: profiles/r06/arbiter_case_671.txt), so its band comes from the
+            # same five evaluations.
             fwd_draws = [float(np.abs(d_d - d_x).max() / nrm)]
+            bwd_draws = [backward_error(p, bx, radius, scale_x, d_d, dp_d)]
             rng = np.random.default_rng(1000 * it + 17)
             for _ in range(4):
                 rec_k = rec * (1.0 + np.ldexp(1.0, -52) * rng.choice([-1.0, 1.0], size=rec.shape))
-                d_k, _, _, _ = block_step(p, record_blocks(p, rec_k, c0, x0, np.float64), radius, scale_d_prev, np.float64)
+                d_k, _, _, dp_k = block_step(p, record_blocks(p, rec_k, c0, x0, np.float64), radius, scale_d_prev, np.float64)
                 fwd_draws.append(float(np.abs(d_k - d_x).max() / nrm))
+                bwd_draws.append(backward_error(p, bx, radius, scale_x, d_k, dp_k))
             rows.append(dict(it=it, cond=float(np.linalg.cond(S.astype(np.float64))),
-                             bwd_engine=backward_error(p, bx, radius, scale_x, d_e, dp_e), bwd_f64=backward_error(p, bx, radius, scale_x, d_d, dp_d),
+                             bwd_engine=backward_error(p, bx, radius, scale_x, d_e, dp_e), bwd_f64=bwd_draws[0], bwd_f64_band=max(bwd_draws),
                              fwd_engine=float(np.abs(d_e - d_x).max() / nrm), fwd_f64=fwd_draws[0], fwd_f64_band=max(fwd_draws),
                              data_shift=float(np.abs(d_o - d_x).max() / nrm)))
             scale_x = scale_x1

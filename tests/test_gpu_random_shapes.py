@@ -43,6 +43,8 @@ def _draw_cases(n, seed=20260928):
 
 
 CASES = _draw_cases(int(os.environ.get("PBA_RANDOM_CASES", "24")))      # the first 24 of the seeded sequence by default; more on request
+if os.environ.get("PBA_RANDOM_FIRST"):      # replay aid: skip the head of the sequence (the rarity check below then skips itself)
+    CASES = CASES[int(os.environ["PBA_RANDOM_FIRST"]):]
 
 
 def _make(c):
@@ -68,8 +70,8 @@ RAN = []             # seed offsets of the cases that ran to the end in THIS pro
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("case", CASES, ids=["%02d-f%d-r%d-c%d-%s%s" % (i, c["n_frames"], c["radius"], c["channels"], c["visibility"], "-ragged" if c["ragged"] else "")
-                                             for i, c in enumerate(CASES)])
+@pytest.mark.parametrize("case", CASES, ids=["%02d-f%d-r%d-c%d-%s%s" % (c["seed_offset"] - 100, c["n_frames"], c["radius"], c["channels"], c["visibility"], "-ragged" if c["ragged"] else "")
+                                             for c in CASES])
 def test_random_shape(case):
     print("case:", case)
     p = _make(case)
@@ -125,7 +127,9 @@ def test_random_shape(case):
             # elimination: over 130 (window, iteration) samples of the sweep the two track each other -- engine 1e-17 .. 2.3e-11, float64
             # 1e-17 .. 4.7e-11, ratio <= 4.2 (profiles/r04/random_sweep_r3_vs_r4.txt); a 1e-6 slip of the damping shows as 5e-11 where
             # the restatement sits at 1e-15 (tests/test_step_arbiter_cpu.py)
-            assert r["bwd_engine"] <= 10.0 * r["bwd_f64"] + 1e-14, r
+            # (r6: against the BAND of five double-precision evaluations, like the forward error below -- one draw of the restatement's own
+            # backward error moves by 20x with the last bits of the records: gpu_util.step_accuracy)
+            assert r["bwd_engine"] <= 10.0 * r["bwd_f64_band"] + 1e-14, r
             # ... and its FORWARD error (camera step against the extended-precision step of the same records) stays within a stated
             # factor of the float64 restatement's at every arbitrated iteration: the pose bar that remains when the oracle-twin bars
             # are left (VERDICT r4 #4b) -- a step that is farther from the exact one than any double algorithm would be is a defect

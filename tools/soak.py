@@ -22,6 +22,7 @@ def main():
     first, times, n = None, [], 0
     free0 = None
     t_end = time.time() + budget
+    t_mark, marks = time.time() + budget / 10.0, []
     while time.time() < t_end:
         eng.set_problem(prob.xyz, prob.desc, prob.obs_point, prob.obs_slot, prob.weights)
         eng.set_cameras(prob.cams, prob.fixed_slot)
@@ -37,13 +38,20 @@ def main():
             print("solve %d differs from the first: final cost %r vs %r" % (n, res["final_cost"], first[0]))
             sys.exit(1)
         n += 1
+        if time.time() >= t_mark:      # growth of the device memory in use along the run (a leak grows with the solves, a one-off pool growth does not)
+            marks.append((n, free0 - torch.cuda.mem_get_info()[0]))
+            t_mark += budget / 10.0
     free1 = torch.cuda.mem_get_info()[0]
     t = np.sort(np.array(times[1:])) * 1e3
     print("driver of the last solve: %s" % eng.solve_driver())
     print("%d solves of %d LM iterations in %.0f s, all bit-identical (final cost %.9e); ms per solve incl. read-back: min %.3f  p50 %.3f  "
           "p99 %.3f  max %.3f; device memory in use grew by %d bytes" % (n, steps, budget, first[0], t[0], t[len(t) // 2], t[int(0.99 * len(t))], t[-1], free0 - free1))
+    print("memory growth along the run (solves, bytes): %s" % marks)
     eng.close()
-    sys.exit(0 if free0 - free1 <= (1 << 20) else 2)
+    # a leak grows with the solves; the runtime's own pools grow once or twice early on (measured: +2 MiB after ~30 k and ~50 k cooperative
+    # launches, then flat for 140 k more: profiles/r06/soak_resident_330s.txt) -- the second half of the run must not grow
+    half = marks[len(marks) // 2 - 1][1] if len(marks) >= 2 else 0
+    sys.exit(0 if (free0 - free1) - half <= (1 << 20) else 2)
 
 
 main()
