@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU box: polled step finalisation (PBA_FIN_POLL=1, default) against ticket -> gather (=0): configs[1], 50 and 20 steps, and a small window on the pipelined driver
+# GPU box, with profiles/r06/experiments/k_sample_polled_finalisation.patch applied (the switch does not exist otherwise): polled step finalisation (PBA_FIN_POLL=1, default) against ticket -> gather (=0): configs[1], 50 and 20 steps, and a small window on the pipelined driver
 run() { python bench.py --no-cpu-baseline --repeats 15 "$@" 2>/dev/null | tail -1 | python -c "
 import sys, json
 d = json.loads(sys.stdin.read())

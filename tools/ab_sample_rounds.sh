@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU box, EXPERIMENT lib (PBA_LIB): k_sample's 1.53 rounds of workgroups (1563 blocks over 1024 slots) against (a) 3 workgroups per CU via
+# GPU box, EXPERIMENT lib (PBA_LIB) = a build with profiles/r06/experiments/k_sample_rounds_pair_pad.patch applied: k_sample's 1.53 rounds of workgroups (1563 blocks over 1024 slots) against (a) 3 workgroups per CU via
 # unused dynamic LDS at a window of 1532 blocks (= 2 x 766), (b) a paired launch: 784 workgroups running two blocks each
 export PBA_LIB=photobundle_amd/libpba_hip_exp.so
 run() { python bench.py --no-cpu-baseline --steps 50 --warmup 5 --repeats 11 "$@" 2>/dev/null | tail -1 | python -c "
