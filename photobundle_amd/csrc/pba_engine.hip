@@ -124,6 +124,7 @@ struct pba_engine {
   // resident solve (pba_resident.h): one cooperative launch per pba_solve when the window fits one resident round of workgroups
   bool use_resident = true;         // PBA_RESIDENT=0 disables
   unsigned* d_res_sync = nullptr;   // flag block (kResSyncBytes), zeroed once: epochs grow from launch to launch
+  static constexpr unsigned kResEpochLimit = 0xF0000000u;      // the epochs restart (flag block zeroed) before a launch would count beyond this
   unsigned res_epoch = 1;           // first epoch of the next resident launch
   unsigned res_epoch_launch = 1;    // ... of the one in flight / last finished
   int res_groups_max[2][2] = {{-1, -1}, {-1, -1}};   // [radius - 1][unit weights]: co-resident workgroups of k_resident (-1: not asked yet, 0: none)
@@ -558,6 +559,7 @@ int pba_create(const pba_config* cfg, pba_engine** out) {
   if (const char* sv = getenv("PBA_FUSE")) e->fuse = atoi(sv) != 0;
   if (const char* sv = getenv("PBA_ASYNC")) e->use_async = atoi(sv) != 0;
   if (const char* sv = getenv("PBA_RESIDENT")) e->use_resident = atoi(sv) != 0;
+  if (const char* sv = getenv("PBA_RES_EPOCH0")) e->res_epoch = e->res_epoch_launch = (unsigned)strtoul(sv, nullptr, 0);      // test aid: start next to the restart of the epochs
   (void)hipDeviceGetAttribute(&e->n_cus, hipDeviceAttributeMultiprocessorCount, cfg->device);
   (void)hipDeviceGetAttribute(&e->coop_launch, hipDeviceAttributeCooperativeLaunch, cfg->device);
   if ((rc = dev_alloc(e, &e->d_res_sync, kResSyncBytes / sizeof(unsigned)))) return bail(rc);
@@ -1929,9 +1931,16 @@ int pba_internal_resident_launch(pba_engine* e, const pba_solver_options* o, uns
   P.min_diag = o->min_lm_diagonal; P.max_diag = o->max_lm_diagonal; P.radius0 = o->initial_trust_region_radius;
   // epochs: one per step trip; the launch reserves max_num_iterations + 8 of them, pba_internal_resident_done hands back what the solve did not use
   // (the reference's 500-iteration limit against ~30 iterations actually taken: the 32-bit epochs then last ten times longer)
+  // (32-bit epochs: a zeroed word would validate at epoch 0 and a stale one 2^32 epochs -- about a day of back-to-back solves -- later, so long
+  // before the count wraps the block is zeroed again, stream-ordered behind the previous solve, and the count restarts)
+  const unsigned need = (unsigned)std::max(0, o->max_num_iterations) + 8u;
+  if (e->res_epoch > pba_engine::kResEpochLimit - need) {
+    HIP_TRY(e, hipMemsetAsync(e->d_res_sync, 0, kResSyncBytes, e->stream));
+    e->res_epoch = 1;
+  }
   P.sync = e->d_res_sync; P.epoch0 = e->res_epoch;
   e->res_epoch_launch = e->res_epoch;
-  e->res_epoch += (unsigned)std::max(0, o->max_num_iterations) + 8u;
+  e->res_epoch += need;
   // every device-side wait is bounded (a lost flag must not hang the GPU): well below the host watchdog and the compute-queue's own
   P.timeout_ticks = (unsigned long long)(std::min(2.0, 0.25 * e->wait_timeout_s) * e->tick_hz);
   P.lm_init = e->h_lm_dev; P.host_state = e->h_lm_dev; P.log = e->d_log; P.host_log = e->h_log_dev; P.max_log = (int)pba_engine::kMaxLog;

@@ -184,3 +184,31 @@ def test_a_refused_cooperative_launch_falls_back_to_the_pipelined_driver():
         a, b = out[0][k], out[1][k]
         assert [i["cost"] for i in a["iterations"]] == [i["cost"] for i in b["iterations"]]
         assert a["cams"].tobytes() == b["cams"].tobytes() and a["xyz"].tobytes() == b["xyz"].tobytes()
+
+
+def test_the_epochs_restart_long_before_they_wrap():
+    """The hand-over words carry 32-bit epochs that grow from launch to launch; before a launch would count beyond 0xF0000000 the flag block is
+    zeroed and the count restarts at 1.  PBA_RES_EPOCH0 starts an engine 30 epochs short of that: the first solve runs on the high epochs, the
+    second one restarts them, the third is an ordinary one -- all three with the bits of an engine that starts at epoch 1."""
+    from photobundle_amd import synthetic
+    from photobundle_amd.engine import Engine, default_solver_options
+    wkw, skw = CASES[1]
+    p = synthetic.make_window(**wkw)
+    rows, cols = wkw["size"]
+    out = []
+    for epoch0 in (None, 0xF0000000 - 30):
+        if epoch0 is not None:
+            os.environ["PBA_RES_EPOCH0"] = str(epoch0)
+        try:
+            with Engine(rows, cols, p.K, p.radius, p.n_frames, huber=p.huber) as e:
+                runs = []
+                for rep in range(3):
+                    e.load(p)
+                    r = e.solve(default_solver_options(**skw))
+                    assert e.solve_driver() == "resident"
+                    runs.append(([i["cost"] for i in r["iterations"]], r["cams"].tobytes(), r["xyz"].tobytes()))
+                out.append(runs)
+        finally:
+            os.environ.pop("PBA_RES_EPOCH0", None)
+    assert out[0] == out[1]
+    assert out[0][0] == out[0][1] == out[0][2]
