@@ -52,3 +52,20 @@ def test_gaussian_blur_f32_5x5_against_torch_conv(sigma):
     want = F.conv2d(x, (k[:, None] * k[None, :])[None, None])[0, 0].numpy()
     got = oracle.gaussian_blur_f32_5x5(img, sigma)
     assert np.abs(got - want).max() <= 1e-4
+
+
+def test_sample_linear_interior_against_torch_grid_sample():
+    """SampleLinear / SampleWithDerivative (reference src/sample_eigen.h:33-126) inside the image: pixel centres at integer coordinates, the four
+    neighbours blended with (1 - d, d) -- F.grid_sample(align_corners=True) on the three planes (I, Gx, Gy).  The reference's float / double mix
+    moves the result by 1e-5 of the range at most; its rule OUTSIDE [0, n - 1] (truncation towards zero, then clamped taps: positions in
+    (-1, 0) extrapolate) is its own and is pinned by the known-answer tests (tests/test_oracle_kat.py), not here."""
+    rng = np.random.default_rng(5)
+    rows, cols = 37, 53
+    pl = oracle.planes_from_u8(rng.integers(0, 256, (rows, cols)).astype(np.uint8))
+    ys, xs = rng.uniform(0, rows - 1, 3000), rng.uniform(0, cols - 1, 3000)
+    got = np.stack([oracle.sample_linear(pl, y, x) for y, x in zip(ys, xs)]).astype(np.float64)
+    gx = 2.0 * torch.from_numpy(np.float32(xs).astype(np.float64)) / (cols - 1) - 1.0       # (the sampler receives float coordinates)
+    gy = 2.0 * torch.from_numpy(np.float32(ys).astype(np.float64)) / (rows - 1) - 1.0
+    want = F.grid_sample(torch.from_numpy(pl.astype(np.float64))[None], torch.stack([gx, gy], -1)[None, None], mode="bilinear",
+                         padding_mode="border", align_corners=True)[0, :, 0, :].T.numpy()
+    assert np.abs(got - want).max() <= 1e-4
